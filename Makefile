@@ -1,0 +1,30 @@
+# Builds the product library (HIP, gfx950) in-tree.  `make` = product; `make oracle` = CPU checkers.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := vkfft_amd/csrc
+LIBDIR := vkfft_amd/lib
+CXXFLAGS := -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I$(CSRC) -Wno-unused-result
+OBJS := build/obj/api.o build/obj/planner.o build/obj/plan_real.o build/obj/kernels.o
+HDRS := $(wildcard $(CSRC)/*.h) include/vkFFT.h
+
+all: $(LIBDIR)/libvkfft_mi355x.so
+
+build/obj/%.o: $(CSRC)/%.cpp $(HDRS)
+	@mkdir -p build/obj
+	$(HIPCC) $(CXXFLAGS) --offload-arch=$(ARCH) -c $< -o $@
+
+build/obj/kernels.o: $(CSRC)/kernels.hip $(HDRS)
+	@mkdir -p build/obj
+	$(HIPCC) $(CXXFLAGS) --offload-arch=$(ARCH) -c $< -o $@
+
+$(LIBDIR)/libvkfft_mi355x.so: $(OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build/obj $(LIBDIR)/*.so
+
+.PHONY: all oracle clean

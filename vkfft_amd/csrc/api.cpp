@@ -1,0 +1,318 @@
+// C-ABI entry points of libvkfft_mi355x.so — same names, argument meaning and error behaviour as the
+// reference's header-only API:
+//   initializeVkFFT  vkFFT_AppManagement/vkFFT_InitializeApp.h:1468 (+ setConfigurationVkFFT :428)
+//   VkFFTAppend      vkFFT_AppManagement/vkFFT_RunApp.h:79
+//   deleteVkFFT      vkFFT_AppManagement/vkFFT_DeleteApp.h:28
+//   VkFFTGetVersion  vkFFT.h:109, getVkFFTErrorString vkFFT_Structs.h:479
+// There is no CPU fallback anywhere in this library: without a usable HIP device plan creation fails.
+#include "../../include/vkFFT.h"
+#include "engine.h"
+#include <cstdlib>
+#include <cstring>
+#include <cstdio>
+#include <new>
+
+using namespace vkfft_mi355x;
+
+namespace {
+
+struct AppState {
+	void* tempOwned = nullptr;     // temp buffer allocated by the library
+	uint64_t tempOwnedBytes = 0;
+	hipEvent_t* events = nullptr;
+	uint32_t numEvents = 0;
+};
+
+VkFFTResult hip_to_result(hipError_t e, VkFFTResult code) { return e == hipSuccess ? VKFFT_SUCCESS : code; }
+
+void free_direction(VkFFTPlan* pl) {
+	if (!pl) return;
+	DirectionPlan* dp = (DirectionPlan*)pl->impl;
+	if (dp) {
+		if (dp->dArena) (void)hipFree(dp->dArena);
+		delete dp;
+	}
+	free(pl);
+}
+
+VkFFTResult make_direction(VkFFTApplication* app, const TransformDesc& base, bool inverse, VkFFTPlan** outPlan) {
+	VkFFTPlan* pl = (VkFFTPlan*)calloc(1, sizeof(VkFFTPlan));
+	if (!pl) return VKFFT_ERROR_MALLOC_FAILED;
+	DirectionPlan* dp = new (std::nothrow) DirectionPlan();
+	if (!dp) { free(pl); return VKFFT_ERROR_MALLOC_FAILED; }
+	pl->impl = dp;
+	TransformDesc d = base;
+	d.inverse = inverse;
+	int r = build_direction_plan(d, *dp);
+	if (r) { free_direction(pl); return (VkFFTResult)r; }
+	if (!dp->arena.empty()) {
+		if (hipMalloc(&dp->dArena, dp->arena.size()) != hipSuccess) { free_direction(pl); return VKFFT_ERROR_FAILED_TO_ALLOCATE; }
+		if (hipMemcpy(dp->dArena, dp->arena.data(), dp->arena.size(), hipMemcpyHostToDevice) != hipSuccess) { free_direction(pl); return VKFFT_ERROR_FAILED_TO_COPY; }
+	}
+	for (uint64_t i = 0; i < app->configuration.FFTdim; i++) {
+		pl->numAxisUploads[i] = dp->uploadsPerAxis[i];
+		for (int k = 0; k < 4; k++) pl->axisSplit[i][k] = dp->axisSplit[i][k];
+		for (uint64_t k = 0; k < VKFFT_MAX_FFT_DIMENSIONS; k++) pl->actualFFTSizePerAxis[i][k] = app->configuration.size[k];
+		if (app->configuration.FFTdim == 1 && app->actualNumBatches > 1) pl->actualFFTSizePerAxis[i][1] = app->actualNumBatches;
+		pl->actualPerformR2CPerAxis[i] = (i == 0) ? app->configuration.performR2C : 0;
+	}
+	*outPlan = pl;
+	return VKFFT_SUCCESS;
+}
+
+} // namespace
+
+extern "C" {
+
+VKFFT_API int VkFFTGetVersion(void) { return 10304; }
+
+VKFFT_API void vkfftMI355XStructSizes(pfUINT out[4]) {
+	out[0] = sizeof(VkFFTConfiguration);
+	out[1] = sizeof(VkFFTLaunchParams);
+	out[2] = sizeof(VkFFTPlan);
+	out[3] = sizeof(VkFFTApplication);
+}
+
+VKFFT_API void deleteVkFFT(VkFFTApplication* app) {
+	if (!app) return;
+	AppState* st = (AppState*)app->impl;
+	if (st) {
+		if (st->tempOwned) (void)hipFree(st->tempOwned);
+		if (st->events) {
+			for (uint32_t i = 0; i < st->numEvents; i++) if (st->events[i]) (void)hipEventDestroy(st->events[i]);
+			free(st->events);
+		}
+		delete st;
+	}
+	free_direction(app->localFFTPlan);
+	free_direction(app->localFFTPlan_inverse);
+	memset(app, 0, sizeof(VkFFTApplication));
+}
+
+VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration in) {
+	if (app == nullptr) return VKFFT_ERROR_EMPTY_app;
+	{
+		const unsigned char* t = (const unsigned char*)app;
+		for (size_t i = 0; i < sizeof(VkFFTApplication); i++) if (t[i] != 0) return VKFFT_ERROR_NONZERO_APP_INITIALIZATION;
+	}
+	VkFFTConfiguration& c = app->configuration;
+	// ---- validation in the reference's order (setConfigurationVkFFT) ---------------------------------
+	if (in.FFTdim == 0) return VKFFT_ERROR_EMPTY_FFTdim;
+	if (in.FFTdim > VKFFT_MAX_FFT_DIMENSIONS) return VKFFT_ERROR_FFTdim_GT_MAX_FFT_DIMENSIONS;
+	if (in.device == nullptr) return VKFFT_ERROR_INVALID_DEVICE;
+	if (in.size[0] == 0) return VKFFT_ERROR_EMPTY_size;
+	if (in.saveApplicationToString && in.loadApplicationFromString) return VKFFT_ERROR_ENABLED_saveApplicationToString;
+	if (in.loadApplicationFromString && in.loadApplicationString == nullptr) return VKFFT_ERROR_EMPTY_applicationString;
+	if (in.useCustomBluesteinPaddingPattern && (!in.primeSizes || !in.paddedSizes)) return VKFFT_ERROR_EMPTY_useCustomBluesteinPaddingPattern_arrays;
+	auto unsupported = [&](const char* what) {
+		fprintf(stderr, "vkfft_mi355x: %s is outside the scope of this library (see DESIGN.md)\n", what);
+		return VKFFT_ERROR_PLAN_NOT_INITIALIZED;
+	};
+	if (in.performConvolution || in.kernelConvolution || in.matrixConvolution) return unsupported("convolution");
+	for (int i = 0; i < VKFFT_MAX_FFT_DIMENSIONS; i++) if (in.performZeropadding[i]) return unsupported("zero-padding");
+	if (in.halfPrecision || in.halfPrecisionMemoryOnly) return unsupported("half precision");
+	if (in.quadDoubleDoublePrecision || in.quadDoubleDoublePrecisionDoubleMemory) return unsupported("double-double precision");
+	if (in.doublePrecisionFloatMemory) return unsupported("doublePrecisionFloatMemory");
+	if (in.performDCT > 4 || in.performDST > 4) return VKFFT_ERROR_UNSUPPORTED_FFT_LENGTH_R2R;
+	if ((in.performDCT && in.performDST) || ((in.performDCT || in.performDST) && in.performR2C)) return VKFFT_ERROR_UNSUPPORTED_FFT_LENGTH_R2R;
+
+	c = in;
+	// ---- device ----------------------------------------------------------------------------------------
+	{
+		int v = 0;
+		hipDevice_t dev = *in.device;
+		if (hipDeviceGetAttribute(&v, hipDeviceAttributeWarpSize, dev) != hipSuccess) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_FAILED_TO_GET_ATTRIBUTE; }
+		c.warpSize = (pfUINT)v;
+		if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxThreadsPerBlock, dev) != hipSuccess) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_FAILED_TO_GET_ATTRIBUTE; }
+		c.maxThreadsNum = (pfUINT)v;
+		c.maxComputeWorkGroupSize[0] = c.maxComputeWorkGroupSize[1] = c.maxComputeWorkGroupSize[2] = (pfUINT)v;
+		int g[3] = {0, 0, 0};
+		(void)hipDeviceGetAttribute(&g[0], hipDeviceAttributeMaxGridDimX, dev);
+		(void)hipDeviceGetAttribute(&g[1], hipDeviceAttributeMaxGridDimY, dev);
+		(void)hipDeviceGetAttribute(&g[2], hipDeviceAttributeMaxGridDimZ, dev);
+		for (int i = 0; i < 3; i++) c.maxComputeWorkGroupCount[i] = (pfUINT)g[i];
+		if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_FAILED_TO_GET_ATTRIBUTE; }
+		c.sharedMemorySize = in.sharedMemorySize ? in.sharedMemorySize : (pfUINT)v;
+		c.sharedMemorySizeStatic = c.sharedMemorySize;
+		pfUINT p2 = 1; while (p2 * 2 <= c.sharedMemorySize) p2 *= 2;
+		c.sharedMemorySizePow2 = p2;
+		(void)hipDeviceGetAttribute(&v, hipDeviceAttributeComputeCapabilityMajor, dev); c.computeCapabilityMajor = (pfUINT)v;
+		(void)hipDeviceGetAttribute(&v, hipDeviceAttributeComputeCapabilityMinor, dev); c.computeCapabilityMinor = (pfUINT)v;
+		c.vendorID = 0x1002;
+		if (!in.coalescedMemory) c.coalescedMemory = 256;
+		if (!in.aimThreads) c.aimThreads = 256;
+		if (!in.numSharedBanks) c.numSharedBanks = 64;
+		c.useLUT = 1; c.useLUT_4step = 1;
+		c.registerBoost = 1; c.registerBoost4Step = 1;
+	}
+	// ---- sizes, strides (reference: InitializeApp.h:984-1045) -------------------------------------------
+	for (int i = 1; i < VKFFT_MAX_FFT_DIMENSIONS; i++) if (c.size[i] == 0) c.size[i] = 1;
+	const bool r2c = in.performR2C != 0;
+	if (in.bufferStride[0] == 0) c.bufferStride[0] = r2c ? c.size[0] / 2 + 1 : c.size[0];
+	if (in.inputBufferStride[0] == 0) c.inputBufferStride[0] = (r2c && !in.isInputFormatted) ? c.size[0] + 2 : c.size[0];
+	if (in.outputBufferStride[0] == 0) c.outputBufferStride[0] = (r2c && !in.isOutputFormatted) ? c.size[0] + 2 : c.size[0];
+	for (int i = 1; i < VKFFT_MAX_FFT_DIMENSIONS; i++) {
+		if (in.bufferStride[i] == 0) c.bufferStride[i] = c.bufferStride[i - 1] * c.size[i];
+		if (in.inputBufferStride[i] == 0) c.inputBufferStride[i] = c.inputBufferStride[i - 1] * c.size[i];
+		if (in.outputBufferStride[i] == 0) c.outputBufferStride[i] = c.outputBufferStride[i - 1] * c.size[i];
+	}
+	if (c.bufferNum == 0) c.bufferNum = 1;
+	if (c.tempBufferNum == 0) c.tempBufferNum = 1;
+	if (c.inputBufferNum == 0) c.inputBufferNum = 1;
+	if (c.outputBufferNum == 0) c.outputBufferNum = 1;
+	if (c.kernelNum == 0) c.kernelNum = 1;
+	if (c.numberBatches == 0) c.numberBatches = 1;
+	if (c.coordinateFeatures == 0) c.coordinateFeatures = 1;
+	if (c.numberKernels == 0) c.numberKernels = 1;
+	c.reorderFourStep = in.disableReorderFourStep ? 0 : 1;
+	if (in.userTempBuffer) {
+		if (in.tempBufferSize == nullptr) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_EMPTY_tempBufferSize; }
+		if (in.tempBuffer == nullptr) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_EMPTY_tempBuffer; }
+	}
+	if (in.isInputFormatted && in.inverseReturnToInputBuffer == 0) { /* fine: inverse writes to buffer */ }
+	for (pfUINT i = 0; i < c.FFTdim; i++) if (c.size[i] == 1) c.omitDimension[i] = 1;
+	if (r2c && c.omitDimension[0] && c.size[0] > 1) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_UNSUPPORTED_FFT_OMIT; }
+	// batch folding visible to callers (reference: vkFFT_Plan_FFT.h:55-61)
+	app->actualNumBatches = c.numberBatches;
+	const uint64_t totalBatch = c.numberBatches * c.coordinateFeatures;
+	if (c.FFTdim == 1 && c.numberBatches > 1 && c.coordinateFeatures == 1) c.numberBatches = 1;
+	app->firstAxis = 0; app->lastAxis = c.FFTdim - 1;
+	for (pfUINT i = 0; i < c.FFTdim; i++) if (!c.omitDimension[i]) { app->firstAxis = i; break; }
+	for (pfUINT i = c.FFTdim; i-- > 0;) if (!c.omitDimension[i]) { app->lastAxis = i; break; }
+
+	// ---- transform description ---------------------------------------------------------------------------
+	TransformDesc d;
+	d.fftDim = (int)c.FFTdim;
+	for (int i = 0; i < 4; i++) { d.size[i] = c.size[i]; d.omit[i] = c.omitDimension[i] != 0; }
+	d.batch = totalBatch;
+	d.dp = c.doublePrecision != 0;
+	d.kind = r2c ? 1 : c.performDCT ? 2 : c.performDST ? 3 : 0;
+	d.r2rType = (int)(c.performDCT ? c.performDCT : c.performDST);
+	d.normalize = c.normalize != 0;
+	d.reorder = c.reorderFourStep != 0;
+	for (int i = 0; i < 4; i++) { d.bufStride[i] = c.bufferStride[i]; d.inStride[i] = c.inputBufferStride[i]; d.outStride[i] = c.outputBufferStride[i]; }
+	d.inFormatted = c.isInputFormatted != 0; d.outFormatted = c.isOutputFormatted != 0;
+	d.inverseReturnToInput = c.inverseReturnToInputBuffer != 0;
+	d.maxLds = c.sharedMemorySize;
+	d.forceBluesteinSize = c.forceBluesteinSequenceSize;
+	d.fixMaxRadixBluestein = (int)c.fixMaxRadixBluestein;
+	if (c.fixMaxRaderPrimeMult) d.raderMultMax = c.fixMaxRaderPrimeMult;
+	if (c.userTempBuffer && c.tempBufferSize) d.userTempBytes = c.tempBufferSize[0];
+	if (const char* e = getenv("VKFFT_MI355X_CHUNK_MIB")) d.chunkTargetBytes = (uint64_t)atoll(e) << 20;
+	if (const char* e = getenv("VKFFT_MI355X_GENERIC_ONLY")) d.disableFastKernels = atoi(e) != 0;
+
+	AppState* st = new (std::nothrow) AppState();
+	if (!st) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_MALLOC_FAILED; }
+	app->impl = st;
+
+	VkFFTResult res = VKFFT_SUCCESS;
+	if (!c.makeForwardPlanOnly) {
+		res = make_direction(app, d, true, &app->localFFTPlan_inverse);
+		if (res != VKFFT_SUCCESS) { deleteVkFFT(app); return res; }
+	}
+	if (!c.makeInversePlanOnly) {
+		res = make_direction(app, d, false, &app->localFFTPlan);
+		if (res != VKFFT_SUCCESS) { deleteVkFFT(app); return res; }
+	}
+	// ---- scratch ------------------------------------------------------------------------------------------
+	uint64_t need = 0;
+	if (app->localFFTPlan) need = std::max<uint64_t>(need, ((DirectionPlan*)app->localFFTPlan->impl)->tempBytes);
+	if (app->localFFTPlan_inverse) need = std::max<uint64_t>(need, ((DirectionPlan*)app->localFFTPlan_inverse->impl)->tempBytes);
+	if (need && !c.userTempBuffer) {
+		if (hipMalloc(&st->tempOwned, need) != hipSuccess) { deleteVkFFT(app); return VKFFT_ERROR_FAILED_TO_ALLOCATE; }
+		st->tempOwnedBytes = need;
+		c.allocateTempBuffer = 1;
+	}
+	// ---- multi-stream events ------------------------------------------------------------------------------
+	if (c.num_streams > 1 && c.stream) {
+		st->events = (hipEvent_t*)calloc(c.num_streams, sizeof(hipEvent_t));
+		if (!st->events) { deleteVkFFT(app); return VKFFT_ERROR_MALLOC_FAILED; }
+		st->numEvents = (uint32_t)c.num_streams;
+		for (uint32_t i = 0; i < st->numEvents; i++)
+			if (hipEventCreateWithFlags(&st->events[i], hipEventDisableTiming) != hipSuccess) { deleteVkFFT(app); return VKFFT_ERROR_FAILED_TO_CREATE_EVENT; }
+		c.stream_event = st->events;
+	}
+	return VKFFT_SUCCESS;
+}
+
+VKFFT_API VkFFTResult VkFFTAppend(VkFFTApplication* app, int inverse, VkFFTLaunchParams* lp) {
+	if (app == nullptr) return VKFFT_ERROR_EMPTY_app;
+	VkFFTConfiguration& c = app->configuration;
+	AppState* st = (AppState*)app->impl;
+	if (st == nullptr) return VKFFT_ERROR_PLAN_NOT_INITIALIZED;
+	VkFFTPlan* pl;
+	if (inverse != 1) { // reference: anything but 1 is forward (vkFFT_RunApp.h:102-111)
+		if (!app->localFFTPlan) return VKFFT_ERROR_ONLY_INVERSE_FFT_INITIALIZED;
+		pl = app->localFFTPlan;
+	} else {
+		if (!app->localFFTPlan_inverse) return VKFFT_ERROR_ONLY_FORWARD_FFT_INITIALIZED;
+		pl = app->localFFTPlan_inverse;
+	}
+	// launch-time buffer / offset override (reference: VkFFTCheckUpdateBufferSet, vkFFT_UpdateBuffers.h:628)
+	if (lp) {
+		if (lp->buffer) c.buffer = lp->buffer;
+		if (lp->tempBuffer) c.tempBuffer = lp->tempBuffer;
+		if (lp->inputBuffer) c.inputBuffer = lp->inputBuffer;
+		if (lp->outputBuffer) c.outputBuffer = lp->outputBuffer;
+		if (c.specifyOffsetsAtLaunch) {
+			c.bufferOffset = lp->bufferOffset; c.tempBufferOffset = lp->tempBufferOffset;
+			c.inputBufferOffset = lp->inputBufferOffset; c.outputBufferOffset = lp->outputBufferOffset;
+		}
+	}
+	if (c.buffer == nullptr || c.buffer[0] == nullptr) return VKFFT_ERROR_EMPTY_buffer;
+	if (c.isInputFormatted && (c.inputBuffer == nullptr || c.inputBuffer[0] == nullptr)) return VKFFT_ERROR_EMPTY_inputBuffer;
+	if (c.isOutputFormatted && (c.outputBuffer == nullptr || c.outputBuffer[0] == nullptr)) return VKFFT_ERROR_EMPTY_outputBuffer;
+	DirectionPlan* dp = (DirectionPlan*)pl->impl;
+	LaunchBuffers lb;
+	lb.base[ROLE_BUFFER] = (char*)c.buffer[0] + c.bufferOffset;
+	if (c.isInputFormatted) lb.base[ROLE_INPUT] = (char*)c.inputBuffer[0] + c.inputBufferOffset;
+	if (c.isOutputFormatted) lb.base[ROLE_OUTPUT] = (char*)c.outputBuffer[0] + c.outputBufferOffset;
+	if (dp->tempBytes) {
+		if (c.userTempBuffer) {
+			if (c.tempBuffer == nullptr || c.tempBuffer[0] == nullptr) return VKFFT_ERROR_EMPTY_tempBuffer;
+			lb.base[ROLE_TEMP] = (char*)c.tempBuffer[0] + c.tempBufferOffset;
+		} else lb.base[ROLE_TEMP] = st->tempOwned;
+	}
+	hipStream_t stream = 0;
+	if (c.stream && c.num_streams >= 1) stream = c.stream[0];
+	int r = execute_direction(*dp, lb, stream);
+	if (r) { fprintf(stderr, "vkfft_mi355x: kernel launch failed\n"); return (VkFFTResult)r; }
+	return VKFFT_SUCCESS;
+}
+
+VKFFT_API const char* getVkFFTErrorString(VkFFTResult r) {
+	switch (r) {
+#define C(x) case x: return #x;
+	C(VKFFT_SUCCESS) C(VKFFT_ERROR_MALLOC_FAILED) C(VKFFT_ERROR_INSUFFICIENT_CODE_BUFFER) C(VKFFT_ERROR_INSUFFICIENT_TEMP_BUFFER)
+	C(VKFFT_ERROR_PLAN_NOT_INITIALIZED) C(VKFFT_ERROR_NULL_TEMP_PASSED) C(VKFFT_ERROR_MATH_FAILED) C(VKFFT_ERROR_FFTdim_GT_MAX_FFT_DIMENSIONS)
+	C(VKFFT_ERROR_NONZERO_APP_INITIALIZATION) C(VKFFT_ERROR_INVALID_PHYSICAL_DEVICE) C(VKFFT_ERROR_INVALID_DEVICE) C(VKFFT_ERROR_INVALID_QUEUE)
+	C(VKFFT_ERROR_INVALID_COMMAND_POOL) C(VKFFT_ERROR_INVALID_FENCE) C(VKFFT_ERROR_ONLY_FORWARD_FFT_INITIALIZED) C(VKFFT_ERROR_ONLY_INVERSE_FFT_INITIALIZED)
+	C(VKFFT_ERROR_INVALID_CONTEXT) C(VKFFT_ERROR_INVALID_PLATFORM) C(VKFFT_ERROR_ENABLED_saveApplicationToString) C(VKFFT_ERROR_EMPTY_FILE)
+	C(VKFFT_ERROR_EMPTY_FFTdim) C(VKFFT_ERROR_EMPTY_size) C(VKFFT_ERROR_EMPTY_bufferSize) C(VKFFT_ERROR_EMPTY_buffer) C(VKFFT_ERROR_EMPTY_tempBufferSize)
+	C(VKFFT_ERROR_EMPTY_tempBuffer) C(VKFFT_ERROR_EMPTY_inputBufferSize) C(VKFFT_ERROR_EMPTY_inputBuffer) C(VKFFT_ERROR_EMPTY_outputBufferSize)
+	C(VKFFT_ERROR_EMPTY_outputBuffer) C(VKFFT_ERROR_EMPTY_kernelSize) C(VKFFT_ERROR_EMPTY_kernel) C(VKFFT_ERROR_EMPTY_applicationString)
+	C(VKFFT_ERROR_EMPTY_useCustomBluesteinPaddingPattern_arrays) C(VKFFT_ERROR_EMPTY_app) C(VKFFT_ERROR_INVALID_user_tempBuffer_too_small)
+	C(VKFFT_ERROR_UNSUPPORTED_RADIX) C(VKFFT_ERROR_UNSUPPORTED_FFT_LENGTH) C(VKFFT_ERROR_UNSUPPORTED_FFT_LENGTH_R2C) C(VKFFT_ERROR_UNSUPPORTED_FFT_LENGTH_R2R)
+	C(VKFFT_ERROR_UNSUPPORTED_FFT_OMIT) C(VKFFT_ERROR_FAILED_TO_ALLOCATE) C(VKFFT_ERROR_FAILED_TO_MAP_MEMORY) C(VKFFT_ERROR_FAILED_TO_ALLOCATE_COMMAND_BUFFERS)
+	C(VKFFT_ERROR_FAILED_TO_BEGIN_COMMAND_BUFFER) C(VKFFT_ERROR_FAILED_TO_END_COMMAND_BUFFER) C(VKFFT_ERROR_FAILED_TO_SUBMIT_QUEUE)
+	C(VKFFT_ERROR_FAILED_TO_WAIT_FOR_FENCES) C(VKFFT_ERROR_FAILED_TO_RESET_FENCES) C(VKFFT_ERROR_FAILED_TO_CREATE_DESCRIPTOR_POOL)
+	C(VKFFT_ERROR_FAILED_TO_CREATE_DESCRIPTOR_SET_LAYOUT) C(VKFFT_ERROR_FAILED_TO_ALLOCATE_DESCRIPTOR_SETS) C(VKFFT_ERROR_FAILED_TO_CREATE_PIPELINE_LAYOUT)
+	C(VKFFT_ERROR_FAILED_SHADER_PREPROCESS) C(VKFFT_ERROR_FAILED_SHADER_PARSE) C(VKFFT_ERROR_FAILED_SHADER_LINK) C(VKFFT_ERROR_FAILED_SPIRV_GENERATE)
+	C(VKFFT_ERROR_FAILED_TO_CREATE_SHADER_MODULE) C(VKFFT_ERROR_FAILED_TO_CREATE_INSTANCE) C(VKFFT_ERROR_FAILED_TO_SETUP_DEBUG_MESSENGER)
+	C(VKFFT_ERROR_FAILED_TO_FIND_PHYSICAL_DEVICE) C(VKFFT_ERROR_FAILED_TO_CREATE_DEVICE) C(VKFFT_ERROR_FAILED_TO_CREATE_FENCE)
+	C(VKFFT_ERROR_FAILED_TO_CREATE_COMMAND_POOL) C(VKFFT_ERROR_FAILED_TO_CREATE_BUFFER) C(VKFFT_ERROR_FAILED_TO_ALLOCATE_MEMORY)
+	C(VKFFT_ERROR_FAILED_TO_BIND_BUFFER_MEMORY) C(VKFFT_ERROR_FAILED_TO_FIND_MEMORY) C(VKFFT_ERROR_FAILED_TO_SYNCHRONIZE) C(VKFFT_ERROR_FAILED_TO_COPY)
+	C(VKFFT_ERROR_FAILED_TO_CREATE_PROGRAM) C(VKFFT_ERROR_FAILED_TO_COMPILE_PROGRAM) C(VKFFT_ERROR_FAILED_TO_GET_CODE_SIZE) C(VKFFT_ERROR_FAILED_TO_GET_CODE)
+	C(VKFFT_ERROR_FAILED_TO_DESTROY_PROGRAM) C(VKFFT_ERROR_FAILED_TO_LOAD_MODULE) C(VKFFT_ERROR_FAILED_TO_GET_FUNCTION)
+	C(VKFFT_ERROR_FAILED_TO_SET_DYNAMIC_SHARED_MEMORY) C(VKFFT_ERROR_FAILED_TO_MODULE_GET_GLOBAL) C(VKFFT_ERROR_FAILED_TO_LAUNCH_KERNEL)
+	C(VKFFT_ERROR_FAILED_TO_EVENT_RECORD) C(VKFFT_ERROR_FAILED_TO_ADD_NAME_EXPRESSION) C(VKFFT_ERROR_FAILED_TO_INITIALIZE)
+	C(VKFFT_ERROR_FAILED_TO_SET_DEVICE_ID) C(VKFFT_ERROR_FAILED_TO_GET_DEVICE) C(VKFFT_ERROR_FAILED_TO_CREATE_CONTEXT) C(VKFFT_ERROR_FAILED_TO_CREATE_PIPELINE)
+	C(VKFFT_ERROR_FAILED_TO_SET_KERNEL_ARG) C(VKFFT_ERROR_FAILED_TO_CREATE_COMMAND_QUEUE) C(VKFFT_ERROR_FAILED_TO_RELEASE_COMMAND_QUEUE)
+	C(VKFFT_ERROR_FAILED_TO_ENUMERATE_DEVICES) C(VKFFT_ERROR_FAILED_TO_GET_ATTRIBUTE) C(VKFFT_ERROR_FAILED_TO_CREATE_EVENT)
+	C(VKFFT_ERROR_FAILED_TO_CREATE_COMMAND_LIST) C(VKFFT_ERROR_FAILED_TO_DESTROY_COMMAND_LIST) C(VKFFT_ERROR_FAILED_TO_SUBMIT_BARRIER)
+#undef C
+	}
+	return "Unknown VkFFT error";
+}
+
+} // extern "C"

@@ -1,0 +1,130 @@
+// Shared host/device definitions of the MI355X FFT engine: complex type, fast integer division,
+// and the per-launch parameter blocks ("pass descriptors") the planner fills and the kernels read.
+//
+// A *pass* is one kernel launch = one trip of the data through HBM.  It runs G independent
+// sub-FFTs of length L.  The reference's equivalent is one "axis upload" (VkFFTAxis,
+// vkFFT_Structs.h:1037; built by VkFFTPlanAxis, vkFFT_Plan_FFT.h:33), but where the reference
+// bakes these numbers into a generated source string, here they are plain kernel arguments of
+// ahead-of-time compiled kernels.
+#pragma once
+#include <stdint.h>
+
+#if defined(VKFFT_HOSTEMU)
+#include "hostemu_runtime.h" // tests/hostemu: CPU SIMT emulation used ONLY by the CPU test-suite
+#else
+#include <hip/hip_runtime.h>
+#define VKFFT_DYN_SMEM(var) extern __shared__ __attribute__((aligned(16))) char var[];
+#endif
+
+namespace vkfft_mi355x {
+
+template <typename T> struct alignas(2 * sizeof(T)) cx {
+	T x, y;
+};
+using cf = cx<float>;
+using cd = cx<double>;
+
+template <typename T> __host__ __device__ inline cx<T> cmul(cx<T> a, cx<T> b) {
+	return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+template <typename T> __host__ __device__ inline cx<T> cmulc(cx<T> a, cx<T> b) { // a * conj(b)
+	return {a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};
+}
+template <typename T> __host__ __device__ inline cx<T> cadd(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename T> __host__ __device__ inline cx<T> csub(cx<T> a, cx<T> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename T> __host__ __device__ inline cx<T> cswap(cx<T> a) { return {a.y, a.x}; }
+template <typename T> __host__ __device__ inline cx<T> cconj(cx<T> a) { return {a.x, -a.y}; }
+template <typename T> __host__ __device__ inline cx<T> cscale(cx<T> a, T s) { return {a.x * s, a.y * s}; }
+// multiply by -i (forward quarter turn) / +i
+template <typename T> __host__ __device__ inline cx<T> cmul_mi(cx<T> a) { return {a.y, -a.x}; }
+template <typename T> __host__ __device__ inline cx<T> cmul_pi(cx<T> a) { return {-a.y, a.x}; }
+
+// Division by a launch-invariant divisor for n < 2^24 (all in-workgroup indices are far below).
+struct FastDiv {
+	uint32_t d;
+	float rcp;
+	__host__ __device__ inline void divmod(uint32_t n, uint32_t& q, uint32_t& r) const {
+		uint32_t qq = (uint32_t)((float)n * rcp);
+		int32_t rr = (int32_t)(n - qq * d);
+		if (rr < 0) { qq--; rr += (int32_t)d; }
+		else if (rr >= (int32_t)d) { qq++; rr -= (int32_t)d; }
+		q = qq; r = (uint32_t)rr;
+	}
+};
+inline FastDiv make_fastdiv(uint32_t d) { FastDiv f; f.d = d ? d : 1; f.rcp = 1.0f / (float)f.d; return f; }
+
+constexpr int kMaxStages = 16;
+
+// pre/post operations fused into a pass (values of PassParams::preOp / postOp)
+enum : uint32_t {
+	OP_NONE = 0,
+	OP_TWIDDLE_4STEP = 1,   // post: x[j] *= exp(-2*pi*i * j * col / fsN)      (vkFFT_4step.h:31)
+	OP_R2C_EVEN_POST = 2,   // post: half-length complex FFT -> N/2+1 Hermitian outputs   (vkFFT_R2C_even_decomposition.h:181)
+	OP_C2R_EVEN_PRE = 3,    // pre : Hermitian half -> packed half-length complex input
+	OP_R2C_FULL = 4,        // pre : real -> (x,0); post: store first N/2+1               (vkFFT_R2C.h:27, "callback" form)
+	OP_C2R_FULL = 5,        // pre : Hermitian half expanded to full length; post: store real part
+	OP_DCT2_PRE = 6, OP_DCT2_POST = 7,   // vkFFT_R2R.h:193,784
+	OP_DCT3_PRE = 8, OP_DCT3_POST = 9,
+	OP_DCT1_PRE = 10, OP_DCT1_POST = 11, // vkFFT_R2R.h:28
+	OP_DCT4_PRE = 12, OP_DCT4_POST = 13, // vkFFT_R2R.h:368,861
+	OP_DST1_PRE = 14, OP_DST1_POST = 15,
+	OP_DST2_PRE = 16, OP_DST2_POST = 17,
+	OP_DST3_PRE = 18, OP_DST3_POST = 19,
+	OP_DST4_PRE = 20, OP_DST4_POST = 21,
+	OP_BLUESTEIN_PRE = 22,  // pre : x[n] *= conj(chirp[n]), zero-pad to L            (vkFFT_Bluestein.h:32)
+	OP_BLUESTEIN_MID = 23,  // mid : pointwise * FFT(chirp), then the stage list runs again as inverse (vkFFT_Bluestein.h:201)
+	OP_BLUESTEIN_POST = 24, // post: x[k] *= conj(chirp[k]) for k < N
+	OP_MUL_LUT = 25,        // post: pointwise multiply by aux[j] (multi-pass Bluestein)
+};
+
+struct StageDesc {
+	uint32_t radix;   // 2,3,4,5,7,8,11,13,16 or a Rader prime
+	uint32_t S;       // product of the radices of earlier stages (Stockham stride)
+	uint32_t lutOff;  // offset (complex elements) of this stage's twiddle run in PassParams::lut
+	uint32_t kind;    // 0 radix butterfly, 1 Rader direct-multiplication, 2 Rader FFT-convolution
+	uint32_t aux0, aux1; // Rader: offsets of generator tables / convolution kernel
+};
+
+// One dimension of the sub-FFT enumeration: count + element strides on the input and output side.
+struct BatchDim {
+	uint32_t count;
+	int64_t inStride, outStride;
+};
+
+struct PassParams {
+	const void* in;
+	void* out;
+	const void* lut;     // stage twiddles, cx<T>
+	const void* aux;     // op-specific table (4-step two-level LUT, R2C/DCT twiddles, chirp, ...)
+	const void* aux2;    // second op-specific table (Bluestein FFT(chirp), DCT-IV post twiddles)
+	uint32_t L;          // sub-FFT length computed by the stages
+	uint32_t nStages;
+	StageDesc st[kMaxStages];
+	// element j of sub-FFT (g0,g1,g2) lives at  j*inStrideJ + g0*dim[0].inStride + g1*dim[1].inStride + g2*dim[2].inStride
+	// (units: complex elements, or real scalars when the pre/post op reads/writes real data)
+	int64_t inStrideJ, outStrideJ;
+	BatchDim dim[3];     // dim[0] is the tiled one: a workgroup takes T consecutive g0
+	uint32_t T;          // sub-FFTs per workgroup (power of two)
+	uint32_t logT;
+	uint32_t colMode;    // load side: 0 lanes run along j (unit inStrideJ), 1 lanes run along g0 (unit dim[0] stride)
+	uint32_t colModeOut; // same for the store side
+	uint32_t padShift;   // LDS index a -> a + (a >> padShift); 31 = no padding
+	uint32_t Tp;         // LDS pitch between consecutive a (T rounded up to odd, 1 when T==1)
+	uint32_t swapIn;     // swap re/im of the FFT input  } inverse transform = swap . forward . swap;
+	uint32_t swapOut;    // swap re/im of the FFT output } multi-pass plans set swapIn on the first, swapOut on the last pass
+	uint32_t preOp, midOp, postOp;
+	uint32_t bluesteinSwapIn, bluesteinSwapOut;
+	uint32_t inLen, outLen; // elements gathered / stored per sub-FFT (differ from L for real transforms, Bluestein)
+	uint32_t opN;        // logical transform size of the pre/post op (e.g. real length N of R2C / DCT)
+	uint32_t fsN;        // 4-step: twiddle exponent denominator (product of all pass lengths of this decomposition level)
+	uint32_t fsLoBits;   // 4-step two-level LUT: aux = 2^fsLoBits low entries followed by the high entries
+	FastDiv fsColDiv;    // 4-step: column index used in the twiddle = g0 / fsColDiv
+	double scale;        // multiplied into the output (1/N normalisation); 1.0 = off
+	FastDiv divL, divOutLen;
+	FastDiv divNb[kMaxStages]; // L / radix per stage
+	FastDiv divS[kMaxStages];
+	uint32_t ldsElems;   // elements per LDS buffer (two buffers are used)
+	uint32_t tilesPerG0; // ceil(dim[0].count / T)
+};
+
+} // namespace vkfft_mi355x

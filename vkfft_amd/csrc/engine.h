@@ -1,0 +1,96 @@
+// Host-side engine interface: the planner turns a transform description into a list of passes; the
+// executor enqueues them.  Replaces the reference's VkFFTScheduler / VkFFTPlanAxis / VkFFT_DispatchPlan
+// (vkFFT_Scheduler.h:2223, vkFFT_Plan_FFT.h:33, vkFFT_DispatchPlan.h:26) with a design that selects among
+// ahead-of-time compiled kernels instead of generating source.
+#pragma once
+#include "common.h"
+#include <vector>
+#include <string>
+#include <cstddef>
+
+namespace vkfft_mi355x {
+
+enum BufRole : int { ROLE_BUFFER = 0, ROLE_TEMP = 1, ROLE_INPUT = 2, ROLE_OUTPUT = 3 };
+enum KernelKind : int { KERNEL_GENERIC = 0, KERNEL_POW2_ROW = 1, KERNEL_POW2_COL = 2 };
+
+struct HostDim {
+	uint64_t count;
+	int64_t inStride, outStride;
+};
+
+// One kernel launch (possibly repeated over host-side outer dimensions).
+struct PassPlan {
+	PassParams prm;       // pointers are filled at launch
+	int inRole = ROLE_BUFFER, outRole = ROLE_BUFFER;
+	int64_t inOffset = 0, outOffset = 0; // element offsets (units of the pass's element type) added to the role base
+	int inElemBytes = 8, outElemBytes = 8; // bytes per element on each side (real vs complex, fp32 vs fp64)
+	bool dp = false;
+	int kernel = KERNEL_GENERIC;
+	int variant = 0;      // index into the fast-kernel table
+	uint32_t threads = 256;
+	size_t ldsBytes = 0;
+	std::vector<HostDim> hostLoop; // outer dims iterated on the host (rare: >3 non-collapsible batch dims)
+	// arena offsets (bytes) of the tables, SIZE_MAX = none
+	size_t lutOff = (size_t)-1, auxOff = (size_t)-1, aux2Off = (size_t)-1;
+	// chunking: this pass's dim index whose range the executor may split ( -1: none )
+	int chunkDim = -1;
+	std::string label;
+};
+
+struct DirectionPlan {
+	std::vector<PassPlan> passes;
+	std::vector<unsigned char> arena;  // host image of every LUT of this direction
+	void* dArena = nullptr;            // device copy
+	uint64_t tempBytes = 0;            // scratch this direction needs (0: none)
+	// chunked execution of passes [chunkFirst, chunkLast] over the outermost batch dim, so that the
+	// intermediate stays resident in the 256 MiB Infinity Cache between passes
+	int chunkFirst = -1, chunkLast = -1;
+	uint64_t chunkBatch = 0, totalBatch = 0;
+	uint64_t chunkTempStrideBytes = 0;
+	uint32_t uploadsPerAxis[4] = {0, 0, 0, 0};
+	uint64_t axisSplit[4][4] = {};
+};
+
+// ---- transform description handed to the planner (derived from VkFFTConfiguration) -------------------
+struct TransformDesc {
+	int fftDim = 1;
+	uint64_t size[4] = {1, 1, 1, 1};
+	uint64_t batch = 1;          // numberBatches * coordinateFeatures folded
+	bool dp = false;
+	int kind = 0;                // 0 C2C, 1 R2C/C2R, 2 DCT, 3 DST
+	int r2rType = 0;             // 1..4
+	bool inverse = false;
+	bool normalize = false;
+	bool omit[4] = {false, false, false, false};
+	bool reorder = true;
+	// element strides of the main buffer (complex elements for C2C, see planner for real kinds)
+	uint64_t bufStride[5] = {0, 0, 0, 0, 0};  // [0] = pitch of axis 1 (elements between consecutive rows), ... [fftDim-1] = batch pitch
+	bool inFormatted = false, outFormatted = false;
+	uint64_t inStride[5] = {0, 0, 0, 0, 0}, outStride[5] = {0, 0, 0, 0, 0};
+	bool inverseReturnToInput = false;
+	uint64_t maxLds = 160 * 1024;
+	uint64_t forceBluesteinSize = 0;
+	int fixMaxRadixBluestein = 0;
+	uint64_t raderMultMin = 17, raderMultMax = 128;
+	uint64_t userTempBytes = 0;  // >0: temp supplied by the caller with this size
+	uint64_t chunkTargetBytes = 96ull << 20; // working-set target of the Infinity-Cache chunking (0 disables)
+	bool disableFastKernels = false;
+};
+
+// returns 0 or a VkFFTResult code
+int build_direction_plan(const TransformDesc& d, DirectionPlan& out);
+
+// launchers (kernels.hip)
+struct LaunchBuffers {
+	void* base[4] = {nullptr, nullptr, nullptr, nullptr}; // by BufRole
+};
+int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
+int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream);
+
+// fast-kernel registry queries used by the planner
+bool pow2_row_available(uint32_t log2n, bool dp, uint32_t* threads, uint32_t* fftsPerWg, size_t* ldsBytes, int* variant);
+
+// misc
+std::vector<uint32_t> factorize_radices(uint64_t n, bool* smooth);
+
+} // namespace vkfft_mi355x

@@ -1,0 +1,362 @@
+// Generic Stockham pass: any length L = product of radices {2,3,4,5,7,8,11,13,16} (+ Rader primes), any
+// strided batch enumeration, optional fused pre/post operation (Four-Step twiddle, R2C/C2R packing,
+// DCT/DST pre/post processing, Bluestein chirp).  One workgroup transforms T sub-FFTs held in LDS.
+//
+// Structure (cf. the reference's generated kernel, vkFFT_FFT.h:48-388, §3.3 of SURVEY.md):
+//   gather-load  : global -> LDS, lanes mapped for coalescing (along the sub-FFT for unit-stride rows,
+//                  across neighbouring sub-FFTs for strided columns), pre-op applied on the fly
+//   stage loop   : Stockham autosort radix stages ping-ponging between two LDS buffers
+//                  (read t + i*L/R, twiddle, butterfly, write (t-s)*R + s + k*S; vkFFT_RadixStage.h:104-137,
+//                   vkFFT_RadixShuffle.h:127-190 compute the same index maps)
+//   gather-store : LDS -> global with the post-op, again lane-mapped for coalescing (transposed when
+//                  the output side is laid out differently: Four-Step reorder, vkFFT_ReadWrite.h:1405-1476)
+// Everything length- or stride-dependent is a kernel argument (PassParams); nothing is generated at
+// run time.  The hand-specialised power-of-two kernels in kernel_pow2.h replace this kernel on the
+// headline path; this one provides coverage.
+#pragma once
+#include "butterflies.h"
+
+namespace vkfft_mi355x {
+
+template <typename T> struct GlobalIO {
+	// complex / real element access with 64-bit element offsets
+	static __device__ inline cx<T> ldc(const void* p, int64_t i) { return ((const cx<T>*)p)[i]; }
+	static __device__ inline T ldr(const void* p, int64_t i) { return ((const T*)p)[i]; }
+	static __device__ inline void stc(void* p, int64_t i, cx<T> v) { ((cx<T>*)p)[i] = v; }
+	static __device__ inline void str(void* p, int64_t i, T v) { ((T*)p)[i] = v; }
+};
+
+template <typename T> __device__ inline cx<T> twiddle4(const PassParams& p, uint32_t e) {
+	const cx<T>* tab = (const cx<T>*)p.aux;
+	const uint32_t lo = e & ((1u << p.fsLoBits) - 1u), hi = e >> p.fsLoBits;
+	return cmul(tab[lo], tab[(1u << p.fsLoBits) + hi]);
+}
+
+// value that goes to LDS position `pos` of sub-FFT f (before the optional inverse swap)
+template <typename T>
+__device__ inline cx<T> pre_gather(const PassParams& p, const void* in, int64_t base, uint32_t pos) {
+	using IO = GlobalIO<T>;
+	const int64_t sj = p.inStrideJ;
+	const cx<T> zero = {(T)0, (T)0};
+	switch (p.preOp) {
+	default:
+	case OP_NONE:
+		return pos < p.inLen ? IO::ldc(in, base + (int64_t)pos * sj) : zero;
+	case OP_C2R_EVEN_PRE: { // opN = real length N, L = N/2
+		const uint32_t H = p.opN >> 1;
+		cx<T> a = IO::ldc(in, base + (int64_t)pos * sj);
+		cx<T> b = cconj(IO::ldc(in, base + (int64_t)(H - pos) * sj));
+		cx<T> w = cconj(((const cx<T>*)p.aux)[pos]);
+		cx<T> d = cmul(w, csub(a, b));
+		cx<T> s = cadd(a, b);
+		return {s.x - d.y, s.y + d.x}; // s + i*d
+	}
+	case OP_R2C_FULL:
+		return {IO::ldr(in, base + (int64_t)pos * sj), (T)0};
+	case OP_C2R_FULL: {
+		const uint32_t N = p.opN;
+		if (pos <= N / 2) return IO::ldc(in, base + (int64_t)pos * sj);
+		return cconj(IO::ldc(in, base + (int64_t)(N - pos) * sj));
+	}
+	case OP_DCT2_PRE: case OP_DST2_PRE: {
+		const uint32_t N = p.opN;
+		const uint32_t src = pos < (N + 1) / 2 ? 2 * pos : 2 * (N - 1 - pos) + 1;
+		T v = IO::ldr(in, base + (int64_t)src * sj);
+		if (p.preOp == OP_DST2_PRE && (src & 1)) v = -v;
+		return {v, (T)0};
+	}
+	case OP_DCT3_PRE: case OP_DST3_PRE: { // V_k = e^{+i pi k/2N} (x_k - i x_{N-k}), x_N = 0
+		const uint32_t N = p.opN;
+		T a, b;
+		if (p.preOp == OP_DCT3_PRE) {
+			a = IO::ldr(in, base + (int64_t)pos * sj);
+			b = pos == 0 ? (T)0 : IO::ldr(in, base + (int64_t)(N - pos) * sj);
+		} else { // DST-III = (-1)^n DCT-III(reversed input)
+			a = IO::ldr(in, base + (int64_t)(N - 1 - pos) * sj);
+			b = pos == 0 ? (T)0 : IO::ldr(in, base + (int64_t)(pos - 1) * sj);
+		}
+		cx<T> w = cconj(((const cx<T>*)p.aux)[pos]);
+		return cmul(w, cx<T>{a, -b});
+	}
+	case OP_DCT1_PRE: { // even extension, L = 2N-2
+		const uint32_t N = p.opN, M = 2 * N - 2;
+		const uint32_t src = pos < N ? pos : M - pos;
+		return {IO::ldr(in, base + (int64_t)src * sj), (T)0};
+	}
+	case OP_DST1_PRE: { // odd extension, L = 2N+2
+		const uint32_t N = p.opN;
+		if (pos == 0 || pos == N + 1) return zero;
+		if (pos <= N) return {IO::ldr(in, base + (int64_t)(pos - 1) * sj), (T)0};
+		return {-IO::ldr(in, base + (int64_t)(2 * N + 1 - pos) * sj), (T)0};
+	}
+	case OP_DCT4_PRE: case OP_DST4_PRE: {
+		const uint32_t N = p.opN;
+		const bool dst = p.preOp == OP_DST4_PRE;
+		if (p.L * 2 == N) { // even N: half-length complex FFT
+			uint32_t i0 = 2 * pos, i1 = N - 1 - 2 * pos;
+			if (dst) { i0 = N - 1 - i0; i1 = N - 1 - i1; }
+			T a = IO::ldr(in, base + (int64_t)i0 * sj), b = IO::ldr(in, base + (int64_t)i1 * sj);
+			return cmul(cx<T>{a, b}, ((const cx<T>*)p.aux)[pos]);
+		}
+		if (pos >= N) return zero; // L = 2N, zero padded
+		T a = IO::ldr(in, base + (int64_t)(dst ? N - 1 - pos : pos) * sj);
+		return cscale(((const cx<T>*)p.aux)[pos], a);
+	}
+	case OP_BLUESTEIN_PRE: {
+		if (pos >= p.inLen) return zero;
+		cx<T> v = IO::ldc(in, base + (int64_t)pos * sj);
+		if (p.bluesteinSwapIn) v = cswap(v);
+		return cmulc(v, ((const cx<T>*)p.aux)[pos]);
+	}
+	}
+}
+
+// output element k of sub-FFT f, gathered from LDS buffer `buf` (values already un-swapped by `rd`)
+template <typename T, typename RD>
+__device__ inline void post_store(const PassParams& p, void* out, int64_t base, uint32_t k, uint32_t colIdx, RD rd) {
+	using IO = GlobalIO<T>;
+	const int64_t sj = p.outStrideJ;
+	const T sc = (T)p.scale;
+	switch (p.postOp) {
+	default:
+	case OP_NONE: {
+		cx<T> v = rd(k);
+		IO::stc(out, base + (int64_t)k * sj, cscale(v, sc));
+		return;
+	}
+	case OP_TWIDDLE_4STEP: {
+		cx<T> v = cmul(rd(k), twiddle4<T>(p, k * colIdx));
+		IO::stc(out, base + (int64_t)k * sj, cscale(v, sc));
+		return;
+	}
+	case OP_MUL_LUT: {
+		cx<T> v = cmul(rd(k), ((const cx<T>*)p.aux2)[k]);
+		IO::stc(out, base + (int64_t)k * sj, cscale(v, sc));
+		return;
+	}
+	case OP_R2C_EVEN_POST: { // k in [0, N/2]
+		const uint32_t H = p.opN >> 1;
+		cx<T> zk = rd(k == H ? 0 : k), zm = cconj(rd(k == 0 ? 0 : H - k));
+		cx<T> w = ((const cx<T>*)p.aux)[k];
+		cx<T> s = cadd(zk, zm), d = cmul(w, csub(zk, zm));
+		// 0.5 * (s - i d)
+		IO::stc(out, base + (int64_t)k * sj, cx<T>{(T)0.5 * sc * (s.x + d.y), (T)0.5 * sc * (s.y - d.x)});
+		return;
+	}
+	case OP_R2C_FULL: {
+		IO::stc(out, base + (int64_t)k * sj, cscale(rd(k), sc));
+		return;
+	}
+	case OP_C2R_FULL: {
+		IO::str(out, base + (int64_t)k * sj, rd(k).x * sc);
+		return;
+	}
+	case OP_DCT2_POST: case OP_DST2_POST: {
+		const uint32_t N = p.opN;
+		const uint32_t kk = p.postOp == OP_DST2_POST ? N - 1 - k : k;
+		cx<T> v = cmul(((const cx<T>*)p.aux)[kk], rd(kk));
+		IO::str(out, base + (int64_t)k * sj, (T)2 * sc * v.x);
+		return;
+	}
+	case OP_DCT3_POST: case OP_DST3_POST: { // y[src(m)] = Re v_m : gather form, output index k
+		const uint32_t N = p.opN;
+		const uint32_t m = (k & 1) ? N - 1 - (k >> 1) : (k >> 1);
+		T v = rd(m).x * sc;
+		if (p.postOp == OP_DST3_POST && (k & 1)) v = -v;
+		IO::str(out, base + (int64_t)k * sj, v);
+		return;
+	}
+	case OP_DCT1_POST:
+		IO::str(out, base + (int64_t)k * sj, rd(k).x * sc);
+		return;
+	case OP_DST1_POST:
+		IO::str(out, base + (int64_t)k * sj, -rd(k + 1).y * sc);
+		return;
+	case OP_DCT4_POST: case OP_DST4_POST: {
+		const uint32_t N = p.opN;
+		T v;
+		if (p.L * 2 == N) {
+			const uint32_t m = (k & 1) ? (N - 1 - k) >> 1 : k >> 1;
+			cx<T> c = cmul(rd(m), ((const cx<T>*)p.aux2)[m]);
+			v = (k & 1) ? (T)-2 * c.y : (T)2 * c.x;
+		} else {
+			cx<T> c = cmul(rd(k), ((const cx<T>*)p.aux2)[k]);
+			v = (T)2 * c.x;
+		}
+		if (p.postOp == OP_DST4_POST && (k & 1)) v = -v;
+		IO::str(out, base + (int64_t)k * sj, v * sc);
+		return;
+	}
+	case OP_BLUESTEIN_POST: {
+		cx<T> v = cmulc(rd(k), ((const cx<T>*)p.aux)[k]);
+		if (p.bluesteinSwapOut) v = cswap(v);
+		IO::stc(out, base + (int64_t)k * sj, cscale(v, sc));
+		return;
+	}
+	}
+}
+
+template <int R, typename T>
+__device__ inline void run_stage(const PassParams& p, const StageDesc& sd, int si, const cx<T>* __restrict__ src,
+                                 cx<T>* __restrict__ dst, uint32_t tid, uint32_t nthr) {
+	const uint32_t nb = p.L / R;            // butterflies per sub-FFT
+	const uint32_t total = nb << p.logT;    // over the T sub-FFTs of the workgroup
+	const uint32_t S = sd.S;
+	const uint32_t Tp = p.Tp, ps = p.padShift;
+	const cx<T>* lut = (const cx<T>*)p.lut + sd.lutOff;
+	const bool alongF = p.T >= 16;
+	for (uint32_t u = tid; u < total; u += nthr) {
+		uint32_t f, t;
+		if (alongF) { f = u & (p.T - 1); t = u >> p.logT; }
+		else p.divNb[si].divmod(u, f, t);
+		uint32_t q, s;
+		if (S == 1) { q = t; s = 0; }
+		else p.divS[si].divmod(t, q, s);
+		cx<T> v[R];
+#pragma unroll
+		for (int i = 0; i < R; i++) {
+			const uint32_t a = t + i * nb;
+			v[i] = src[(a + (a >> ps)) * Tp + f];
+		}
+		if (S > 1) {
+#pragma unroll
+			for (int i = 1; i < R; i++) v[i] = cmul(v[i], lut[(i - 1) * S + s]);
+		}
+		dft<R, T>(v);
+		const uint32_t ob = q * S * R + s;
+#pragma unroll
+		for (int k = 0; k < R; k++) {
+			const uint32_t a = ob + k * S;
+			dst[(a + (a >> ps)) * Tp + f] = v[k];
+		}
+	}
+}
+
+// Rader stage, direct-multiplication form (reference: appendMultRaderStage, vkFFT_RaderKernels.h:1278):
+// a prime-radix butterfly evaluated as a dense (P x P) DFT from a table of the P-th roots of unity.
+template <typename T>
+__device__ inline void run_stage_direct(const PassParams& p, const StageDesc& sd, int si, const cx<T>* __restrict__ src,
+                                        cx<T>* __restrict__ dst, uint32_t tid, uint32_t nthr) {
+	const uint32_t R = sd.radix;
+	const uint32_t nb = p.L / R;
+	const uint32_t S = sd.S;
+	const uint32_t Tp = p.Tp, ps = p.padShift;
+	const cx<T>* lut = (const cx<T>*)p.lut + sd.lutOff;   // stage twiddles (R-1 runs of S)
+	const cx<T>* root = (const cx<T>*)p.lut + sd.aux0;    // exp(-2 pi i m / R), m = 0..R-1
+	// one thread per output element: (f, t, k)
+	const uint32_t total = (nb * R) << p.logT;
+	for (uint32_t u = tid; u < total; u += nthr) {
+		uint32_t f = u & (p.T - 1), rest = u >> p.logT;
+		uint32_t k, t;
+		p.divNb[si].divmod(rest, k, t); // k slow so that neighbouring lanes share k (broadcast roots)
+		uint32_t q, s;
+		if (S == 1) { q = t; s = 0; }
+		else p.divS[si].divmod(t, q, s);
+		cx<T> acc = {(T)0, (T)0};
+		uint32_t m = 0; // (i*k) mod R
+		for (uint32_t i = 0; i < R; i++) {
+			const uint32_t a = t + i * nb;
+			cx<T> x = src[(a + (a >> ps)) * Tp + f];
+			if (S > 1 && i > 0) x = cmul(x, lut[(i - 1) * S + s]);
+			cx<T> w = root[m];
+			acc.x += x.x * w.x - x.y * w.y;
+			acc.y += x.x * w.y + x.y * w.x;
+			m += k; if (m >= R) m -= R;
+		}
+		const uint32_t a = q * S * R + s + k * S;
+		dst[(a + (a >> ps)) * Tp + f] = acc;
+	}
+}
+
+template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kernel(const PassParams p) {
+	VKFFT_DYN_SMEM(smem_raw)
+	cx<T>* bufA = (cx<T>*)smem_raw;
+	cx<T>* bufB = bufA + p.ldsElems;
+	const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+
+	// which tile of which (g1,g2)
+	uint32_t wg = blockIdx.x;
+	const uint32_t tile = wg % p.tilesPerG0;
+	wg /= p.tilesPerG0;
+	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
+	const uint32_t g0base = tile << p.logT;
+	const uint32_t remain = p.dim[0].count - g0base;
+	const uint32_t nvalid = remain < p.T ? remain : p.T;
+	const int64_t inBase = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)g0base * p.dim[0].inStride;
+	const int64_t outBase = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)g0base * p.dim[0].outStride;
+	const uint32_t Tp = p.Tp, ps = p.padShift;
+
+	// ---- gather-load -------------------------------------------------------------------------------
+	{
+		const uint32_t total = p.L << p.logT;
+		for (uint32_t idx = tid; idx < total; idx += nthr) {
+			uint32_t f, pos;
+			if (p.colMode) { f = idx & (p.T - 1); pos = idx >> p.logT; }
+			else p.divL.divmod(idx, f, pos);
+			cx<T> v = {(T)0, (T)0};
+			if (f < nvalid) v = pre_gather<T>(p, p.in, inBase + (int64_t)f * p.dim[0].inStride, pos);
+			if (p.swapIn) v = cswap(v);
+			bufA[(pos + (pos >> ps)) * Tp + f] = v;
+		}
+	}
+	__syncthreads();
+
+	cx<T>* src = bufA;
+	cx<T>* dst = bufB;
+	const int reps = p.midOp == OP_BLUESTEIN_MID ? 2 : 1;
+	for (int rep = 0; rep < reps; rep++) {
+		for (uint32_t si = 0; si < p.nStages; si++) {
+			const StageDesc& sd = p.st[si];
+			if (sd.kind == 1) run_stage_direct<T>(p, sd, si, src, dst, tid, nthr);
+			else switch (sd.radix) {
+				case 2: run_stage<2, T>(p, sd, si, src, dst, tid, nthr); break;
+				case 3: run_stage<3, T>(p, sd, si, src, dst, tid, nthr); break;
+				case 4: run_stage<4, T>(p, sd, si, src, dst, tid, nthr); break;
+				case 5: run_stage<5, T>(p, sd, si, src, dst, tid, nthr); break;
+				case 7: run_stage<7, T>(p, sd, si, src, dst, tid, nthr); break;
+				case 8: run_stage<8, T>(p, sd, si, src, dst, tid, nthr); break;
+				case 11: run_stage<11, T>(p, sd, si, src, dst, tid, nthr); break;
+				case 13: run_stage<13, T>(p, sd, si, src, dst, tid, nthr); break;
+				case 16: run_stage<16, T>(p, sd, si, src, dst, tid, nthr); break;
+				default: break;
+			}
+			__syncthreads();
+			cx<T>* tmp = src; src = dst; dst = tmp;
+		}
+		if (rep == 0 && reps == 2) {
+			// Bluestein: multiply the spectrum by FFT(chirp) (aux2 already carries 1/L) and run the stage
+			// list again as an inverse transform through the swap identity.
+			const uint32_t total = p.L << p.logT;
+			const cx<T>* bh = (const cx<T>*)p.aux2;
+			for (uint32_t idx = tid; idx < total; idx += nthr) {
+				uint32_t f, pos;
+				if (p.T >= 16) { f = idx & (p.T - 1); pos = idx >> p.logT; }
+				else p.divL.divmod(idx, f, pos);
+				const uint32_t li = (pos + (pos >> ps)) * Tp + f;
+				src[li] = cswap(cmul(src[li], bh[pos]));
+			}
+			__syncthreads();
+		}
+	}
+
+	// ---- gather-store ------------------------------------------------------------------------------
+	{
+		const uint32_t total = p.outLen << p.logT;
+		const bool swapO = p.swapOut || reps == 2;
+		for (uint32_t idx = tid; idx < total; idx += nthr) {
+			uint32_t f, k;
+			if (p.colModeOut) { f = idx & (p.T - 1); k = idx >> p.logT; }
+			else p.divOutLen.divmod(idx, f, k);
+			if (f >= nvalid) continue;
+			auto rd = [&](uint32_t a) -> cx<T> {
+				cx<T> v = src[(a + (a >> ps)) * Tp + f];
+				return swapO ? cswap(v) : v;
+			};
+			uint32_t colIdx = 0;
+			if (p.postOp == OP_TWIDDLE_4STEP) { uint32_t qq, rr; p.fsColDiv.divmod(g0base + f, qq, rr); colIdx = qq; }
+			post_store<T>(p, p.out, outBase + (int64_t)f * p.dim[0].outStride, k, colIdx, rd);
+		}
+	}
+}
+
+} // namespace vkfft_mi355x

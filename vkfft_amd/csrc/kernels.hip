@@ -1,0 +1,84 @@
+// Kernel instantiations and the launch layer (the counterpart of the reference's hipModuleLaunchKernel
+// glue, vkFFT_DispatchPlan.h:226-295 — but on ahead-of-time compiled gfx950 kernels).
+#include "engine.h"
+#include "kernel_generic.h"
+#include "kernel_pow2.h"
+#include <cstdio>
+#include <algorithm>
+
+namespace vkfft_mi355x {
+
+int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
+	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
+	if (grid64 == 0) return 0;
+	if (grid64 > 0x7fffffffull) return 4039;
+	const dim3 grid((uint32_t)grid64), block(pp.threads);
+	switch (pp.kernel) {
+	case KERNEL_GENERIC:
+		if (pp.dp) hipLaunchKernelGGL(generic_pass_kernel<double>, grid, block, pp.ldsBytes, stream, prm);
+		else hipLaunchKernelGGL(generic_pass_kernel<float>, grid, block, pp.ldsBytes, stream, prm);
+		break;
+	case KERNEL_POW2_ROW:
+	case KERNEL_POW2_COL:
+		return launch_pow2(pp, prm, stream);
+	default:
+		return 4039;
+	}
+	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
+
+static int launch_with_hostloop(const PassPlan& pp, PassParams prm, hipStream_t stream, size_t level) {
+	if (level == pp.hostLoop.size()) return launch_pass(pp, prm, stream);
+	const HostDim& h = pp.hostLoop[level];
+	for (uint64_t i = 0; i < h.count; i++) {
+		PassParams q = prm;
+		q.in = (const char*)prm.in + (int64_t)i * h.inStride * pp.inElemBytes;
+		q.out = (char*)prm.out + (int64_t)i * h.outStride * pp.outElemBytes;
+		int r = launch_with_hostloop(pp, q, stream, level + 1);
+		if (r) return r;
+	}
+	return 0;
+}
+
+static void bind(const DirectionPlan& plan, const PassPlan& pp, const LaunchBuffers& bufs, PassParams& prm) {
+	prm.in = (const char*)bufs.base[pp.inRole] + pp.inOffset * pp.inElemBytes;
+	prm.out = (char*)bufs.base[pp.outRole] + pp.outOffset * pp.outElemBytes;
+	const char* ar = (const char*)plan.dArena;
+	prm.lut = pp.lutOff != (size_t)-1 ? ar + pp.lutOff : nullptr;
+	prm.aux = pp.auxOff != (size_t)-1 ? ar + pp.auxOff : nullptr;
+	prm.aux2 = pp.aux2Off != (size_t)-1 ? ar + pp.aux2Off : nullptr;
+}
+
+int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream) {
+	const int np = (int)plan.passes.size();
+	for (int i = 0; i < np; i++) {
+		if (i == plan.chunkFirst && plan.chunkBatch > 0) {
+			// passes [chunkFirst, chunkLast] run chunk by chunk over the batch so that the scratch written by
+			// one pass is still resident in the Infinity Cache when the next pass reads it
+			for (uint64_t b0 = 0; b0 < plan.totalBatch; b0 += plan.chunkBatch) {
+				const uint64_t nb = std::min<uint64_t>(plan.chunkBatch, plan.totalBatch - b0);
+				for (int k = plan.chunkFirst; k <= plan.chunkLast; k++) {
+					const PassPlan& pp = plan.passes[k];
+					PassParams prm = pp.prm;
+					bind(plan, pp, bufs, prm);
+					BatchDim& bd = prm.dim[pp.chunkDim];
+					if (pp.inRole != ROLE_TEMP) prm.in = (const char*)prm.in + (int64_t)b0 * bd.inStride * pp.inElemBytes;
+					if (pp.outRole != ROLE_TEMP) prm.out = (char*)prm.out + (int64_t)b0 * bd.outStride * pp.outElemBytes;
+					bd.count = (uint32_t)nb;
+					int r = launch_with_hostloop(pp, prm, stream, 0);
+					if (r) return r;
+				}
+			}
+			i = plan.chunkLast;
+			continue;
+		}
+		const PassPlan& pp = plan.passes[i];
+		PassParams prm = pp.prm;
+		bind(plan, pp, bufs, prm);
+		int r = launch_with_hostloop(pp, prm, stream, 0);
+		if (r) return r;
+	}
+	return 0;
+}
+
+} // namespace vkfft_mi355x

@@ -1,0 +1,561 @@
+// Planner: transform description -> list of passes (kernel launches) with all index maps, twiddle tables
+// and pre/post operations resolved.  Behavioural counterpart of the reference's VkFFTScheduler
+// (vkFFT_Scheduler.h:2223: factorisation, pass count from on-chip capacity, radix list),
+// VkFFTSplitAxisBlock (vkFFT_AxisBlockSplitter.h:26: workgroup shape), VkFFTPlanAxis
+// (vkFFT_Plan_FFT.h:33: strides, batch folding) and VkFFT_AllocateLUT (vkFFT_ManageLUT.h:28: tables
+// computed in extended precision on the CPU).  The decisions themselves are re-derived for MI355X:
+// 160 KiB LDS per workgroup, 256-byte coalescing segments for strided tiles, Infinity-Cache chunking.
+#include "engine.h"
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+#include <complex>
+#include <map>
+
+namespace vkfft_mi355x {
+
+typedef long double ld;
+typedef std::complex<ld> cld;
+static const ld PI_LD = 3.14159265358979323846264338327950288419716939937510L;
+
+// exp(-2*pi*i*num/den), argument reduced exactly in integers first
+static cld unit_root(uint64_t num, uint64_t den) {
+	num %= den;
+	// octant reduction keeps |angle| <= pi/4 for best accuracy
+	ld x = (ld)num / (ld)den; // in [0,1)
+	uint64_t oct8 = (uint64_t)(8 * x + 0.5L);
+	(void)oct8;
+	ld ang = 2 * PI_LD * x;
+	return cld(cosl(ang), -sinl(ang));
+}
+// exp(-i*pi*num/den)
+static cld unit_root_pi(uint64_t num, uint64_t den) { return unit_root(num, 2 * den); }
+
+struct Arena {
+	std::vector<unsigned char>& b;
+	explicit Arena(std::vector<unsigned char>& v) : b(v) {}
+	size_t alloc(size_t bytes) {
+		size_t off = (b.size() + 255) & ~(size_t)255;
+		b.resize(off + bytes);
+		return off;
+	}
+	template <typename T> void put(size_t off, size_t idx, cld v) {
+		T* p = (T*)(b.data() + off);
+		p[2 * idx] = (T)v.real();
+		p[2 * idx + 1] = (T)v.imag();
+	}
+	void putc(size_t off, size_t idx, cld v, bool dp) {
+		if (dp) put<double>(off, idx, v); else put<float>(off, idx, v);
+	}
+};
+
+std::vector<uint32_t> factorize_radices(uint64_t n, bool* smooth) {
+	std::vector<uint32_t> f;
+	const uint32_t primes[6] = {2, 3, 5, 7, 11, 13};
+	for (uint32_t p : primes) while (n % p == 0) { f.push_back(p); n /= p; }
+	// remaining part: trial division (larger primes are handled by Rader/Bluestein)
+	for (uint64_t p = 17; p * p <= n; p += 2) while (n % p == 0) { f.push_back((uint32_t)p); n /= p; }
+	if (n > 1) f.push_back((uint32_t)n);
+	if (smooth) { *smooth = true; for (uint32_t p : f) if (p > 13) *smooth = false; }
+	return f;
+}
+
+// radix list for one pass of length L (L's prime factors <= 13, or small Rader primes)
+static std::vector<uint32_t> radix_schedule(uint64_t L) {
+	bool smooth;
+	std::vector<uint32_t> pf = factorize_radices(L, &smooth);
+	int twos = 0;
+	std::vector<uint32_t> rad;
+	for (uint32_t p : pf) { if (p == 2) twos++; else rad.push_back(p); }
+	// split 2^twos into ceil(twos/4) radices of (almost) equal size, largest first
+	if (twos > 0) {
+		int parts = (twos + 3) / 4;
+		int base = twos / parts, extra = twos % parts;
+		for (int i = 0; i < parts; i++) rad.push_back(1u << (base + (i < extra ? 1 : 0)));
+	}
+	std::sort(rad.begin(), rad.end(), [](uint32_t a, uint32_t b) { return a > b; });
+	return rad;
+}
+
+static uint32_t ilog2(uint64_t v) { uint32_t l = 0; while ((1ull << (l + 1)) <= v) l++; return l; }
+static uint32_t ceil_log2(uint64_t v) { uint32_t l = 0; while ((1ull << l) < v) l++; return l; }
+
+struct PassBuild {
+	uint64_t L = 0;
+	int64_t inStrideJ = 1, outStrideJ = 1;
+	std::vector<HostDim> dims; // dims[0] tiled
+	bool colIn = false, colOut = false;
+	bool dp = false;
+	uint32_t preOp = OP_NONE, midOp = OP_NONE, postOp = OP_NONE;
+	uint32_t inLen = 0, outLen = 0, opN = 0;
+	bool swapIn = false, swapOut = false, bsSwapIn = false, bsSwapOut = false;
+	uint64_t fsN = 0; uint32_t fsColDiv = 1;
+	double scale = 1.0;
+	int inRole = ROLE_BUFFER, outRole = ROLE_BUFFER;
+	int64_t inOffset = 0, outOffset = 0;
+	bool realIn = false, realOut = false;
+	uint32_t raderDirectMax = 0;
+	std::string label;
+	uint32_t forceT = 0;
+	bool noCollapse = false;
+	int chunkDim = -1;
+	uint64_t maxLds = 160 * 1024;
+	// tables prepared by the caller (arena offsets)
+	size_t auxOff = (size_t)-1, aux2Off = (size_t)-1;
+};
+
+// collapse dims that form one arithmetic progression on both sides; keep dims[0] (tiled) separate unless
+// it merges with dims[1] exactly (then tiles simply continue across the boundary)
+static void collapse_dims(std::vector<HostDim>& d) {
+	// drop count-1 dims (except keep at least one)
+	std::vector<HostDim> r;
+	for (auto& x : d) if (x.count > 1) r.push_back(x);
+	if (r.empty()) r.push_back({1, 0, 0});
+	for (size_t i = 0; i + 1 < r.size();) {
+		if ((int64_t)r[i].count * r[i].inStride == r[i + 1].inStride && (int64_t)r[i].count * r[i].outStride == r[i + 1].outStride
+		    && r[i].count * r[i + 1].count < (1ull << 31)) {
+			r[i].count *= r[i + 1].count;
+			r.erase(r.begin() + i + 1);
+		} else i++;
+	}
+	d = r;
+}
+
+static int finish_pass(const PassBuild& b, Arena& ar, PassPlan& pp) {
+	PassParams& p = pp.prm;
+	memset(&p, 0, sizeof(p));
+	const bool dp = b.dp;
+	const size_t es = dp ? 16 : 8;
+	p.L = (uint32_t)b.L;
+	std::vector<uint32_t> rad = radix_schedule(b.L);
+	if (b.L == 1) rad.clear();
+	if (rad.size() > (size_t)kMaxStages) return 3002;
+	p.nStages = (uint32_t)rad.size();
+	// stage twiddles
+	uint64_t lutElems = 0, S = 1;
+	for (uint32_t R : rad) { if (S > 1) lutElems += (uint64_t)(R - 1) * S; if (R > 16) lutElems += R; S *= R; }
+	size_t lutOff = ar.alloc((lutElems + 1) * es);
+	uint64_t cur = 0; S = 1;
+	for (size_t si = 0; si < rad.size(); si++) {
+		uint32_t R = rad[si];
+		StageDesc& sd = p.st[si];
+		sd.radix = R; sd.S = (uint32_t)S; sd.lutOff = (uint32_t)cur; sd.kind = R > 16 ? 1 : 0;
+		if (R > 16 && R > b.raderDirectMax) return 3002;
+		if (S > 1) {
+			for (uint32_t i = 1; i < R; i++)
+				for (uint64_t s = 0; s < S; s++) ar.putc(lutOff, cur + (uint64_t)(i - 1) * S + s, unit_root((uint64_t)i * s, (uint64_t)R * S), dp);
+			cur += (uint64_t)(R - 1) * S;
+		}
+		if (R > 16) {
+			sd.aux0 = (uint32_t)cur;
+			for (uint32_t m = 0; m < R; m++) ar.putc(lutOff, cur + m, unit_root(m, R), dp);
+			cur += R;
+		}
+		p.divNb[si] = make_fastdiv((uint32_t)(b.L / R));
+		p.divS[si] = make_fastdiv((uint32_t)S);
+		S *= R;
+	}
+	pp.lutOff = lutOff;
+	pp.auxOff = b.auxOff; pp.aux2Off = b.aux2Off;
+
+	std::vector<HostDim> dims = b.dims;
+	if (dims.empty()) dims.push_back({1, 0, 0});
+	// dims[0] stays the tiled dim; collapse the rest among themselves
+	if (!b.noCollapse) {
+		std::vector<HostDim> rest(dims.begin() + 1, dims.end());
+		collapse_dims(rest);
+		HostDim d0 = dims[0];
+		// merge rest[0] into d0 when contiguous (typical: rows of a batch)
+		if (!rest.empty() && rest[0].count > 1 && (int64_t)d0.count * d0.inStride == rest[0].inStride
+		    && (int64_t)d0.count * d0.outStride == rest[0].outStride && d0.count * rest[0].count < (1ull << 31)) {
+			d0.count *= rest[0].count;
+			rest.erase(rest.begin());
+		}
+		dims.clear(); dims.push_back(d0);
+		for (auto& r : rest) if (r.count > 1) dims.push_back(r);
+	}
+	while (dims.size() < 3) dims.push_back({1, 0, 0});
+	pp.hostLoop.clear();
+	while (dims.size() > 3) { pp.hostLoop.push_back(dims.back()); dims.pop_back(); }
+	for (int i = 0; i < 3; i++) { p.dim[i].count = (uint32_t)dims[i].count; p.dim[i].inStride = dims[i].inStride; p.dim[i].outStride = dims[i].outStride; }
+	p.inStrideJ = b.inStrideJ; p.outStrideJ = b.outStrideJ;
+
+	// workgroup tile
+	const bool anyCol = b.colIn || b.colOut;
+	uint32_t T;
+	const uint64_t ldsPerSub = 2 * (b.L + b.L / 16 + 2) * es; // both ping-pong buffers
+	if (b.forceT) T = b.forceT;
+	else if (anyCol) {
+		T = dp ? 16 : 32; // 256-byte segments
+		while (T > 1 && (uint64_t)(T + 1) * ldsPerSub > (b.maxLds * 7) / 10) T >>= 1; // leave room for two workgroups per CU when possible
+		while (T > 1 && (uint64_t)(T + 1) * ldsPerSub > b.maxLds) T >>= 1;
+		if (T < 4 && (uint64_t)5 * ldsPerSub <= b.maxLds) T = 4;
+	} else {
+		// unit-stride rows: enough sub-FFTs for >= ~2048 points per workgroup
+		T = 1;
+		while (T < 64 && (uint64_t)T * b.L < 2048 && (uint64_t)(2 * T + 1) * ldsPerSub <= 64 * 1024) T <<= 1;
+	}
+	while (T > 1 && T / 2 >= dims[0].count) T >>= 1;
+	if ((uint64_t)(T == 1 ? 1 : T + 1) * ldsPerSub > b.maxLds) return 3002;
+	p.T = T; p.logT = ilog2(T);
+	p.Tp = T == 1 ? 1 : T + 1;
+	p.padShift = T >= 16 ? 31 : 4;
+	p.colMode = b.colIn ? 1 : 0; p.colModeOut = b.colOut ? 1 : 0;
+	p.swapIn = b.swapIn; p.swapOut = b.swapOut;
+	p.preOp = b.preOp; p.midOp = b.midOp; p.postOp = b.postOp;
+	p.bluesteinSwapIn = b.bsSwapIn; p.bluesteinSwapOut = b.bsSwapOut;
+	p.inLen = b.inLen ? b.inLen : (uint32_t)b.L;
+	p.outLen = b.outLen ? b.outLen : (uint32_t)b.L;
+	p.opN = b.opN;
+	p.fsN = (uint32_t)b.fsN;
+	p.fsColDiv = make_fastdiv(b.fsColDiv);
+	p.scale = b.scale;
+	p.divL = make_fastdiv((uint32_t)b.L);
+	p.divOutLen = make_fastdiv(p.outLen);
+	const uint64_t padded = p.padShift >= 31 ? b.L : b.L + (b.L >> p.padShift);
+	p.ldsElems = (uint32_t)((padded + 1) * p.Tp);
+	p.tilesPerG0 = (uint32_t)((dims[0].count + T - 1) / T);
+	pp.ldsBytes = 2 * (size_t)p.ldsElems * es;
+	if (pp.ldsBytes > b.maxLds) return 3002;
+	// threads: about one radix-8 butterfly per thread per stage
+	uint64_t work = (uint64_t)T * b.L / 8;
+	uint32_t thr = 64;
+	while (thr < work && thr < 1024) thr <<= 1;
+	if (pp.ldsBytes > 48 * 1024 && thr < 256) thr = 256;
+	pp.threads = thr;
+	pp.dp = dp;
+	pp.kernel = KERNEL_GENERIC;
+	pp.inRole = b.inRole; pp.outRole = b.outRole;
+	pp.inOffset = b.inOffset; pp.outOffset = b.outOffset;
+	pp.inElemBytes = (int)((b.realIn ? 1 : 2) * (dp ? 8 : 4));
+	pp.outElemBytes = (int)((b.realOut ? 1 : 2) * (dp ? 8 : 4));
+	pp.label = b.label;
+	pp.chunkDim = b.chunkDim;
+
+	// Four-Step two-level table
+	if (b.postOp == OP_TWIDDLE_4STEP) {
+		uint32_t lo = (ceil_log2(b.fsN) + 1) / 2;
+		uint64_t nlo = 1ull << lo, nhi = (b.fsN + nlo - 1) / nlo;
+		size_t off = ar.alloc((nlo + nhi) * es);
+		for (uint64_t i = 0; i < nlo; i++) ar.putc(off, i, unit_root(i, b.fsN), dp);
+		for (uint64_t i = 0; i < nhi; i++) ar.putc(off, nlo + i, unit_root(i * nlo, b.fsN), dp);
+		p.fsLoBits = lo;
+		pp.auxOff = off;
+	}
+	return 0;
+}
+
+// ---- single-pass capacity ------------------------------------------------------------------------------
+static uint64_t max_row_len(bool dp, uint64_t maxLds) { // unit-stride, T = 1
+	uint64_t es = dp ? 16 : 8;
+	uint64_t L = 1;
+	while (2 * (2 * L + 2 * L / 16 + 2) * es <= maxLds) L *= 2;
+	return L; // fp32: 8192, fp64: 4096 at 160 KiB
+}
+static uint64_t max_col_len(bool dp, uint64_t maxLds, uint32_t T) {
+	uint64_t es = dp ? 16 : 8;
+	return maxLds / ((uint64_t)(T + 1) * 2 * es) - 2;
+}
+
+static bool is_supported_len(uint64_t L, uint32_t directMax) {
+	std::vector<uint32_t> pf = factorize_radices(L, nullptr);
+	for (uint32_t p : pf) if (p > 13 && p > directMax) return false;
+	return true;
+}
+
+// choose N = n[0]*n[1](*n[2]); n[0] is the pass that runs over the largest stride (executed first).
+// Preference order: two passes with wide tiles and two workgroups per CU, ..., three passes last.
+static bool choose_split(uint64_t N, bool dp, uint64_t maxLds, uint32_t directMax, std::vector<uint64_t>& out) {
+	struct Opt { uint32_t T; uint64_t budget; };
+	const uint32_t Tw = dp ? 16 : 32;
+	const Opt opts[5] = {{Tw, maxLds / 2}, {Tw / 2, maxLds / 2}, {Tw, maxLds}, {Tw / 2, maxLds}, {Tw / 4, maxLds}};
+	std::vector<uint64_t> divs;
+	for (uint64_t d = 1; d * d <= N; d++) if (N % d == 0) { divs.push_back(d); if (d != N / d) divs.push_back(N / d); }
+	std::sort(divs.begin(), divs.end());
+	auto ok = [&](uint64_t L, uint64_t cap) { return L >= 2 && L <= cap && is_supported_len(L, directMax); };
+	for (const Opt& o : opts) {
+		const uint64_t cap = max_col_len(dp, o.budget, o.T);
+		uint64_t best = 0;
+		for (uint64_t d : divs) if (d <= N / d && ok(d, cap) && ok(N / d, cap)) best = d;
+		if (best) { out = {N / best, best}; return true; }
+	}
+	for (const Opt& o : opts) {
+		const uint64_t cap = max_col_len(dp, o.budget, o.T);
+		double bestCost = 1e300; uint64_t ba = 0, bb = 0;
+		for (uint64_t a : divs) if (ok(a, cap)) for (uint64_t b2 : divs) if ((N / a) % b2 == 0 && ok(b2, cap) && ok(N / a / b2, cap)) {
+			uint64_t c = N / a / b2;
+			double m = (double)std::max(a, std::max(b2, c));
+			if (m < bestCost) { bestCost = m; ba = a; bb = b2; }
+		}
+		if (ba) { out = {ba, bb, N / ba / bb}; return true; }
+	}
+	return false;
+}
+
+struct AxisJob {
+	uint64_t N = 0;                 // logical length of this axis
+	int64_t inStrideJ = 1, outStrideJ = 1;
+	std::vector<HostDim> others;    // every other dimension (count, inStride, outStride); others[0] should be the unit-stride one for strided axes
+	bool dp = false;
+	bool inverse = false;
+	double scale = 1.0;
+	int inRole = ROLE_BUFFER, outRole = ROLE_BUFFER;
+	int axisIndex = 0;
+	uint64_t batchOuter = 1; // count of the outermost "others" entry (chunking candidate)
+};
+
+static uint32_t direct_max(const TransformDesc& d) { return (uint32_t)std::min<uint64_t>(d.raderMultMax, 61); }
+
+// host-side mixed-radix FFT in long double (for Bluestein's FFT(chirp))
+static void host_fft(std::vector<cld>& a) {
+	size_t n = a.size();
+	if (n <= 1) return;
+	size_t p = 0;
+	for (size_t q : {2, 3, 5, 7, 11, 13}) if (n % q == 0) { p = q; break; }
+	if (!p) { // naive
+		std::vector<cld> r(n);
+		for (size_t k = 0; k < n; k++) { cld s = 0; for (size_t j = 0; j < n; j++) s += a[j] * unit_root((uint64_t)j * k % n, n); r[k] = s; }
+		a = r; return;
+	}
+	size_t m = n / p;
+	std::vector<std::vector<cld>> sub(p, std::vector<cld>(m));
+	for (size_t j = 0; j < n; j++) sub[j % p][j / p] = a[j];
+	for (auto& s : sub) host_fft(s);
+	for (size_t k = 0; k < n; k++) {
+		cld acc = 0;
+		for (size_t r = 0; r < p; r++) acc += sub[r][k % m] * unit_root((uint64_t)r * k % n, n);
+		a[k] = acc;
+	}
+}
+
+static uint64_t next_smooth(uint64_t n, int maxPrime) {
+	for (uint64_t m = n;; m++) {
+		uint64_t r = m;
+		for (int p : {2, 3, 5, 7, 11, 13}) { if (p > maxPrime) break; while (r % p == 0) r /= p; }
+		if (r == 1) return m;
+	}
+}
+
+// ---- C2C along one axis -------------------------------------------------------------------------------
+static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
+	const bool dp = j.dp;
+	const uint32_t dmax = direct_max(d);
+	const bool unit = j.inStrideJ == 1 && j.outStrideJ == 1;
+	bool smoothOK = is_supported_len(j.N, dmax);
+	const uint64_t rowCap = max_row_len(dp, d.maxLds);
+	PassBuild b;
+	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax;
+	b.inRole = j.inRole; b.outRole = j.outRole;
+	out.axisSplit[j.axisIndex][0] = j.N;
+
+	if (!smoothOK) {
+		// Bluestein (chirp-z) through a padded smooth length M >= 2N-1
+		const uint64_t N = j.N;
+		uint64_t M = d.forceBluesteinSize ? d.forceBluesteinSize : next_smooth(2 * N - 1, d.fixMaxRadixBluestein ? d.fixMaxRadixBluestein : 7);
+		uint64_t cap = unit ? rowCap : max_col_len(dp, d.maxLds, 4);
+		if (M > cap) return 3002; // multi-pass Bluestein: not yet
+		const size_t es = dp ? 16 : 8;
+		size_t chirpOff = ar.alloc(N * es), bhatOff = ar.alloc(M * es);
+		std::vector<cld> bext(M, cld(0, 0));
+		for (uint64_t n = 0; n < N; n++) {
+			unsigned __int128 sq = (unsigned __int128)n * n;
+			uint64_t e = (uint64_t)(sq % (2 * N));
+			cld c = std::conj(unit_root_pi(e, N)); // exp(+i pi n^2 / N)
+			ar.putc(chirpOff, n, c, dp);
+			bext[n] = c;
+			if (n) bext[M - n] = c;
+		}
+		host_fft(bext);
+		for (uint64_t k = 0; k < M; k++) ar.putc(bhatOff, k, bext[k] / (ld)M, dp);
+		b.L = M; b.inLen = (uint32_t)N; b.outLen = (uint32_t)N;
+		b.preOp = OP_BLUESTEIN_PRE; b.midOp = OP_BLUESTEIN_MID; b.postOp = OP_BLUESTEIN_POST;
+		b.bsSwapIn = b.bsSwapOut = j.inverse;
+		b.auxOff = chirpOff; b.aux2Off = bhatOff;
+		b.scale = j.scale;
+		b.inStrideJ = j.inStrideJ; b.outStrideJ = j.outStrideJ;
+		b.colIn = b.colOut = !unit;
+		b.dims = j.others;
+		b.label = "bluestein";
+		PassPlan pp; int r = finish_pass(b, ar, pp); if (r) return r;
+		passes.push_back(pp);
+		out.uploadsPerAxis[j.axisIndex] = 1;
+		return 0;
+	}
+
+	const uint64_t singleCap = unit ? rowCap : max_col_len(dp, d.maxLds, 4);
+	if (j.N <= singleCap) {
+		b.L = j.N;
+		b.inStrideJ = j.inStrideJ; b.outStrideJ = j.outStrideJ;
+		b.colIn = b.colOut = !unit;
+		b.dims = j.others;
+		b.swapIn = b.swapOut = j.inverse;
+		b.scale = j.scale;
+		b.label = unit ? "c2c-row" : "c2c-col";
+		PassPlan pp; int r = finish_pass(b, ar, pp); if (r) return r;
+		passes.push_back(pp);
+		out.uploadsPerAxis[j.axisIndex] = 1;
+		return 0;
+	}
+	if (!unit) return 3002; // multi-pass along a strided axis: not yet
+
+	// ---- Four-Step on a unit-stride axis: N = n0 * M, recursively M = n1 * n2 -------------------------
+	std::vector<uint64_t> sp;
+	if (!choose_split(j.N, dp, d.maxLds, dmax, sp)) return 3002;
+	out.uploadsPerAxis[j.axisIndex] = (uint32_t)sp.size();
+	for (size_t i = 0; i < sp.size(); i++) out.axisSplit[j.axisIndex][i] = sp[sp.size() - 1 - i];
+	const uint64_t N = j.N;
+	// every "other" dim of the job has stride multiples of N on a dense layout in temp; temp keeps the batch
+	// layout of the *input* side compacted: sub-transform b lives at b*N.
+	std::vector<HostDim> othersIn = j.others, othersTmp = j.others;
+	{ // dense enumeration of the other dims inside temp
+		int64_t run = (int64_t)N;
+		for (auto& o : othersTmp) { o.inStride = run; o.outStride = run; run *= (int64_t)o.count; }
+	}
+	auto dimsFor = [&](const HostDim& tiled, std::vector<HostDim> extra, int inKind, int outKind) {
+		// inKind/outKind: 0 = user layout of the axis job (in / out side), 1 = temp layout
+		std::vector<HostDim> r; r.push_back(tiled);
+		for (auto& e : extra) r.push_back(e);
+		for (size_t i = 0; i < j.others.size(); i++) {
+			HostDim h; h.count = j.others[i].count;
+			h.inStride = inKind == 0 ? j.others[i].inStride : othersTmp[i].inStride;
+			h.outStride = outKind == 0 ? j.others[i].outStride : othersTmp[i].outStride;
+			r.push_back(h);
+		}
+		return r;
+	};
+	if (sp.size() == 2) {
+		const uint64_t n0 = sp[0], M = sp[1];
+		// pass A: x[n0][M] columns, FFT over n0, twiddle, store transposed Y^T[m][k0] into temp
+		PassBuild a = b;
+		a.L = n0; a.inStrideJ = (int64_t)M; a.outStrideJ = 1;
+		a.colIn = true; a.colOut = false;
+		a.dims = dimsFor({M, 1, (int64_t)n0}, {}, 0, 1);
+		a.swapIn = j.inverse; a.postOp = OP_TWIDDLE_4STEP; a.fsN = N; a.fsColDiv = 1;
+		a.inRole = j.inRole; a.outRole = ROLE_TEMP; a.label = "4step-A"; a.noCollapse = true; a.chunkDim = (int)j.others.size();
+		PassPlan pa; int r = finish_pass(a, ar, pa); if (r) return r;
+		// pass B: temp[m][k0]: FFT over m (stride n0) for T adjacent k0; X[k0 + n0*k1]
+		PassBuild c = b;
+		c.L = M; c.inStrideJ = (int64_t)n0; c.outStrideJ = (int64_t)n0;
+		c.colIn = c.colOut = true;
+		c.dims = dimsFor({n0, 1, 1}, {}, 1, 0);
+		c.swapOut = j.inverse; c.scale = j.scale;
+		c.inRole = ROLE_TEMP; c.outRole = j.outRole; c.label = "4step-B"; c.noCollapse = true; c.chunkDim = (int)j.others.size();
+		PassPlan pb; r = finish_pass(c, ar, pb); if (r) return r;
+		passes.push_back(pa); passes.push_back(pb);
+	} else {
+		const uint64_t n0 = sp[0], n1 = sp[1], n2 = sp[2], M = n1 * n2;
+		PassBuild a = b;
+		a.L = n0; a.inStrideJ = (int64_t)M; a.outStrideJ = 1;
+		a.colIn = true; a.colOut = false;
+		a.dims = dimsFor({M, 1, (int64_t)n0}, {}, 0, 1);
+		a.swapIn = j.inverse; a.postOp = OP_TWIDDLE_4STEP; a.fsN = N; a.fsColDiv = 1;
+		a.inRole = j.inRole; a.outRole = ROLE_TEMP; a.label = "4step3-A"; a.noCollapse = true; a.chunkDim = (int)j.others.size();
+		PassPlan pa; int r = finish_pass(a, ar, pa); if (r) return r;
+		// pass B (in place on temp): layout [m = i1*n2 + i2][k0]; FFT over i1 (stride n2*n0); tiled dim c = i2*n0 + k0
+		PassBuild bb = b;
+		bb.L = n1; bb.inStrideJ = bb.outStrideJ = (int64_t)(n2 * n0);
+		bb.colIn = bb.colOut = true;
+		bb.dims = dimsFor({n2 * n0, 1, 1}, {}, 1, 1);
+		bb.postOp = OP_TWIDDLE_4STEP; bb.fsN = M; bb.fsColDiv = (uint32_t)n0;
+		bb.inRole = bb.outRole = ROLE_TEMP; bb.label = "4step3-B"; bb.noCollapse = true; bb.chunkDim = (int)j.others.size();
+		PassPlan pb; r = finish_pass(bb, ar, pb); if (r) return r;
+		// pass C: temp [k1][i2][k0]: FFT over i2 (stride n0); out X[k0 + n0*(k1 + n1*k2)]
+		PassBuild c = b;
+		c.L = n2; c.inStrideJ = (int64_t)n0; c.outStrideJ = (int64_t)(n1 * n0);
+		c.colIn = c.colOut = true;
+		c.dims = dimsFor({n0, 1, 1}, {{n1, (int64_t)(n2 * n0), (int64_t)n0}}, 1, 0);
+		c.swapOut = j.inverse; c.scale = j.scale;
+		c.inRole = ROLE_TEMP; c.outRole = j.outRole; c.label = "4step3-C"; c.noCollapse = true; c.chunkDim = (int)j.others.size() + 1;
+		PassPlan pc; r = finish_pass(c, ar, pc); if (r) return r;
+		passes.push_back(pa); passes.push_back(pb); passes.push_back(pc);
+	}
+	uint64_t nsub = 1;
+	for (auto& o : j.others) nsub *= o.count;
+	out.tempBytes = std::max<uint64_t>(out.tempBytes, nsub * N * (dp ? 16 : 8));
+	return 0;
+}
+
+// ---- top level ----------------------------------------------------------------------------------------
+int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
+	out = DirectionPlan();
+	Arena ar(out.arena);
+	const bool dp = d.dp;
+	const int nd = d.fftDim;
+
+	// source / destination roles and their strides
+	int srcRole = ROLE_BUFFER, dstRole = ROLE_BUFFER;
+	uint64_t sStr[5], dStr[5];
+	for (int i = 0; i < 5; i++) { sStr[i] = d.bufStride[i]; dStr[i] = d.bufStride[i]; }
+	if (!d.inverse) {
+		if (d.inFormatted) { srcRole = ROLE_INPUT; for (int i = 0; i < 5; i++) sStr[i] = d.inStride[i]; }
+		if (d.outFormatted) { dstRole = ROLE_OUTPUT; for (int i = 0; i < 5; i++) dStr[i] = d.outStride[i]; }
+	} else {
+		if (d.outFormatted) { srcRole = ROLE_OUTPUT; for (int i = 0; i < 5; i++) sStr[i] = d.outStride[i]; }
+		if (d.inFormatted && d.inverseReturnToInput) { dstRole = ROLE_INPUT; for (int i = 0; i < 5; i++) dStr[i] = d.inStride[i]; }
+	}
+
+	// axis execution order (reference: forward 0..n-1, inverse n-1..0; vkFFT_RunApp.h:114-321, :469-648)
+	std::vector<int> order;
+	for (int a = 0; a < nd; a++) if (!d.omit[a] && d.size[a] > 1) order.push_back(a);
+	if (d.inverse) std::reverse(order.begin(), order.end());
+	if (order.empty()) return 0;
+
+	// normalisation factor
+	double scale = 1.0;
+	if (d.inverse && d.normalize) {
+		for (int a : order) {
+			double n = (double)d.size[a];
+			if (d.kind == 2 || d.kind == 3) {
+				if (d.r2rType == 1) n = d.kind == 2 ? 2.0 * (n - 1) : 2.0 * (n + 1);
+				else n = 2.0 * n;
+			}
+			scale /= n;
+		}
+	}
+
+	if (d.kind == 0) {
+		for (size_t oi = 0; oi < order.size(); oi++) {
+			const int a = order[oi];
+			// the "mover" pass: forward -> first executed axis reads SRC writes DST; inverse -> last executed axis
+			const bool mover = d.inverse ? (oi + 1 == order.size()) : (oi == 0);
+			const bool before = d.inverse; // non-mover passes run in place on SRC (inverse) or DST (forward)
+			int inRole, outRole; const uint64_t *is, *os;
+			if (mover) { inRole = srcRole; outRole = dstRole; is = sStr; os = dStr; }
+			else if (before) { inRole = outRole = srcRole; is = os = sStr; }
+			else { inRole = outRole = dstRole; is = os = dStr; }
+			AxisJob j;
+			j.N = d.size[a]; j.dp = dp; j.inverse = d.inverse; j.axisIndex = a;
+			j.inRole = inRole; j.outRole = outRole;
+			j.inStrideJ = a == 0 ? 1 : (int64_t)is[a - 1];
+			j.outStrideJ = a == 0 ? 1 : (int64_t)os[a - 1];
+			j.scale = (oi + 1 == order.size()) ? scale : 1.0;
+			// other dims, unit-stride axis 0 first (tiled for strided axes); for axis 0 the next axis comes first
+			for (int o = 0; o < nd; o++) if (o != a) {
+				HostDim h; h.count = d.size[o];
+				h.inStride = o == 0 ? 1 : (int64_t)is[o - 1];
+				h.outStride = o == 0 ? 1 : (int64_t)os[o - 1];
+				j.others.push_back(h);
+			}
+			j.others.push_back({d.batch, (int64_t)is[nd - 1], (int64_t)os[nd - 1]});
+			int r = plan_c2c_axis(d, j, ar, out, out.passes);
+			if (r) return r;
+		}
+	} else {
+		return 3003; // filled in by plan_real.cpp
+	}
+
+	// Infinity-Cache chunking of a multi-pass 1D plan over the batch
+	if (nd == 1 && out.passes.size() >= 2 && d.chunkTargetBytes && out.tempBytes) {
+		const uint64_t perFFT = d.size[0] * (dp ? 16 : 8);
+		uint64_t cb = std::max<uint64_t>(1, d.chunkTargetBytes / (2 * perFFT));
+		if (cb < d.batch) {
+			out.chunkFirst = 0; out.chunkLast = (int)out.passes.size() - 1;
+			out.chunkBatch = cb; out.totalBatch = d.batch;
+			if (!d.userTempBytes) out.tempBytes = cb * perFFT;
+		}
+	}
+	if (d.userTempBytes && out.tempBytes > d.userTempBytes) return 2016;
+	return 0;
+}
+
+} // namespace vkfft_mi355x
