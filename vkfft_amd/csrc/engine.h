@@ -88,7 +88,7 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream);
 
 // fast-kernel registry queries used by the planner
-bool pow2_row_available(uint32_t log2n, bool dp, uint32_t* threads, uint32_t* fftsPerWg, size_t* ldsBytes, int* variant);
+bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads);
 
 // misc
 std::vector<uint32_t> factorize_radices(uint64_t n, bool* smooth);

@@ -4,6 +4,7 @@
 #include "kernel_generic.h"
 #include "kernel_pow2.h"
 #include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 
 namespace vkfft_mi355x {
@@ -25,6 +26,25 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 		return 4039;
 	}
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
+
+bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads) {
+	int want = 0;
+	char name[64];
+	snprintf(name, sizeof(name), "VKFFT_MI355X_P2V%u", log2n);
+	if (const char* e = getenv(name)) want = atoi(e);
+	int seen = 0, found = -1;
+	for (int i = 0; i < kNumPow2Variants; i++) {
+		if (kPow2Variants[i].log2n != (int)log2n || kPow2Variants[i].dp != dp) continue;
+		if (found < 0) found = i;
+		if (seen == want) { found = i; break; }
+		seen++;
+	}
+	if (found < 0) return false;
+	*variant = found;
+	for (int k = 0; k < 4; k++) bits[k] = kPow2Variants[found].bits[k];
+	*fpw = kPow2Variants[found].fpw; *threads = kPow2Variants[found].threads;
+	return true;
 }
 
 static int launch_with_hostloop(const PassPlan& pp, PassParams prm, hipStream_t stream, size_t level) {

@@ -97,6 +97,8 @@ struct PassBuild {
 	uint32_t raderDirectMax = 0;
 	std::string label;
 	uint32_t forceT = 0;
+	std::vector<uint32_t> radices; // explicit stage radices (fast kernels fix their own schedule)
+	int fastKernel = KERNEL_GENERIC, fastVariant = -1, fastThreads = 0;
 	bool noCollapse = false;
 	int chunkDim = -1;
 	uint64_t maxLds = 160 * 1024;
@@ -127,7 +129,7 @@ static int finish_pass(const PassBuild& b, Arena& ar, PassPlan& pp) {
 	const bool dp = b.dp;
 	const size_t es = dp ? 16 : 8;
 	p.L = (uint32_t)b.L;
-	std::vector<uint32_t> rad = radix_schedule(b.L);
+	std::vector<uint32_t> rad = b.radices.empty() ? radix_schedule(b.L) : b.radices;
 	if (b.L == 1) rad.clear();
 	if (rad.size() > (size_t)kMaxStages) return 3002;
 	p.nStages = (uint32_t)rad.size();
@@ -195,8 +197,10 @@ static int finish_pass(const PassBuild& b, Arena& ar, PassPlan& pp) {
 		T = 1;
 		while (T < 64 && (uint64_t)T * b.L < 2048 && (uint64_t)(2 * T + 1) * ldsPerSub <= 64 * 1024) T <<= 1;
 	}
-	while (T > 1 && T / 2 >= dims[0].count) T >>= 1;
-	if ((uint64_t)(T == 1 ? 1 : T + 1) * ldsPerSub > b.maxLds) return 3002;
+	if (b.fastKernel == KERNEL_GENERIC) {
+		while (T > 1 && T / 2 >= dims[0].count) T >>= 1;
+		if ((uint64_t)(T == 1 ? 1 : T + 1) * ldsPerSub > b.maxLds) return 3002;
+	}
 	p.T = T; p.logT = ilog2(T);
 	p.Tp = T == 1 ? 1 : T + 1;
 	p.padShift = T >= 16 ? 31 : 4;
@@ -216,7 +220,7 @@ static int finish_pass(const PassBuild& b, Arena& ar, PassPlan& pp) {
 	p.ldsElems = (uint32_t)((padded + 1) * p.Tp);
 	p.tilesPerG0 = (uint32_t)((dims[0].count + T - 1) / T);
 	pp.ldsBytes = 2 * (size_t)p.ldsElems * es;
-	if (pp.ldsBytes > b.maxLds) return 3002;
+	if (pp.ldsBytes > b.maxLds && b.fastKernel == KERNEL_GENERIC) return 3002;
 	// threads: about one radix-8 butterfly per thread per stage
 	uint64_t work = (uint64_t)T * b.L / 8;
 	uint32_t thr = 64;
@@ -231,6 +235,9 @@ static int finish_pass(const PassBuild& b, Arena& ar, PassPlan& pp) {
 	pp.outElemBytes = (int)((b.realOut ? 1 : 2) * (dp ? 8 : 4));
 	pp.label = b.label;
 	pp.chunkDim = b.chunkDim;
+	if (b.fastKernel != KERNEL_GENERIC) { // hand-specialised kernel: fixed tile, static LDS
+		pp.kernel = b.fastKernel; pp.variant = b.fastVariant; pp.threads = (uint32_t)b.fastThreads; pp.ldsBytes = 0;
+	}
 
 	// Four-Step two-level table
 	if (b.postOp == OP_TWIDDLE_4STEP) {
@@ -383,8 +390,15 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	}
 
 	const uint64_t singleCap = unit ? rowCap : max_col_len(dp, d.maxLds, 4);
-	if (j.N <= singleCap) {
+	if (j.N <= singleCap || (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N <= (dp ? 8192u : 16384u))) {
 		b.L = j.N;
+		if (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N >= 4) {
+			int variant, bits[4], fpw, thr;
+			if (pow2_row_lookup(ilog2(j.N), dp, &variant, bits, &fpw, &thr)) {
+				b.fastKernel = KERNEL_POW2_ROW; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
+				for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
+			}
+		}
 		b.inStrideJ = j.inStrideJ; b.outStrideJ = j.outStrideJ;
 		b.colIn = b.colOut = !unit;
 		b.dims = j.others;
