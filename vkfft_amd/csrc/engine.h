@@ -73,7 +73,7 @@ struct TransformDesc {
 	int fixMaxRadixBluestein = 0;
 	uint64_t raderMultMin = 17, raderMultMax = 128;
 	uint64_t userTempBytes = 0;  // >0: temp supplied by the caller with this size
-	uint64_t chunkTargetBytes = 96ull << 20; // working-set target of the Infinity-Cache chunking (0 disables)
+	uint64_t chunkTargetBytes = 0; // working-set target of the Infinity-Cache chunking (0 = off: measured slower on MI355X)
 	bool disableFastKernels = false;
 };
 
@@ -89,6 +89,7 @@ int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipS
 
 // fast-kernel registry queries used by the planner
 bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads);
+bool pow2_col_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* tc, int* threads);
 
 // misc
 std::vector<uint32_t> factorize_radices(uint64_t n, bool* smooth);

@@ -43,7 +43,14 @@ template <int B0, int B1, int B2, int B3> struct Pow2Sched {
 	}
 };
 
-template <typename T, typename SCH, int SI, int TPF, int LDSPF>
+// LDS slot of FFT element a: row kernels pad the index (a + a>>LOGE) inside the FFT's own slab; column
+// kernels keep TCP = TC+1 columns per element row ([a][c], odd pitch) and ldsf already points at column c.
+template <int TCP, int LOGE> __device__ inline uint32_t pow2_slot(uint32_t a) {
+	if constexpr (TCP == 0) return a + (a >> LOGE);
+	else return a * TCP;
+}
+
+template <typename T, typename SCH, int SI, int TPF, int TCP>
 __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const cx<T>* __restrict__ lut, const uint32_t tau, const bool waveOnly) {
 	constexpr int LOGE = SCH::LOGE, E = 1 << LOGE;
 	constexpr int LOGR = SCH::bits[SI], R = 1 << LOGR, NB = E / R;
@@ -71,7 +78,7 @@ __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const cx<T>* __restric
 #pragma unroll
 			for (int k = 0; k < R; k++) {
 				const uint32_t a = ob + k * S;
-				ldsf[a + (a >> LOGE)] = x[k];
+				ldsf[pow2_slot<TCP, LOGE>(a)] = x[k];
 			}
 		}
 	}
@@ -80,12 +87,12 @@ __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const cx<T>* __restric
 #pragma unroll
 		for (int m = 0; m < E; m++) {
 			const uint32_t a = tau + m * TPF;
-			v[m] = ldsf[a + (a >> LOGE)];
+			v[m] = ldsf[pow2_slot<TCP, LOGE>(a)];
 		}
 		if constexpr (SI + 2 < SCH::NS) { // another exchange will overwrite the buffer: all reads must be done first
 			if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
 		}
-		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, LDSPF>(v, ldsf, lut, tau, waveOnly);
+		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, TCP>(v, ldsf, lut, tau, waveOnly);
 	}
 }
 
@@ -117,7 +124,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_ro
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = cswap(v[m]);
 	}
-	pow2_stages<T, SCH, 0, TPF, LDSPF>(v, lds + f * LDSPF, (const cx<T>*)p.lut, tau, waveOnly);
+	pow2_stages<T, SCH, 0, TPF, 0>(v, lds + f * LDSPF, (const cx<T>*)p.lut, tau, waveOnly);
 	if (p.swapOut) {
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = cswap(v[m]);
@@ -133,9 +140,87 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_ro
 	}
 }
 
+// ---- strided-tile ("column") kernel: Four-Step passes and the non-unit-stride axes of 2D/3D transforms ----
+// A workgroup transforms TC neighbouring columns; lanes run across the columns so that every global
+// access is a TC*sizeof(complex) contiguous segment (256 B for TC=32 fp32).  Same register-resident
+// Stockham core as the row kernel; the LDS exchange is [element][column] with an odd pitch, conflict-free
+// in both directions.  Optional fused epilogue: Four-Step twiddle (two-level LUT) and a transposed store
+// (each column written out as one contiguous run) for the first Four-Step pass.
+template <typename T, typename SCH, int TC>
+__global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col_kernel(const PassParams p) {
+	constexpr int LOGN = SCH::LOGN, L = 1 << LOGN, LOGE = SCH::LOGE, E = 1 << LOGE, TPF = L / E;
+	constexpr int TCP = TC + 1, NT = TPF * TC;
+	__shared__ cx<T> lds[L * TCP];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t c = tid % TC, tau = tid / TC;
+	uint32_t wg = blockIdx.x;
+	const uint32_t tile = wg % p.tilesPerG0;
+	wg /= p.tilesPerG0;
+	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
+	const uint32_t col0 = tile * TC;
+	const bool valid = col0 + c < p.dim[0].count;
+	const int64_t inB = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)col0 * p.dim[0].inStride;
+	const int64_t outB = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)col0 * p.dim[0].outStride;
+	const cx<T>* in = (const cx<T>*)p.in + inB + (int64_t)c * p.dim[0].inStride;
+	cx<T> v[E];
+	if (valid) {
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = in[(int64_t)(tau + m * TPF) * p.inStrideJ];
+	} else {
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = cx<T>{(T)0, (T)0};
+	}
+	if (p.swapIn) {
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = cswap(v[m]);
+	}
+	pow2_stages<T, SCH, 0, TPF, TCP>(v, lds + c, (const cx<T>*)p.lut, tau, false);
+	if (p.swapOut) {
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = cswap(v[m]);
+	}
+	if (p.postOp == OP_TWIDDLE_4STEP) {
+		uint32_t colIdx, rr;
+		p.fsColDiv.divmod(col0 + c, colIdx, rr);
+		const cx<T>* tab = (const cx<T>*)p.aux;
+		const uint32_t loMask = (1u << p.fsLoBits) - 1u;
+#pragma unroll
+		for (int m = 0; m < E; m++) {
+			const uint32_t e = (tau + m * TPF) * colIdx;
+			v[m] = cmul(v[m], cmul(tab[e & loMask], tab[(loMask + 1u) + (e >> p.fsLoBits)]));
+		}
+	}
+	const T sc = (T)p.scale;
+	if (sc != (T)1) {
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = cscale(v[m], sc);
+	}
+	if (p.colModeOut) {
+		if (valid) {
+			cx<T>* out = (cx<T>*)p.out + outB + (int64_t)c * p.dim[0].outStride;
+#pragma unroll
+			for (int m = 0; m < E; m++) out[(int64_t)(tau + m * TPF) * p.outStrideJ] = v[m];
+		}
+	} else {
+		// transposed store: column c becomes the contiguous run out[c*dim0.outStride + k*outStrideJ], lanes along k
+		if constexpr (SCH::NS > 1) __syncthreads(); // the last exchange's reads are complete
+#pragma unroll
+		for (int m = 0; m < E; m++) lds[(tau + m * TPF) * TCP + c] = v[m];
+		__syncthreads();
+		const uint32_t nvalid = p.dim[0].count - col0 < (uint32_t)TC ? p.dim[0].count - col0 : (uint32_t)TC;
+		cx<T>* out = (cx<T>*)p.out + outB;
+#pragma unroll
+		for (int i = 0; i < E; i++) {
+			const uint32_t idx = tid + i * NT;
+			const uint32_t k = idx % L, cc = idx / L;
+			if (cc < nvalid) out[(int64_t)cc * p.dim[0].outStride + (int64_t)k * p.outStrideJ] = lds[k * TCP + cc];
+		}
+	}
+}
+
 // ---- registry --------------------------------------------------------------------------------------------
 struct Pow2Variant {
-	int log2n; bool dp; int bits[4]; int fpw; int threads;
+	int log2n; bool dp; int bits[4]; int fpw; int threads; // fpw: FFTs per workgroup (row) / columns per workgroup (col)
 	void (*launch)(const PassParams&, dim3, hipStream_t);
 };
 
@@ -143,6 +228,14 @@ template <typename T, typename SCH, int FPW> void pow2_row_launch(const PassPara
 	constexpr int threads = ((1 << SCH::LOGN) >> SCH::LOGE) * FPW;
 	hipLaunchKernelGGL((pow2_row_kernel<T, SCH, FPW>), grid, dim3(threads), 0, s, prm);
 }
+
+template <typename T, typename SCH, int TC> void pow2_col_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
+	constexpr int threads = ((1 << SCH::LOGN) >> SCH::LOGE) * TC;
+	hipLaunchKernelGGL((pow2_col_kernel<T, SCH, TC>), grid, dim3(threads), 0, s, prm);
+}
+
+#define VKFFT_P2C(T, dp, b0, b1, b2, b3, tc) \
+	{ (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, tc, (((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (tc)), &pow2_col_launch<T, Pow2Sched<b0, b1, b2, b3>, tc> }
 
 #define VKFFT_P2(T, dp, b0, b1, b2, b3, fpw) \
 	{ (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, fpw, (((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (fpw)), &pow2_row_launch<T, Pow2Sched<b0, b1, b2, b3>, fpw> }
@@ -179,11 +272,31 @@ static const Pow2Variant kPow2Variants[] = {
 };
 constexpr int kNumPow2Variants = (int)(sizeof(kPow2Variants) / sizeof(kPow2Variants[0]));
 
+// column kernels: first entry of each (log2n, dp) is the default; VKFFT_MI355X_P2C<log2n>=k selects the k-th
+static const Pow2Variant kPow2ColVariants[] = {
+	VKFFT_P2C(float, false, 2, 2, 0, 0, 32), VKFFT_P2C(float, false, 2, 2, 0, 0, 16),
+	VKFFT_P2C(float, false, 3, 2, 0, 0, 32), VKFFT_P2C(float, false, 3, 2, 0, 0, 16),
+	VKFFT_P2C(float, false, 3, 3, 0, 0, 32), VKFFT_P2C(float, false, 3, 3, 0, 0, 16),
+	VKFFT_P2C(float, false, 4, 3, 0, 0, 32), VKFFT_P2C(float, false, 4, 3, 0, 0, 16), VKFFT_P2C(float, false, 3, 2, 2, 0, 32),
+	VKFFT_P2C(float, false, 4, 4, 0, 0, 32), VKFFT_P2C(float, false, 4, 4, 0, 0, 16), VKFFT_P2C(float, false, 3, 3, 2, 0, 32), VKFFT_P2C(float, false, 3, 3, 2, 0, 16),
+	VKFFT_P2C(float, false, 4, 3, 2, 0, 16), VKFFT_P2C(float, false, 4, 3, 2, 0, 32), VKFFT_P2C(float, false, 3, 3, 3, 0, 16),
+	VKFFT_P2C(float, false, 4, 3, 3, 0, 16), VKFFT_P2C(float, false, 4, 3, 3, 0, 8),
+	VKFFT_P2C(double, true, 2, 2, 0, 0, 16),
+	VKFFT_P2C(double, true, 3, 2, 0, 0, 16),
+	VKFFT_P2C(double, true, 3, 3, 0, 0, 16),
+	VKFFT_P2C(double, true, 3, 2, 2, 0, 16), VKFFT_P2C(double, true, 4, 3, 0, 0, 16),
+	VKFFT_P2C(double, true, 3, 3, 2, 0, 16), VKFFT_P2C(double, true, 4, 4, 0, 0, 16),
+	VKFFT_P2C(double, true, 3, 3, 3, 0, 8), VKFFT_P2C(double, true, 4, 3, 2, 0, 8), VKFFT_P2C(double, true, 3, 3, 3, 0, 16),
+	VKFFT_P2C(double, true, 4, 3, 3, 0, 8),
+};
+constexpr int kNumPow2ColVariants = (int)(sizeof(kPow2ColVariants) / sizeof(kPow2ColVariants[0]));
+
 inline int launch_pow2(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
 	if (grid64 == 0) return 0;
-	if (grid64 > 0x7fffffffull || pp.variant < 0 || pp.variant >= kNumPow2Variants) return 4039;
-	kPow2Variants[pp.variant].launch(prm, dim3((uint32_t)grid64), stream);
+	const bool col = pp.kernel == KERNEL_POW2_COL;
+	if (grid64 > 0x7fffffffull || pp.variant < 0 || pp.variant >= (col ? kNumPow2ColVariants : kNumPow2Variants)) return 4039;
+	(col ? kPow2ColVariants : kPow2Variants)[pp.variant].launch(prm, dim3((uint32_t)grid64), stream);
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
 }
 

@@ -28,23 +28,29 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
 }
 
-bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads) {
+static bool pow2_lookup(const Pow2Variant* tab, int ntab, const char* envPrefix, uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads) {
 	int want = 0;
 	char name[64];
-	snprintf(name, sizeof(name), "VKFFT_MI355X_P2V%u", log2n);
+	snprintf(name, sizeof(name), "%s%u", envPrefix, log2n);
 	if (const char* e = getenv(name)) want = atoi(e);
 	int seen = 0, found = -1;
-	for (int i = 0; i < kNumPow2Variants; i++) {
-		if (kPow2Variants[i].log2n != (int)log2n || kPow2Variants[i].dp != dp) continue;
+	for (int i = 0; i < ntab; i++) {
+		if (tab[i].log2n != (int)log2n || tab[i].dp != dp) continue;
 		if (found < 0) found = i;
 		if (seen == want) { found = i; break; }
 		seen++;
 	}
 	if (found < 0) return false;
 	*variant = found;
-	for (int k = 0; k < 4; k++) bits[k] = kPow2Variants[found].bits[k];
-	*fpw = kPow2Variants[found].fpw; *threads = kPow2Variants[found].threads;
+	for (int k = 0; k < 4; k++) bits[k] = tab[found].bits[k];
+	*fpw = tab[found].fpw; *threads = tab[found].threads;
 	return true;
+}
+bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads) {
+	return pow2_lookup(kPow2Variants, kNumPow2Variants, "VKFFT_MI355X_P2V", log2n, dp, variant, bits, fpw, threads);
+}
+bool pow2_col_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* tc, int* threads) {
+	return pow2_lookup(kPow2ColVariants, kNumPow2ColVariants, "VKFFT_MI355X_P2C", log2n, dp, variant, bits, tc, threads);
 }
 
 static int launch_with_hostloop(const PassPlan& pp, PassParams prm, hipStream_t stream, size_t level) {

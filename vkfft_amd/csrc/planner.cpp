@@ -99,6 +99,7 @@ struct PassBuild {
 	uint32_t forceT = 0;
 	std::vector<uint32_t> radices; // explicit stage radices (fast kernels fix their own schedule)
 	int fastKernel = KERNEL_GENERIC, fastVariant = -1, fastThreads = 0;
+	bool allowFast = true;
 	bool noCollapse = false;
 	int chunkDim = -1;
 	uint64_t maxLds = 160 * 1024;
@@ -123,7 +124,18 @@ static void collapse_dims(std::vector<HostDim>& d) {
 	d = r;
 }
 
-static int finish_pass(const PassBuild& b, Arena& ar, PassPlan& pp) {
+static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
+	PassBuild b = bIn;
+	// strided-tile passes of power-of-two length run on the hand-specialised column kernel
+	if (b.allowFast && b.fastKernel == KERNEL_GENERIC && b.colIn && b.L >= 16 && b.L <= 1024 && (b.L & (b.L - 1)) == 0 && b.preOp == OP_NONE
+	    && b.midOp == OP_NONE && (b.postOp == OP_NONE || b.postOp == OP_TWIDDLE_4STEP) && !b.realIn && !b.realOut && !b.forceT) {
+		int variant, bits[4], tc, thr;
+		if (pow2_col_lookup(ilog2(b.L), b.dp, &variant, bits, &tc, &thr)) {
+			b.fastKernel = KERNEL_POW2_COL; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)tc;
+			b.radices.clear();
+			for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
+		}
+	}
 	PassParams& p = pp.prm;
 	memset(&p, 0, sizeof(p));
 	const bool dp = b.dp;
@@ -191,7 +203,6 @@ static int finish_pass(const PassBuild& b, Arena& ar, PassPlan& pp) {
 		T = dp ? 16 : 32; // 256-byte segments
 		while (T > 1 && (uint64_t)(T + 1) * ldsPerSub > (b.maxLds * 7) / 10) T >>= 1; // leave room for two workgroups per CU when possible
 		while (T > 1 && (uint64_t)(T + 1) * ldsPerSub > b.maxLds) T >>= 1;
-		if (T < 4 && (uint64_t)5 * ldsPerSub <= b.maxLds) T = 4;
 	} else {
 		// unit-stride rows: enough sub-FFTs for >= ~2048 points per workgroup
 		T = 1;
@@ -272,7 +283,9 @@ static bool is_supported_len(uint64_t L, uint32_t directMax) {
 
 // choose N = n[0]*n[1](*n[2]); n[0] is the pass that runs over the largest stride (executed first).
 // Preference order: two passes with wide tiles and two workgroups per CU, ..., three passes last.
-static bool choose_split(uint64_t N, bool dp, uint64_t maxLds, uint32_t directMax, std::vector<uint64_t>& out) {
+static bool choose_split(uint64_t N, bool dp, uint64_t maxLds, uint32_t directMax, bool fast, std::vector<uint64_t>& out) {
+	const bool fastP2 = fast && (N & (N - 1)) == 0; // fast column kernels: single LDS buffer, L <= 1024
+	auto capOf = [&](uint32_t T, uint64_t budget) { uint64_t c = max_col_len(dp, fastP2 ? 2 * budget : budget, T); return fastP2 ? std::min<uint64_t>(c, 1024) : c; };
 	struct Opt { uint32_t T; uint64_t budget; };
 	const uint32_t Tw = dp ? 16 : 32;
 	const Opt opts[5] = {{Tw, maxLds / 2}, {Tw / 2, maxLds / 2}, {Tw, maxLds}, {Tw / 2, maxLds}, {Tw / 4, maxLds}};
@@ -281,13 +294,13 @@ static bool choose_split(uint64_t N, bool dp, uint64_t maxLds, uint32_t directMa
 	std::sort(divs.begin(), divs.end());
 	auto ok = [&](uint64_t L, uint64_t cap) { return L >= 2 && L <= cap && is_supported_len(L, directMax); };
 	for (const Opt& o : opts) {
-		const uint64_t cap = max_col_len(dp, o.budget, o.T);
+		const uint64_t cap = capOf(o.T, o.budget);
 		uint64_t best = 0;
 		for (uint64_t d : divs) if (d <= N / d && ok(d, cap) && ok(N / d, cap)) best = d;
 		if (best) { out = {N / best, best}; return true; }
 	}
 	for (const Opt& o : opts) {
-		const uint64_t cap = max_col_len(dp, o.budget, o.T);
+		const uint64_t cap = capOf(o.T, o.budget);
 		double bestCost = 1e300; uint64_t ba = 0, bb = 0;
 		for (uint64_t a : divs) if (ok(a, cap)) for (uint64_t b2 : divs) if ((N / a) % b2 == 0 && ok(b2, cap) && ok(N / a / b2, cap)) {
 			uint64_t c = N / a / b2;
@@ -351,7 +364,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	bool smoothOK = is_supported_len(j.N, dmax);
 	const uint64_t rowCap = max_row_len(dp, d.maxLds);
 	PassBuild b;
-	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax;
+	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax; b.allowFast = !d.disableFastKernels;
 	b.inRole = j.inRole; b.outRole = j.outRole;
 	out.axisSplit[j.axisIndex][0] = j.N;
 
@@ -359,7 +372,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		// Bluestein (chirp-z) through a padded smooth length M >= 2N-1
 		const uint64_t N = j.N;
 		uint64_t M = d.forceBluesteinSize ? d.forceBluesteinSize : next_smooth(2 * N - 1, d.fixMaxRadixBluestein ? d.fixMaxRadixBluestein : 7);
-		uint64_t cap = unit ? rowCap : max_col_len(dp, d.maxLds, 4);
+		uint64_t cap = unit ? rowCap : max_col_len(dp, d.maxLds, 1);
 		if (M > cap) return 3002; // multi-pass Bluestein: not yet
 		const size_t es = dp ? 16 : 8;
 		size_t chirpOff = ar.alloc(N * es), bhatOff = ar.alloc(M * es);
@@ -389,7 +402,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		return 0;
 	}
 
-	const uint64_t singleCap = unit ? rowCap : max_col_len(dp, d.maxLds, 4);
+	const uint64_t singleCap = unit ? rowCap : max_col_len(dp, d.maxLds, 1);
 	if (j.N <= singleCap || (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N <= (dp ? 8192u : 16384u))) {
 		b.L = j.N;
 		if (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N >= 4) {
@@ -414,7 +427,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 
 	// ---- Four-Step on a unit-stride axis: N = n0 * M, recursively M = n1 * n2 -------------------------
 	std::vector<uint64_t> sp;
-	if (!choose_split(j.N, dp, d.maxLds, dmax, sp)) return 3002;
+	if (!choose_split(j.N, dp, d.maxLds, dmax, !d.disableFastKernels, sp)) return 3002;
 	out.uploadsPerAxis[j.axisIndex] = (uint32_t)sp.size();
 	for (size_t i = 0; i < sp.size(); i++) out.axisSplit[j.axisIndex][i] = sp[sp.size() - 1 - i];
 	const uint64_t N = j.N;
@@ -489,6 +502,119 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	return 0;
 }
 
+
+// ---- real transforms ---------------------------------------------------------------------------------------
+// R2C/C2R along axis 0 (reference: two-sequences packing vkFFT_R2C.h:450/:178 for single-upload, even
+// decomposition vkFFT_R2C_even_decomposition.h:40 for long even N, callback form vkFFT_R2C.h:27 otherwise).
+// Here: even N -> one half-length complex FFT per row with the split fused as a post/pre operation of the
+// same kernel; odd N -> full-length complex FFT of the real row.
+static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vector<HostDim>& othersReal, const std::vector<HostDim>& othersCplx,
+                          int realRole, int cplxRole, double scale, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
+	const uint64_t N = d.size[0];
+	const bool dp = d.dp;
+	const size_t es = dp ? 16 : 8;
+	const uint32_t dmax = direct_max(d);
+	PassBuild b;
+	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax; b.allowFast = false;
+	b.opN = (uint32_t)N; b.scale = scale;
+	const bool even = (N % 2 == 0);
+	b.L = even ? N / 2 : N;
+	if (!is_supported_len(b.L, dmax) || b.L > max_row_len(dp, d.maxLds)) return 3003;
+	// rows: combine the real-side and complex-side strides per dim
+	std::vector<HostDim> dims;
+	for (size_t i = 0; i < othersReal.size(); i++) {
+		HostDim h; h.count = othersReal[i].count;
+		int64_t rs = othersReal[i].inStride, cs = othersCplx[i].inStride;
+		if (even) { if (rs % 2) return 3003; rs /= 2; } // real rows viewed as packed complex pairs
+		if (!inverse) { h.inStride = rs; h.outStride = cs; } else { h.inStride = cs; h.outStride = rs; }
+		dims.push_back(h);
+	}
+	b.dims = dims;
+	b.inStrideJ = b.outStrideJ = 1;
+	if (even) {
+		size_t aux = ar.alloc((N / 2 + 1) * es);
+		for (uint64_t k = 0; k <= N / 2; k++) ar.putc(aux, k, unit_root(k, N), dp);
+		b.auxOff = aux;
+		if (!inverse) { b.postOp = OP_R2C_EVEN_POST; b.outLen = (uint32_t)(N / 2 + 1); b.inLen = (uint32_t)(N / 2); }
+		else { b.preOp = OP_C2R_EVEN_PRE; b.swapIn = b.swapOut = true; b.inLen = (uint32_t)(N / 2 + 1); b.outLen = (uint32_t)(N / 2); }
+	} else {
+		if (!inverse) { b.preOp = OP_R2C_FULL; b.postOp = OP_R2C_FULL; b.realIn = true; b.outLen = (uint32_t)(N / 2 + 1); }
+		else { b.preOp = OP_C2R_FULL; b.postOp = OP_C2R_FULL; b.realOut = true; b.swapIn = b.swapOut = true; b.inLen = (uint32_t)(N / 2 + 1); b.outLen = (uint32_t)N; }
+	}
+	b.inRole = inverse ? cplxRole : realRole;
+	b.outRole = inverse ? realRole : cplxRole;
+	b.label = inverse ? "c2r" : "r2c";
+	PassPlan pp; int r = finish_pass(b, ar, pp); if (r) return r == 3002 ? 3003 : r;
+	passes.push_back(pp);
+	out.uploadsPerAxis[0] = 1;
+	out.axisSplit[0][0] = N;
+	return 0;
+}
+
+// DCT / DST of type 1..4 along one axis through a complex FFT with fused pre/post maps
+// (reference: vkFFT_R2R.h, size rules vkFFT_Scheduler.h:2271-2280).
+static int plan_r2r_axis(const TransformDesc& d, int type, bool dst, uint64_t N, int64_t strideIn, int64_t strideOut, const std::vector<HostDim>& others,
+                         int inRole, int outRole, double scale, int axisIndex, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
+	const bool dp = d.dp;
+	const size_t es = dp ? 16 : 8;
+	const uint32_t dmax = direct_max(d);
+	PassBuild b;
+	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax; b.allowFast = false;
+	b.opN = (uint32_t)N; b.scale = scale;
+	b.realIn = b.realOut = true;
+	b.inLen = b.outLen = (uint32_t)N;
+	const bool unit = strideIn == 1 && strideOut == 1;
+	b.inStrideJ = strideIn; b.outStrideJ = strideOut;
+	b.colIn = b.colOut = !unit;
+	b.dims = others;
+	b.inRole = inRole; b.outRole = outRole;
+	switch (type) {
+	case 1:
+		if (!dst) { if (N < 2) return 3004; b.L = 2 * N - 2; b.preOp = OP_DCT1_PRE; b.postOp = OP_DCT1_POST; }
+		else { b.L = 2 * N + 2; b.preOp = OP_DST1_PRE; b.postOp = OP_DST1_POST; }
+		break;
+	case 2: {
+		b.L = N; b.preOp = dst ? OP_DST2_PRE : OP_DCT2_PRE; b.postOp = dst ? OP_DST2_POST : OP_DCT2_POST;
+		size_t aux = ar.alloc(N * es);
+		for (uint64_t k = 0; k < N; k++) ar.putc(aux, k, unit_root(k, 4 * N), dp);
+		b.auxOff = aux;
+		break;
+	}
+	case 3: {
+		b.L = N; b.preOp = dst ? OP_DST3_PRE : OP_DCT3_PRE; b.postOp = dst ? OP_DST3_POST : OP_DCT3_POST;
+		b.swapIn = b.swapOut = true;
+		size_t aux = ar.alloc(N * es);
+		for (uint64_t k = 0; k < N; k++) ar.putc(aux, k, unit_root(k, 4 * N), dp);
+		b.auxOff = aux;
+		break;
+	}
+	case 4: {
+		b.preOp = dst ? OP_DST4_PRE : OP_DCT4_PRE; b.postOp = dst ? OP_DST4_POST : OP_DCT4_POST;
+		if (N % 2 == 0) {
+			b.L = N / 2;
+			size_t aux = ar.alloc((N / 2) * es), aux2 = ar.alloc((N / 2) * es);
+			for (uint64_t n = 0; n < N / 2; n++) { ar.putc(aux, n, unit_root(4 * n + 1, 8 * N), dp); ar.putc(aux2, n, unit_root(n, 2 * N), dp); }
+			b.auxOff = aux; b.aux2Off = aux2;
+		} else {
+			b.L = 2 * N;
+			size_t aux = ar.alloc(N * es), aux2 = ar.alloc(N * es);
+			for (uint64_t n = 0; n < N; n++) { ar.putc(aux, n, unit_root(n, 4 * N), dp); ar.putc(aux2, n, unit_root(2 * n + 1, 8 * N), dp); }
+			b.auxOff = aux; b.aux2Off = aux2;
+		}
+		break;
+	}
+	default: return 3004;
+	}
+	if (!is_supported_len(b.L, dmax)) return 3004;
+	if (b.L > (unit ? max_row_len(dp, d.maxLds) : max_col_len(dp, d.maxLds, 1))) return 3004;
+	b.label = dst ? "dst" : "dct";
+	PassPlan pp; int r = finish_pass(b, ar, pp); if (r) return r == 3002 ? 3004 : r;
+	passes.push_back(pp);
+	out.uploadsPerAxis[axisIndex] = 1;
+	out.axisSplit[axisIndex][0] = N;
+	return 0;
+}
+
 // ---- top level ----------------------------------------------------------------------------------------
 int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
 	out = DirectionPlan();
@@ -554,8 +680,65 @@ int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
 			int r = plan_c2c_axis(d, j, ar, out, out.passes);
 			if (r) return r;
 		}
+	} else if (d.kind == 1) {
+		// R2C (forward) / C2R (inverse).  Real side: `input` when isInputFormatted, else the padded rows of `buffer`.
+		if (d.outFormatted) return 3003;
+		const bool realSeparate = d.inFormatted && (!d.inverse || d.inverseReturnToInput);
+		const int realRole = realSeparate ? ROLE_INPUT : ROLE_BUFFER;
+		uint64_t rStr[5]; // real-element strides of the real side
+		for (int i = 0; i < 5; i++) rStr[i] = realSeparate ? d.inStride[i] : 2 * d.bufStride[i];
+		const uint64_t W = d.size[0] / 2 + 1; // complex row width
+		std::vector<HostDim> oReal, oCplx;
+		for (int o = 1; o < nd; o++) { oReal.push_back({d.size[o], (int64_t)rStr[o - 1], (int64_t)rStr[o - 1]}); oCplx.push_back({d.size[o], (int64_t)d.bufStride[o - 1], (int64_t)d.bufStride[o - 1]}); }
+		oReal.push_back({d.batch, (int64_t)rStr[nd - 1], (int64_t)rStr[nd - 1]});
+		oCplx.push_back({d.batch, (int64_t)d.bufStride[nd - 1], (int64_t)d.bufStride[nd - 1]});
+		auto complexAxes = [&](bool inv) -> int {
+			for (size_t oi = 0; oi < order.size(); oi++) {
+				const int a = order[oi];
+				if (a == 0) continue;
+				AxisJob j; j.N = d.size[a]; j.dp = dp; j.inverse = inv; j.axisIndex = a;
+				j.inRole = j.outRole = ROLE_BUFFER;
+				j.inStrideJ = j.outStrideJ = (int64_t)d.bufStride[a - 1];
+				j.scale = 1.0;
+				for (int o = 0; o < nd; o++) if (o != a) {
+					HostDim h; h.count = o == 0 ? W : d.size[o];
+					h.inStride = h.outStride = o == 0 ? 1 : (int64_t)d.bufStride[o - 1];
+					j.others.push_back(h);
+				}
+				j.others.push_back({d.batch, (int64_t)d.bufStride[nd - 1], (int64_t)d.bufStride[nd - 1]});
+				int r = plan_c2c_axis(d, j, ar, out, out.passes);
+				if (r) return r;
+			}
+			return 0;
+		};
+		if (d.omit[0] || d.size[0] < 2) return 3005;
+		if (!d.inverse) {
+			int r = plan_r2c_axis0(d, false, oReal, oCplx, realRole, ROLE_BUFFER, 1.0, ar, out, out.passes); if (r) return r;
+			r = complexAxes(false); if (r) return r;
+		} else {
+			int r = complexAxes(true); if (r) return r;
+			r = plan_r2c_axis0(d, true, oReal, oCplx, realRole, ROLE_BUFFER, scale, ar, out, out.passes); if (r) return r;
+		}
 	} else {
-		return 3003; // filled in by plan_real.cpp
+		// DCT / DST: the same R2R type along every axis; the inverse of type 2 is type 3 and vice versa
+		int type = d.r2rType;
+		if (d.inverse) type = type == 2 ? 3 : type == 3 ? 2 : type;
+		const bool dst = d.kind == 3;
+		for (size_t oi = 0; oi < order.size(); oi++) {
+			const int a = order[oi];
+			const bool mover = d.inverse ? (oi + 1 == order.size()) : (oi == 0);
+			const bool before = d.inverse;
+			int inRole, outRole; const uint64_t *is, *os;
+			if (mover) { inRole = srcRole; outRole = dstRole; is = sStr; os = dStr; }
+			else if (before) { inRole = outRole = srcRole; is = os = sStr; }
+			else { inRole = outRole = dstRole; is = os = dStr; }
+			std::vector<HostDim> others;
+			for (int o = 0; o < nd; o++) if (o != a) others.push_back({d.size[o], o == 0 ? 1 : (int64_t)is[o - 1], o == 0 ? 1 : (int64_t)os[o - 1]});
+			others.push_back({d.batch, (int64_t)is[nd - 1], (int64_t)os[nd - 1]});
+			int r = plan_r2r_axis(d, type, dst, d.size[a], a == 0 ? 1 : (int64_t)is[a - 1], a == 0 ? 1 : (int64_t)os[a - 1], others, inRole, outRole,
+			                      (oi + 1 == order.size()) ? scale : 1.0, a, ar, out, out.passes);
+			if (r) return r;
+		}
 	}
 
 	// Infinity-Cache chunking of a multi-pass 1D plan over the batch
