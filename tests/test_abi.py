@@ -1,0 +1,71 @@
+"""CPU tests of the drop-in boundary: the real HIP library loads here (no GPU), exports every symbol that
+include/vkFFT.h declares, its struct layout matches the FFI binding, error paths behave like the reference's
+(vkFFT_InitializeApp.h:1468-1482, :428ff) and — having no CPU fallback — plan creation fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from vkfft_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_every_declared_symbol(product_lib):
+    hdr = open(os.path.join(ROOT, "include", "vkFFT.h")).read()
+    declared = re.findall(r"VKFFT_API\s+[\w\s\*]+?\b(\w+)\s*\(", hdr)
+    assert set(declared) >= {"initializeVkFFT", "VkFFTAppend", "deleteVkFFT", "VkFFTGetVersion", "getVkFFTErrorString"}
+    for name in declared:
+        assert hasattr(product_lib, name), name
+    assert set(declared) == set(api.EXPORTS)
+
+
+def test_version_and_error_strings(product_lib):
+    assert product_lib.VkFFTGetVersion() == 10304  # vkFFT.h:109
+    assert product_lib.getVkFFTErrorString(0) == b"VKFFT_SUCCESS"
+    assert product_lib.getVkFFTErrorString(3002) == b"VKFFT_ERROR_UNSUPPORTED_FFT_LENGTH"
+    assert product_lib.getVkFFTErrorString(4039) == b"VKFFT_ERROR_FAILED_TO_LAUNCH_KERNEL"
+
+
+def test_struct_sizes_match_binding(product_lib):
+    sizes = (C.c_uint64 * 4)()
+    product_lib.vkfftMI355XStructSizes(sizes)
+    assert list(sizes) == [C.sizeof(api.VkFFTConfiguration), C.sizeof(api.VkFFTLaunchParams), C.sizeof(api.VkFFTPlan), C.sizeof(api.VkFFTApplication)]
+
+
+def _init(lib, cfg, app=None):
+    app = app if app is not None else api.VkFFTApplication()
+    return lib.initializeVkFFT(C.byref(app), cfg), app
+
+
+def test_validation_order_matches_reference(product_lib):
+    lib = product_lib
+    assert lib.initializeVkFFT(None, api.VkFFTConfiguration()) == 2015  # EMPTY_app
+    dirty = api.VkFFTApplication(); dirty.actualNumBatches = 1
+    assert _init(lib, api.VkFFTConfiguration(), dirty)[0] == 8          # NONZERO_APP_INITIALIZATION
+    cfg = api.VkFFTConfiguration()
+    assert _init(lib, cfg)[0] == 2001                                    # EMPTY_FFTdim
+    cfg.FFTdim = 5
+    assert _init(lib, cfg)[0] == 7                                       # FFTdim_GT_MAX
+    cfg.FFTdim = 1
+    assert _init(lib, cfg)[0] == 1002                                    # INVALID_DEVICE
+    dev = C.c_int(0); cfg.device = C.pointer(dev)
+    assert _init(lib, cfg)[0] == 2002                                    # EMPTY_size
+    cfg.size[0] = 64; cfg.performConvolution = 1
+    assert _init(lib, cfg)[0] == 4                                       # out-of-scope feature rejected
+    assert lib.VkFFTAppend(None, -1, None) == 2015
+
+
+def test_no_cpu_fallback_without_gpu(product_lib):
+    """On a box without a GPU plan creation must fail (no silent host path); on a GPU box it succeeds."""
+    import torch
+    cfg = api.VkFFTConfiguration(); cfg.FFTdim = 1; cfg.size[0] = 64
+    dev = C.c_int(0); cfg.device = C.pointer(dev)
+    rc, app = _init(product_lib, cfg)
+    if torch.cuda.is_available():
+        assert rc == 0
+        product_lib.deleteVkFFT(C.byref(app))
+    else:
+        assert rc in (4051, 1002)  # FAILED_TO_GET_ATTRIBUTE / INVALID_DEVICE
+        assert bytes(app) == bytes(C.sizeof(api.VkFFTApplication))  # app left zeroed, as the reference does on failure

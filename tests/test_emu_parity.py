@@ -1,0 +1,167 @@
+"""CPU tests of the host logic (planner, pass descriptors, launch layer, API semantics) and of the kernels'
+index maps: the product sources compiled against the CPU SIMT emulation (tests/hostemu) must reproduce the
+oracle.  The real-GPU versions of these checks are in test_gpu_parity.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import parity
+from helpers import Runner, rel_l2
+from vkfft_amd import api
+
+
+@pytest.fixture(scope="module")
+def run(emu_lib):
+    return Runner(emu_lib, "emu")
+
+
+@pytest.mark.parametrize("N", [2, 3, 4, 5, 7, 8, 11, 13, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+def test_pow2_and_small_radix_rows(run, oracle, N):
+    parity.check_c2c(run, oracle, (N,), 3, False)
+
+
+@pytest.mark.parametrize("N", [6, 9, 10, 12, 14, 15, 30, 100, 243, 343, 121, 169, 1000, 1080, 3125, 2401, 1331, 2197, 6561])
+@pytest.mark.parametrize("dp", [False, True])
+def test_mixed_radix(run, oracle, N, dp):
+    parity.check_c2c(run, oracle, (N,), 2, dp)
+
+
+@pytest.mark.parametrize("N", [17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 17 * 16, 31 * 9])
+def test_rader_direct_primes(run, oracle, N):
+    parity.check_c2c(run, oracle, (N,), 2, False)
+
+
+@pytest.mark.parametrize("N", [67, 127, 251, 1009, 2039, 67 * 4])
+@pytest.mark.parametrize("dp", [False, True])
+def test_bluestein(run, oracle, N, dp):
+    parity.check_c2c(run, oracle, (N,), 2, dp, kind="bluestein")
+
+
+@pytest.mark.parametrize("N,passes", [(1 << 15, 2), (1 << 16, 2), (1 << 18, 2), (3 ** 10, 2), (1 << 21, 3), (5 ** 9, 3)])
+def test_fourstep(run, oracle, N, passes):
+    up = parity.check_c2c(run, oracle, (N,), 1, False, use_c_oracle=N <= (1 << 16))
+    assert up == [passes]
+
+
+def test_fourstep_fp64_and_batch(run, oracle):
+    assert parity.check_c2c(run, oracle, (1 << 14,), 3, True) == [2]
+
+
+@pytest.mark.parametrize("shape", [(16, 8), (64, 32), (100, 60), (12, 10, 6), (32, 16, 8), (8, 4, 2, 3)])
+@pytest.mark.parametrize("dp", [False, True])
+def test_multidim(run, oracle, shape, dp):
+    parity.check_c2c(run, oracle, shape, 2, dp)
+
+
+@pytest.mark.parametrize("shape", [(2,), (16,), (15,), (256,), (1000,), (243,), (64, 32), (30, 20, 10), (33, 8)])
+@pytest.mark.parametrize("dp", [False, True])
+def test_r2c_c2r(run, oracle, shape, dp):
+    parity.check_r2c(run, oracle, shape, 2, dp)
+
+
+@pytest.mark.parametrize("type", [1, 2, 3, 4])
+@pytest.mark.parametrize("dst", [False, True])
+@pytest.mark.parametrize("shape", [(8,), (9,), (64,), (81,), (32, 24), (12, 10, 6)])
+def test_dct_dst(run, oracle, type, dst, shape):
+    parity.check_r2r(run, oracle, shape, 2, False, type, dst)
+    if shape in ((9,), (32, 24)):
+        parity.check_r2r(run, oracle, shape, 2, True, type, dst)
+
+
+def test_golden_reference_fixtures(run, golden):
+    """library (emulated) vs the reference's own outputs captured on an MI355X"""
+    mod, data = golden
+    for case in mod.CASES:
+        if case["name"] not in data:
+            continue
+        x = mod.golden_input(case)
+        kw = {}
+        if case["kind"] == 1:
+            kw["r2c"] = True
+        elif case["kind"] >= 11:
+            kw["dct"] = case["kind"] - 10
+        y, _ = run.transform(x, case["shape"], case["batch"], inverse=bool(case["inverse"]), **kw)
+        ref = data[case["name"]]
+        tol = 2e-14 if case["dp"] else 4e-6
+        if case["kind"] == 1:  # compare the Hermitian half only (padding lanes are the same memory)
+            ct = np.complex128 if case["dp"] else np.complex64
+            y, ref = y.view(ct), ref.view(ct)
+        assert rel_l2(y, ref) < tol, case["name"]
+
+
+def test_normalize_and_batch_folding(run, emu_lib):
+    N, B = 64, 5
+    x = parity.seeded_complex(N * B, False, 9)
+    h = x.copy()
+    app = api.App([N], B, buffer_ptr=h.ctypes.data, normalize=True, lib=emu_lib)
+    # reference folds batches of a 1D plan into dimension 1 (vkFFT_Plan_FFT.h:55-61)
+    assert app.app.actualNumBatches == B and app.app.configuration.numberBatches == 1
+    assert app.app.localFFTPlan.contents.actualFFTSizePerAxis[0][1] == B
+    app.forward(); app.inverse()
+    assert rel_l2(h, x) < 1e-6
+    app.delete()
+    assert bytes(app.app) == bytes(C.sizeof(api.VkFFTApplication))  # deleteVkFFT zeroes the app (DeleteApp.h:322)
+
+
+def test_direction_selection_and_plan_only_errors(emu_lib):
+    x = parity.seeded_complex(32, False, 1); h = x.copy()
+    app = api.App([32], 1, buffer_ptr=h.ctypes.data, makeForwardPlanOnly=1, lib=emu_lib)
+    with pytest.raises(api.VkFFTError) as e:
+        app.inverse()
+    assert e.value.code == 1006  # ONLY_FORWARD_FFT_INITIALIZED
+    # anything != 1 is forward (vkFFT_RunApp.h:102-111)
+    lp = api.VkFFTLaunchParams()
+    assert emu_lib.VkFFTAppend(C.byref(app.app), 0, C.byref(lp)) == 0
+    assert rel_l2(h, np.fft.fft(x.astype(np.complex128))) < 1e-6
+    app.delete()
+
+
+def test_launch_time_buffer_override_and_missing_buffer(emu_lib):
+    x = parity.seeded_complex(128, False, 2); h = x.copy()
+    app = api.App([128], 1, buffer_ptr=0, lib=emu_lib)  # no buffer at plan time (UpdateBuffers.h:633-636)
+    with pytest.raises(api.VkFFTError) as e:
+        app.forward()
+    assert e.value.code == 2004  # EMPTY_buffer
+    app.forward(buffer_ptr=h.ctypes.data)
+    assert rel_l2(h, np.fft.fft(x.astype(np.complex128))) < 1e-6
+    app.delete()
+
+
+def test_out_of_place_formatted_buffers(emu_lib):
+    N, B = 100, 3
+    x = parity.seeded_complex(N * B, False, 4)
+    src = x.copy(); dst = np.zeros_like(x)
+    app = api.App([N], B, buffer_ptr=dst.ctypes.data, isInputFormatted=1, inputBuffer=src.ctypes.data, lib=emu_lib)
+    app.forward()
+    assert np.array_equal(src, x)  # input untouched
+    assert rel_l2(dst, np.fft.fft(x.astype(np.complex128).reshape(B, N), axis=1)) < 1e-6
+    app.delete()
+
+
+def test_user_temp_buffer_too_small(emu_lib):
+    N = 1 << 15
+    buf = np.zeros(N, np.complex64); tmp = np.zeros(16, np.complex64)
+    with pytest.raises(api.VkFFTError) as e:
+        api.App([N], 1, buffer_ptr=buf.ctypes.data, userTempBuffer=1, tempBuffer=tmp.ctypes.data, tempBufferSize=tmp.nbytes, lib=emu_lib)
+    assert e.value.code == 2016  # INVALID_user_tempBuffer_too_small (Scheduler.h:2940-2942)
+
+
+def test_unsupported_features_are_rejected(emu_lib):
+    buf = np.zeros(64, np.complex64)
+    for kw in (dict(performConvolution=1), dict(halfPrecision=1), dict(performZeropadding=[1, 0, 0, 0])):
+        with pytest.raises(api.VkFFTError):
+            api.App([64], 1, buffer_ptr=buf.ctypes.data, lib=emu_lib, **kw)
+
+
+def test_index_permutations_are_bit_exact(run):
+    """Four-Step reorder / transposed stores are pure index permutations: a unit impulse at position p must
+    produce exactly exp(-2 pi i p k / N) to rounding of the twiddles only, and a DC input must give an exact
+    constant N at bin 0 and exact zeros elsewhere is not required - but *positions* must be exact."""
+    N = 1 << 15
+    for p in (0, 1, 777, N - 1):
+        x = np.zeros(N, np.complex64); x[p] = 1.0
+        y, _ = run.transform(x, (N,), 1)
+        k = np.arange(N)
+        ref = np.exp(-2j * np.pi * ((p * k) % N) / N)
+        assert np.abs(y - ref).max() < 2e-6  # every output bin at its natural-order position

@@ -1,0 +1,246 @@
+"""GPU parity tests (pytest -m gpu): the real HIP library through the C-ABI against the oracle on seeded
+inputs, against the reference's captured outputs (tests/golden), and — at BASELINE.json's full 1 GiB sizes —
+through size-independent properties (round trip, linearity, impulse response, Parseval)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import parity
+from helpers import Runner, rel_l2
+from vkfft_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def run(product_lib):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device: the library has no CPU fallback")
+    return Runner(product_lib, "gpu")
+
+
+def test_native_library_is_loaded(product_lib):
+    maps = open("/proc/self/maps").read()
+    assert "libvkfft_mi355x.so" in maps
+
+
+# ---- config 1 / 2: batched 1D C2C fp32 powers of two --------------------------------------------------
+@pytest.mark.parametrize("k", list(range(1, 15)))
+def test_pow2_single_pass(run, oracle, k):
+    N = 1 << k
+    parity.check_c2c(run, oracle, (N,), max(1, min(97, (1 << 17) // N)), False)
+
+
+@pytest.mark.parametrize("k,passes", [(15, 2), (16, 2), (17, 2), (18, 2), (19, 2), (20, 2), (21, 3), (22, 3)])
+def test_pow2_multi_pass(run, oracle, k, passes):
+    N = 1 << k
+    up = parity.check_c2c(run, oracle, (N,), 3 if k < 20 else 2, False)
+    assert up == [passes]
+
+
+def test_config1_vkfft_sample0_plumbing(run, oracle):
+    """BASELINE config 1: N=4096, batch 1, forward+inverse, data = the reference's unseeded rand() stream."""
+    v = oracle.rand_sample(2 * 4096)
+    x = v.view(np.complex64)
+    y, z, _ = run.transform(x, (4096,), 1, both=True)
+    assert rel_l2(y, oracle.truth_c2c(x, (4096,))) < 1e-6
+    assert rel_l2(z, x.astype(np.complex128) * 4096) < 2e-6
+
+
+@pytest.mark.parametrize("k", [8, 10, 12, 13, 14, 16, 18, 20, 22])
+def test_full_size_properties(product_lib, k):
+    """1 GiB buffers (2^27 points): properties that do not need a host reference of the full data set."""
+    import torch
+    N = 1 << k; B = (1 << 27) // N
+    g = torch.Generator(device="cuda"); g.manual_seed(1234 + k)
+    x = torch.empty(2 * N * B, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    buf = x.clone()
+    app = api.App([N], B, buffer_ptr=buf.data_ptr(), lib=product_lib)
+    app.forward(); torch.cuda.synchronize()
+    X = torch.view_as_complex(buf.view(-1, 2)).view(B, N)
+    xc = torch.view_as_complex(x.view(-1, 2)).view(B, N)
+    # (1) spot-check a few transforms of the batch against torch's double FFT (incl. first and last)
+    for b in (0, B // 3, B - 1):
+        ref = torch.fft.fft(xc[b].to(torch.complex128))
+        err = (torch.linalg.norm(X[b].to(torch.complex128) - ref) / torch.linalg.norm(ref)).item()
+        assert err < 1e-6, (k, b, err)
+    # (2) Parseval over the whole buffer: sum|X|^2 = N sum|x|^2
+    e_in = (x.double() ** 2).sum().item(); e_out = (buf.double() ** 2).sum().item()
+    assert abs(e_out / (N * e_in) - 1) < 1e-5
+    # (3) DC bin of every transform = sum of its inputs
+    dc = xc.to(torch.complex128).sum(dim=1)
+    assert (torch.abs(X[:, 0].to(torch.complex128) - dc).max() / np.sqrt(N)).item() < 1e-4
+    # (4) round trip through the inverse = N x  (unnormalised)
+    app.inverse(); torch.cuda.synchronize()
+    rt = (torch.linalg.norm(buf.double() - N * x.double()) / torch.linalg.norm(N * x.double())).item()
+    assert rt < 2e-6, (k, rt)
+    app.delete()
+
+
+def test_full_size_linearity(product_lib):
+    import torch
+    N, B = 1 << 16, 1 << 8
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    a = torch.empty(2 * N * B, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    b = torch.empty(2 * N * B, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    c = (0.5 * a - 0.25 * b).contiguous()
+    app = api.App([N], B, buffer_ptr=a.data_ptr(), lib=product_lib)
+    for t in (a, b, c):
+        app.forward(buffer_ptr=t.data_ptr())
+    torch.cuda.synchronize()
+    lin = 0.5 * a.double() - 0.25 * b.double()
+    assert (torch.linalg.norm(c.double() - lin) / torch.linalg.norm(lin)).item() < 1e-6
+    app.delete()
+
+
+# ---- config 3: non-pow2, Rader, Bluestein, fp64 LUT path ---------------------------------------------
+@pytest.mark.parametrize("N", [3 ** 5, 3 ** 8, 5 ** 4, 5 ** 5, 7 ** 4, 11 ** 3, 13 ** 3, 1080, 2160, 3840, 4000, 7680, 6561, 2 * 3 * 5 * 7 * 11 * 13])
+@pytest.mark.parametrize("dp", [False, True])
+def test_radix_3_5_7_11_13(run, oracle, N, dp):
+    parity.check_c2c(run, oracle, (N,), 4, dp)
+
+
+@pytest.mark.parametrize("N", [3 ** 10, 3 ** 13, 5 ** 8, 7 ** 7, 11 ** 5, 13 ** 5, 4000 * 4096 // 16])
+def test_radix_multi_pass(run, oracle, N):
+    parity.check_c2c(run, oracle, (N,), 2, False, use_c_oracle=False)
+
+
+@pytest.mark.parametrize("N", [17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 17 * 64, 23 * 27, 59 * 8])
+def test_rader_primes(run, oracle, N):
+    parity.check_c2c(run, oracle, (N,), 8, False)
+
+
+@pytest.mark.parametrize("N", [67, 89, 127, 251, 509, 1021, 2039, 4093, 67 * 8])
+def test_bluestein_fp32(run, oracle, N):
+    parity.check_c2c(run, oracle, (N,), 4, False, kind="bluestein")
+
+
+@pytest.mark.parametrize("N", [127, 1021, 2039])
+def test_bluestein_fp64(run, oracle, N):
+    parity.check_c2c(run, oracle, (N,), 4, True, kind="bluestein")
+
+
+@pytest.mark.parametrize("k", [4, 8, 10, 12, 13, 14, 16, 20])
+def test_fp64_pow2(run, oracle, k):
+    parity.check_c2c(run, oracle, (1 << k,), 2, True)
+
+
+# ---- config 4: 3D C2C, R2C/C2R, DCT ---------------------------------------------------------------------
+@pytest.mark.parametrize("shape,b", [((64, 64), 3), ((512, 512), 2), ((128, 64, 32), 2), ((100, 60), 2), ((32, 32, 32), 1), ((30, 20, 10), 2), ((8, 6, 4, 3), 2)])
+@pytest.mark.parametrize("dp", [False, True])
+def test_multidim_c2c(run, oracle, shape, b, dp):
+    parity.check_c2c(run, oracle, shape, b, dp, use_c_oracle=int(np.prod(shape)) * b <= (1 << 14))
+
+
+def test_3d_512cubed(product_lib):
+    """BASELINE config 4: 3D C2C fp32 512^3 (1 GiB): spot lines + round trip."""
+    import torch
+    n = 512
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    x = torch.empty(2 * n ** 3, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    buf = x.clone()
+    app = api.App([n, n, n], 1, buffer_ptr=buf.data_ptr(), lib=product_lib)
+    app.forward(); torch.cuda.synchronize()
+    X = torch.view_as_complex(buf.view(-1, 2)).view(n, n, n)
+    xc = torch.view_as_complex(x.view(-1, 2)).view(n, n, n)
+    # separable check of selected output bins against direct sums is expensive; use a reduced identity instead:
+    # summing the output over two axes equals the 1D FFT of the corresponding input line scaled by n^2... (DC planes)
+    ref_line = torch.fft.fft(xc[0, 0, :].to(torch.complex128)) * 0  # placeholder to keep dtype
+    ref_line = torch.fft.fft(xc.to(torch.complex128).sum(dim=(0, 1)))  # FFT along x of the (y,z)-summed volume = X[0,0,:]
+    err = (torch.linalg.norm(X[0, 0, :].to(torch.complex128) - ref_line) / torch.linalg.norm(ref_line)).item()
+    assert err < 1e-5
+    app.inverse(); torch.cuda.synchronize()
+    rt = (torch.linalg.norm(buf.double() - n ** 3 * x.double()) / torch.linalg.norm(n ** 3 * x.double())).item()
+    assert rt < 2e-6
+    app.delete()
+
+
+@pytest.mark.parametrize("shape,b", [((2,), 2), ((16,), 4), ((15,), 4), ((256,), 8), ((1000,), 3), ((243,), 3), ((4096,), 2), ((8192,), 2), ((1024, 1024), 1), ((64, 32), 2), ((30, 20, 10), 2), ((33, 8), 2)])
+@pytest.mark.parametrize("dp", [False, True])
+def test_r2c_c2r(run, oracle, shape, b, dp):
+    parity.check_r2c(run, oracle, shape, b, dp)
+
+
+@pytest.mark.parametrize("type", [1, 2, 3, 4])
+@pytest.mark.parametrize("dst", [False, True])
+@pytest.mark.parametrize("shape,b", [((8,), 3), ((9,), 3), ((64,), 4), ((81,), 2), ((1024,), 2), ((1024, 1024), 1), ((32, 24), 2), ((12, 10, 6), 2)])
+def test_dct_dst_fp32(run, oracle, type, dst, shape, b):
+    parity.check_r2r(run, oracle, shape, b, False, type, dst)
+
+
+@pytest.mark.parametrize("type", [1, 2, 3, 4])
+@pytest.mark.parametrize("shape,b", [((9,), 3), ((64,), 4), ((32, 24), 2)])
+def test_dct_fp64(run, oracle, type, shape, b):
+    parity.check_r2r(run, oracle, shape, b, True, type, False)
+
+
+# ---- the reference's own outputs ---------------------------------------------------------------------------
+def test_golden_reference_fixtures(run, golden):
+    mod, data = golden
+    for case in mod.CASES:
+        if case["name"] not in data:
+            continue
+        x = mod.golden_input(case)
+        kw = {}
+        if case["kind"] == 1:
+            kw["r2c"] = True
+        elif case["kind"] >= 11:
+            kw["dct"] = case["kind"] - 10
+        y, _ = run.transform(x, case["shape"], case["batch"], inverse=bool(case["inverse"]), **kw)
+        ref = data[case["name"]]
+        tol = 2e-14 if case["dp"] else 4e-6
+        if case["kind"] == 1:
+            ct = np.complex128 if case["dp"] else np.complex64
+            y, ref = y.view(ct), ref.view(ct)
+        assert rel_l2(y, ref) < tol, case["name"]
+
+
+def test_live_reference_comparison_if_built(run):
+    """When oracle/_ref (the reference VkFFT HIP backend, built from /root/reference by oracle/build_ref.sh) travelled to
+    this box, compare against it live on fresh random data."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = os.path.join(root, "oracle", "_ref", "libvkfft_ref.so")
+    if not os.path.exists(p):
+        pytest.skip("oracle/_ref not built")
+    ref = C.CDLL(p); ref.ref_transform.restype = C.c_int
+    for N, B in [(1 << 12, 4), (1 << 17, 2), (2187, 3), (1 << 21, 1)]:
+        x = parity.seeded_complex(N * B, False, N)
+        r = np.ascontiguousarray(x).copy()
+        size = (C.c_uint64 * 4)(N)
+        rc = ref.ref_transform(0, 1, size, C.c_uint64(B), 0, 0, 0, r.ctypes.data_as(C.c_void_p), C.c_uint64(r.nbytes), None)
+        assert rc == 0
+        y, _ = run.transform(x, (N,), B)
+        assert rel_l2(y, r) < 2e-6, N
+
+
+# ---- API behaviour on the device ------------------------------------------------------------------------------
+def test_stream_and_launch_params(product_lib):
+    import torch
+    N, B = 1 << 10, 64
+    s = torch.cuda.Stream()
+    x = torch.randn(2 * N * B, device="cuda")
+    buf = x.clone()
+    with torch.cuda.stream(s):
+        app = api.App([N], B, buffer_ptr=0, stream=s.cuda_stream, normalize=True, lib=product_lib)
+        app.forward(buffer_ptr=buf.data_ptr())
+        app.inverse(buffer_ptr=buf.data_ptr())
+    s.synchronize()
+    assert (torch.linalg.norm(buf - x) / torch.linalg.norm(x)).item() < 1e-6
+    app.delete()
+
+
+def test_out_of_place_and_offsets(product_lib):
+    import torch
+    N, B = 100, 7
+    x = parity.seeded_complex(N * B, False, 4)
+    src = torch.from_numpy(x.view(np.float32).copy()).cuda()
+    dst = torch.zeros(2 * N * B + 64, dtype=torch.float32, device="cuda")
+    app = api.App([N], B, buffer_ptr=dst.data_ptr(), isInputFormatted=1, inputBuffer=src.data_ptr(), bufferOffset=64 * 4 // 2, lib=product_lib)
+    app.forward(); torch.cuda.synchronize()
+    out = dst.cpu().numpy()[32:32 + 2 * N * B].view(np.complex64)
+    assert rel_l2(out, np.fft.fft(x.astype(np.complex128).reshape(B, N), axis=1)) < 1e-6
+    assert np.array_equal(src.cpu().numpy().view(np.complex64), x)
+    app.delete()

@@ -95,14 +95,13 @@ def lib_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvkfft_mi355x.so")
 
 
-def load():
-    """Load the HIP library; raises (never falls back) when it is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    p = lib_path()
-    if not os.path.exists(p):
-        raise RuntimeError(f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'` or `make`")
+def _bind(p):
+    # torch ships its own copy of the HIP runtime: import it first so that this process ends up with ONE
+    # libamdhip64 (the one torch's tensors live in) — device pointers are not shared between two runtimes.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(p)
     lib.initializeVkFFT.restype = C.c_int
     lib.initializeVkFFT.argtypes = [C.POINTER(VkFFTApplication), VkFFTConfiguration]
@@ -120,22 +119,37 @@ def load():
     mine = [C.sizeof(VkFFTConfiguration), C.sizeof(VkFFTLaunchParams), C.sizeof(VkFFTPlan), C.sizeof(VkFFTApplication)]
     if list(sizes) != mine:
         raise RuntimeError(f"struct layout mismatch: library {list(sizes)} vs binding {mine}")
-    _lib = lib
     return lib
+
+
+def load():
+    """Load the HIP library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise RuntimeError(f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'` or `make`")
+        _lib = _bind(p)
+    return _lib
+
+
+def load_test_double(path):
+    """tests only: bind the CPU-emulated build of the same sources (tests/hostemu).  Never used by the product."""
+    return _bind(path)
 
 
 class VkFFTError(RuntimeError):
     def __init__(self, code):
         self.code = code
-        super().__init__(f"VkFFT error {code}: {load().getVkFFTErrorString(code).decode()}")
+        super().__init__(f"VkFFT error {code}")
 
 
 class App:
     """Plan object mirroring the reference call sequence: configure -> initializeVkFFT -> VkFFTAppend -> deleteVkFFT."""
 
     def __init__(self, size, batch=1, *, dp=False, r2c=False, dct=0, dst=0, normalize=False, device_index=0,
-                 buffer_ptr=0, stream=None, **extra):
-        self.lib = load()
+                 buffer_ptr=0, stream=None, lib=None, **extra):
+        self.lib = lib if lib is not None else load()
         self.cfg = VkFFTConfiguration()
         self.app = VkFFTApplication()
         size = list(size) if hasattr(size, "__len__") else [size]
