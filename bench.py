@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native FFT library.
+
+Metric (BASELINE.json): GFLOP/s (5 N log2 N) + achieved HBM GB/s, batched 1D C2C fp32, 1/2/4/8 GPU.
+Workload (BASELINE.json configs[1]): N = 2^8 .. 2^22, batch = 2^27/N  (one 1 GiB in-place buffer per GPU),
+the reference's sample-0 protocol (sample_0_benchmark_VkFFT_single.cpp:85-88, utils_VkFFT.cpp:920-933).
+
+One *step* = one forward + one inverse transform of the 1 GiB buffer for every one of the 15 sizes
+(plans are created once, outside the timed region; inputs are resident in HBM).  Inverse plans are
+normalised (1/N) so that the data stays uniform-random in [-1,1] for the whole run instead of overflowing
+to inf/NaN as it does in the reference's unnormalised loop (data-dependent clocks: MI355X_MICROARCH.md DVFS).
+Multi-GPU: the batch axis is sharded, every rank owns an independent 1 GiB buffer ("weak" scaling), no
+collective on the data path; ranks only meet in the barrier around the timed region.
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     : dominant kernel of the sweep, algorithmic bytes per launch / HIP-event launch duration
+  cpu_baseline : the reference's CPU path (FFTW3 API, served by MKL) timed on this box's host cores on a
+                 bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+KMIN, KMAX, TOTAL_LOG2 = 8, 22, 27
+HBM_PEAK_GBPS = 8000.0        # MI355X spec (MI355X_MICROARCH.md); measured float4-copy ceiling 6290
+
+
+def flops_pair(k):
+    N = 1 << k
+    return 2 * 5.0 * N * k * ((1 << TOTAL_LOG2) // N)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from vkfft_amd import api
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.cuda.current_device()
+    api.load()  # fails loudly if the HIP extension is missing
+
+    nfloat = 2 << TOTAL_LOG2
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1 + rank)
+    buf = torch.empty(nfloat, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=gen)
+    stream = torch.cuda.current_stream().cuda_stream
+    apps = {}
+    for k in range(KMIN, KMAX + 1):
+        N = 1 << k
+        apps[k] = api.App([N], (1 << TOTAL_LOG2) // N, device_index=dev, buffer_ptr=buf.data_ptr(), normalize=True,
+                          stream=stream if stream else None)
+
+    def step():
+        for k in range(KMIN, KMAX + 1):
+            apps[k].forward()
+            apps[k].inverse()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    total_flops = sum(flops_pair(k) for k in range(KMIN, KMAX + 1)) * world
+    bytes_step = (KMAX - KMIN + 1) * 2 * 2 * (8 << TOTAL_LOG2) * world  # 15 sizes x (fwd+inv) x (read+write) x 1 GiB
+    value = total_flops / (ms_per_step * 1e-3) / 1e9
+
+    # ---- per-size table + dominant kernel, HIP events on the launch stream (outside the contract-timed region) ----
+    per_size = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 6
+    for k in range(KMIN, KMAX + 1):
+        e0.record()
+        for _ in range(reps):
+            apps[k].forward(); apps[k].inverse()
+        e1.record(); e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        passes = apps[k].uploads()[0]
+        per_size[k] = dict(pair_ms=round(ms, 4), passes=passes, alg_GBps=round(2 * 2 * (8 << TOTAL_LOG2) / (ms * 1e-3) / 1e9, 1),
+                           GFLOPs=round(flops_pair(k) / (ms * 1e-3) / 1e9, 1))
+    # dominant kernel = the kernel the sweep spends most time in.  Multi-pass sizes (2^15..2^22) run the strided-tile
+    # kernel pow2_col_kernel twice or three times per transform and account for most of the step; its launches are
+    # timed here directly: a two-pass plan of the size with the largest time share = 2 launches per transform.
+    multi = [k for k in per_size if per_size[k]["passes"] > 1]
+    single = [k for k in per_size if per_size[k]["passes"] == 1]
+    t_multi = sum(per_size[k]["pair_ms"] for k in multi)
+    t_single = sum(per_size[k]["pair_ms"] for k in single)
+    if t_multi >= t_single and multi:
+        kd = max((k for k in multi if per_size[k]["passes"] == 2), key=lambda k: per_size[k]["pair_ms"], default=multi[0])
+        kname = "pow2_col_kernel<float> (strided-tile Four-Step pass)"
+    else:
+        kd = max(single, key=lambda k: per_size[k]["pair_ms"])
+        kname = "pow2_row_kernel<float> (single-pass unit-stride)"
+    launches_per_pair = 2 * per_size[kd]["passes"]
+    e0.record()
+    for _ in range(reps):
+        apps[kd].forward(); apps[kd].inverse()
+    e1.record(); e1.synchronize()
+    launch_ms = e0.elapsed_time(e1) / (reps * launches_per_pair)
+    # algorithmic bytes of one launch: SURVEY §8(d): 16 B per point per *transform*; a P-pass plan spreads one
+    # transform over P launches, so one launch accounts for 16*N*B/P bytes of algorithmic traffic.
+    alg_bytes_launch = 16.0 * (1 << TOTAL_LOG2) / per_size[kd]["passes"]
+    achieved = alg_bytes_launch / (launch_ms * 1e-3) / 1e9
+    roofline = dict(bound="hbm", kernel=kname, size_log2N=kd, passes=per_size[kd]["passes"], launch_ms=round(launch_ms, 5),
+                    achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
+                    physical_GBps_per_launch=round(16.0 * (1 << TOTAL_LOG2) / (launch_ms * 1e-3) / 1e9, 1), traffic=None)
+    prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            roofline["traffic"] = json.load(open(prof)).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    # ---- CPU baseline (rank 0, N=1 only) ------------------------------------------------------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    for a in apps.values():
+        a.delete()
+    if rank == 0:
+        out = dict(metric="GFLOP/s (5N log2 N) + achieved HBM GB/s, batched 1D C2C fp32, 1/2/4/8 GPU", value=round(value, 1),
+                   unit="GFLOP/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="batched 1D C2C fp32 in-place, N=2^8..2^22, batch=2^27/N (1 GiB per GPU), FFT+iFFT pair per size per step (sample-0 protocol)",
+                               sizes_log2=[KMIN, KMAX], buffer_bytes_per_gpu=8 << TOTAL_LOG2, parallelism=f"batch-sharded x{world}, no collectives"),
+                   alg_GBps=round(bytes_step / (ms_per_step * 1e-3) / 1e9, 1), per_size=per_size, roofline=roofline, cpu_baseline=cpu)
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+def cpu_baseline():
+    """FFTW3 API (the reference's CPU ground-truth path, sample_11_precision_VkFFT_single.cpp:116-132) served by MKL,
+    all host cores, on a bounded sample: sizes 2^8, 2^12, 2^16, 2^20 with 2^24 points each, forward+inverse."""
+    import numpy as np
+    from oracle import oracle as O
+    try:
+        O.build()
+    except Exception:
+        return None
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("MKL_NUM_THREADS", str(cores))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    pts_log2 = 24
+    rng = np.random.default_rng(0)
+    x = (rng.uniform(-1, 1, 1 << pts_log2) + 1j * rng.uniform(-1, 1, 1 << pts_log2)).astype(np.complex64)
+    flops = 0.0; secs = 0.0
+    ks = [8, 12, 16, 20]
+    if O.fftw_available():
+        for k in ks:
+            N = 1 << k; B = (1 << pts_log2) // N
+            _, tf = O.fftw_c2c(x, N, B, inverse=False, reps=3)
+            _, ti = O.fftw_c2c(x, N, B, inverse=True, reps=3)
+            secs += tf + ti; flops += 2 * 5.0 * N * k * B
+        return dict(value=round(flops / secs / 1e9, 1), unit="GFLOP/s", cores=cores, kind="reference",
+                    sample=f"FFTW3 API via MKL libmkl_rt (FFTW proper is not installed), fftwf_plan_many_dft in-place, N=2^{ks}, 2^{pts_log2} points each, fwd+inv, MKL_NUM_THREADS={os.environ['MKL_NUM_THREADS']}",
+                    alg_GBps=round(len(ks) * 2 * 16.0 * (1 << pts_log2) / secs / 1e9, 1))
+    # fallback: the C restatement of the reference's algorithm (oracle/vkfft_oracle.c), one core
+    pts_log2 = 18
+    x = x[: 1 << pts_log2]
+    for k in ks[:3]:
+        N = 1 << k; B = (1 << pts_log2) // N
+        t0 = time.perf_counter(); O.c2c(x, (N,), B); O.c2c(x, (N,), B, inverse=True); secs += time.perf_counter() - t0
+        flops += 2 * 5.0 * N * k * B
+    return dict(value=round(flops / secs / 1e9, 2), unit="GFLOP/s", cores=1, kind="port",
+                sample=f"oracle/vkfft_oracle.c (scalar C restatement), N=2^{ks[:3]}, 2^{pts_log2} points each, fwd+inv")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,6 @@
+R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-export VKFFT_MI355X_CHUNK_MIB=0
-for k in 12 16 20 22; do
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof$k -o p$k -- python $GRAFT_REPO_ROOT/tools/perf_sweep.py $k $k > /dev/null 2>&1
-done
-find $GRAFT_REPO_ROOT/gpurun_out/ -name "*kernel_stats.csv" | while read f; do echo $f; cut -d, -f1-8 $f | head -8; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_bench_stdout.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o f -- python $R/tools/pmc_probe.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o w -- python $R/tools/pmc_probe.py > /dev/null 2>&1
+find $R/gpurun_out/prof_bench $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write -type f | head -20
