@@ -20,12 +20,18 @@
 #pragma once
 #include "engine.h"
 #include "butterflies.h"
+#include "memops.h"
+#include <cstdlib>
 
 namespace vkfft_mi355x {
 
 #if defined(VKFFT_HOSTEMU)
 #define VKFFT_WAVE_SYNC() hostemu::wave_sync()
+#define VKFFT_OPAQUE_ZERO(z) uint32_t z = 0
 #else
+// hides a (wave-uniform) pointer's provenance from the optimiser: stops loop-invariant twiddle loads from being
+// hoisted out of the persistent tile loop and pinned in dozens of VGPRs
+#define VKFFT_OPAQUE_ZERO(z) uint32_t z = 0; asm volatile("" : "+s"(z))
 // orders this wave's LDS writes before its later LDS reads without an s_barrier
 #define VKFFT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #endif
@@ -50,8 +56,20 @@ template <int TCP, int LOGE> __device__ inline uint32_t pow2_slot(uint32_t a) {
 	else return a * TCP;
 }
 
-template <typename T, typename SCH, int SI, int TPF, int TCP>
-__device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const cx<T>* __restrict__ lut, const uint32_t tau, const bool waveOnly) {
+// stage-twiddle source: global LUT through a buffer resource (row kernels) or a copy of the LUT in LDS (persistent
+// column kernel: keeps the vector-memory queue free for the next tile's prefetch — vmcnt retires in issue order,
+// so any later VMEM load that is consumed would drag the prefetched tile's latency into the critical path)
+template <typename T> struct TwGlobal {
+	GBuf lut;
+	__device__ inline cx<T> get(uint32_t s, uint32_t constOff) const { return gb_load<T>(lut, s * (uint32_t)sizeof(cx<T>), constOff * (uint32_t)sizeof(cx<T>)); }
+};
+template <typename T> struct TwLds {
+	const cx<T>* tab;
+	__device__ inline cx<T> get(uint32_t s, uint32_t constOff) const { return tab[constOff + s]; }
+};
+
+template <typename T, typename SCH, int SI, int TPF, int TCP, typename TW>
+__device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const TW lut, const uint32_t tau, const bool waveOnly) {
 	constexpr int LOGE = SCH::LOGE, E = 1 << LOGE;
 	constexpr int LOGR = SCH::bits[SI], R = 1 << LOGR, NB = E / R;
 	constexpr int LOGS = SCH::logS(SI), S = 1 << LOGS;
@@ -65,9 +83,8 @@ __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const cx<T>* __restric
 		const uint32_t s = t & (S - 1);
 		if constexpr (SI > 0) {
 			constexpr int LO = SCH::lutOff(SI);
-			const cx<T>* w = lut + LO + s;
 #pragma unroll
-			for (int i = 1; i < R; i++) x[i] = cmul(x[i], w[(i - 1) * S]);
+			for (int i = 1; i < R; i++) x[i] = cmul(x[i], lut.get(s, (uint32_t)(LO + (i - 1) * S)));
 		}
 		dft<R, T>(x);
 		if constexpr (last) {
@@ -92,7 +109,7 @@ __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const cx<T>* __restric
 		if constexpr (SI + 2 < SCH::NS) { // another exchange will overwrite the buffer: all reads must be done first
 			if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
 		}
-		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, TCP>(v, ldsf, lut, tau, waveOnly);
+		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, TCP, TW>(v, ldsf, lut, tau, waveOnly);
 	}
 }
 
@@ -101,6 +118,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_ro
 	constexpr int LOGN = SCH::LOGN, N = 1 << LOGN, LOGE = SCH::LOGE, E = 1 << LOGE, TPF = N / E;
 	constexpr int LDSPF = SCH::NS > 1 ? N + (N >> LOGE) : 1;
 	constexpr bool waveOnly = TPF <= 64; // an FFT never straddles wavefronts
+	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	__shared__ cx<T> lds[FPW * LDSPF];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t f = tid / TPF, tau = tid % TPF;
@@ -108,23 +126,22 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_ro
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
 	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
-	const uint32_t g0 = tile * FPW + f;
-	const bool valid = g0 < p.dim[0].count;
-	const cx<T>* in = (const cx<T>*)p.in + ((int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)g0 * p.dim[0].inStride);
-	cx<T>* out = (cx<T>*)p.out + ((int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)g0 * p.dim[0].outStride);
+	const uint32_t f0 = tile * FPW;
+	const bool valid = f0 + f < p.dim[0].count;
+	// wave-uniform tile bases + one 32-bit lane offset per side (memops.h)
+	const GBuf gin = make_gbuf((const cx<T>*)p.in + ((int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride));
+	const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride));
+	const GBuf glut = make_gbuf(p.lut);
+	const uint32_t laneIn = valid ? (f * (uint32_t)p.dim[0].inStride + tau) * ES : kGbInvalid;
+	const uint32_t laneOut = valid ? (f * (uint32_t)p.dim[0].outStride + tau) * ES : kGbInvalid;
 	cx<T> v[E];
-	if (valid) {
 #pragma unroll
-		for (int m = 0; m < E; m++) v[m] = in[tau + m * TPF];
-	} else {
-#pragma unroll
-		for (int m = 0; m < E; m++) v[m] = cx<T>{(T)0, (T)0};
-	}
+	for (int m = 0; m < E; m++) v[m] = gb_load<T>(gin, laneIn, (uint32_t)(m * TPF) * ES);
 	if (p.swapIn) {
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = cswap(v[m]);
 	}
-	pow2_stages<T, SCH, 0, TPF, 0>(v, lds + f * LDSPF, (const cx<T>*)p.lut, tau, waveOnly);
+	pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
 	if (p.swapOut) {
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = cswap(v[m]);
@@ -134,10 +151,26 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_ro
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = cscale(v[m], sc);
 	}
-	if (valid) {
 #pragma unroll
-		for (int m = 0; m < E; m++) out[tau + m * TPF] = v[m];
+	for (int m = 0; m < E; m++) gb_store<T>(gout, laneOut, (uint32_t)(m * TPF) * ES, v[m]);
+}
+
+inline unsigned pow2_num_cus() {
+	static unsigned n = 0;
+	if (!n) {
+#if defined(VKFFT_HOSTEMU)
+		n = 4;
+#else
+		int dev = 0, v = 0;
+		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = (unsigned)v; else n = 256;
+#endif
 	}
+	return n;
+}
+inline unsigned pow2_persist_mult() { // tuning knob: resident-grid multiplier (1 = exactly resident)
+	static int m = 0;
+	if (!m) { const char* e = getenv("VKFFT_MI355X_PERSIST_MULT"); m = e ? atoi(e) : 1; if (m < 1) m = 1; }
+	return (unsigned)m;
 }
 
 // ---- strided-tile ("column") kernel: Four-Step passes and the non-unit-stride axes of 2D/3D transforms ----
@@ -150,6 +183,7 @@ template <typename T, typename SCH, int TC>
 __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col_kernel(const PassParams p) {
 	constexpr int LOGN = SCH::LOGN, L = 1 << LOGN, LOGE = SCH::LOGE, E = 1 << LOGE, TPF = L / E;
 	constexpr int TCP = TC + 1, NT = TPF * TC;
+	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	__shared__ cx<T> lds[L * TCP];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t c = tid % TC, tau = tid / TC;
@@ -161,33 +195,50 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 	const bool valid = col0 + c < p.dim[0].count;
 	const int64_t inB = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)col0 * p.dim[0].inStride;
 	const int64_t outB = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)col0 * p.dim[0].outStride;
-	const cx<T>* in = (const cx<T>*)p.in + inB + (int64_t)c * p.dim[0].inStride;
+	// wave-uniform tile bases + one 32-bit lane offset per side, uniform step between a thread's elements (memops.h)
+	const GBuf gin = make_gbuf((const cx<T>*)p.in + inB);
+	const GBuf gout = make_gbuf((cx<T>*)p.out + outB);
+	const GBuf glut = make_gbuf(p.lut);
+	const uint32_t laneIn = valid ? (tau * (uint32_t)p.inStrideJ + c * (uint32_t)p.dim[0].inStride) * ES : kGbInvalid;
+	const uint32_t stepIn = (uint32_t)(TPF * (uint32_t)p.inStrideJ) * ES;
 	cx<T> v[E];
-	if (valid) {
 #pragma unroll
-		for (int m = 0; m < E; m++) v[m] = in[(int64_t)(tau + m * TPF) * p.inStrideJ];
-	} else {
-#pragma unroll
-		for (int m = 0; m < E; m++) v[m] = cx<T>{(T)0, (T)0};
-	}
+	for (int m = 0; m < E; m++) v[m] = gb_load<T>(gin, laneIn, m * stepIn);
 	if (p.swapIn) {
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = cswap(v[m]);
 	}
-	pow2_stages<T, SCH, 0, TPF, TCP>(v, lds + c, (const cx<T>*)p.lut, tau, false);
+	pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
 	if (p.swapOut) {
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = cswap(v[m]);
 	}
-	if (p.postOp == OP_TWIDDLE_4STEP) {
+	if (p.postOp == OP_TWIDDLE_4STEP && !(p.debugFlags & 1)) {
+		// Four-Step twiddle w^(k*col), k = tau + m*TPF: exponent e_m = e_0 + m*D with D = TPF*col.  Instead of one
+		// table look-up (2 gathers of the two-level LUT) per element, 2*sqrt(E)-1 look-ups feed a two-factor product.
 		uint32_t colIdx, rr;
 		p.fsColDiv.divmod(col0 + c, colIdx, rr);
-		const cx<T>* tab = (const cx<T>*)p.aux;
+		const GBuf gtab = make_gbuf(p.aux);
 		const uint32_t loMask = (1u << p.fsLoBits) - 1u;
+		const uint32_t hiBase = (loMask + 1u) * ES;
+		auto tw = [&](uint32_t e) { return cmul(gb_load<T>(gtab, (e & loMask) * ES, 0), gb_load<T>(gtab, (e >> p.fsLoBits) * ES, hiBase)); };
+		if (p.debugFlags & 8) {
 #pragma unroll
-		for (int m = 0; m < E; m++) {
-			const uint32_t e = (tau + m * TPF) * colIdx;
-			v[m] = cmul(v[m], cmul(tab[e & loMask], tab[(loMask + 1u) + (e >> p.fsLoBits)]));
+			for (int m = 0; m < E; m++) v[m] = cmul(v[m], tw((tau + m * TPF) * colIdx));
+		} else {
+			// m = (j << LOB) + i:  w^(e_0 + m*D) = A[j] * B[i],  A[j] = w^((tau + (j<<LOB)*TPF)*col),  B[i] = w^(i*TPF*col)
+			constexpr int HIB = (LOGE + 1) / 2, LOB = LOGE - HIB;
+			cx<T> A[1 << HIB], B[1 << LOB];
+#pragma unroll
+			for (int j = 0; j < (1 << HIB); j++) A[j] = tw((tau + (uint32_t)((j << LOB) * TPF)) * colIdx);
+			B[0] = cx<T>{(T)1, (T)0};
+#pragma unroll
+			for (int i = 1; i < (1 << LOB); i++) B[i] = tw((uint32_t)(i * TPF) * colIdx);
+			cx<T> wm[E];
+#pragma unroll
+			for (int m = 0; m < E; m++) wm[m] = (m & ((1 << LOB) - 1)) ? cmul(A[m >> LOB], B[m & ((1 << LOB) - 1)]) : A[m >> LOB];
+#pragma unroll
+			for (int m = 0; m < E; m++) v[m] = cmul(v[m], wm[m]);
 		}
 	}
 	const T sc = (T)p.scale;
@@ -196,11 +247,10 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 		for (int m = 0; m < E; m++) v[m] = cscale(v[m], sc);
 	}
 	if (p.colModeOut) {
-		if (valid) {
-			cx<T>* out = (cx<T>*)p.out + outB + (int64_t)c * p.dim[0].outStride;
+		const uint32_t laneOut = valid ? (tau * (uint32_t)p.outStrideJ + c * (uint32_t)p.dim[0].outStride) * ES : kGbInvalid;
+		const uint32_t stepOut = (uint32_t)(TPF * (uint32_t)p.outStrideJ) * ES;
 #pragma unroll
-			for (int m = 0; m < E; m++) out[(int64_t)(tau + m * TPF) * p.outStrideJ] = v[m];
-		}
+		for (int m = 0; m < E; m++) gb_store<T>(gout, laneOut, m * stepOut, v[m]);
 	} else {
 		// transposed store: column c becomes the contiguous run out[c*dim0.outStride + k*outStrideJ], lanes along k
 		if constexpr (SCH::NS > 1) __syncthreads(); // the last exchange's reads are complete
@@ -208,12 +258,12 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 		for (int m = 0; m < E; m++) lds[(tau + m * TPF) * TCP + c] = v[m];
 		__syncthreads();
 		const uint32_t nvalid = p.dim[0].count - col0 < (uint32_t)TC ? p.dim[0].count - col0 : (uint32_t)TC;
-		cx<T>* out = (cx<T>*)p.out + outB;
 #pragma unroll
 		for (int i = 0; i < E; i++) {
 			const uint32_t idx = tid + i * NT;
 			const uint32_t k = idx % L, cc = idx / L;
-			if (cc < nvalid) out[(int64_t)cc * p.dim[0].outStride + (int64_t)k * p.outStrideJ] = lds[k * TCP + cc];
+			const uint32_t off = cc < nvalid ? (cc * (uint32_t)p.dim[0].outStride + k * (uint32_t)p.outStrideJ) * ES : kGbInvalid;
+			gb_store<T>(gout, off, 0, lds[k * TCP + cc]);
 		}
 	}
 }

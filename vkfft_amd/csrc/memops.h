@@ -1,0 +1,60 @@
+// Global-memory access for the hand-specialised kernels: CDNA buffer addressing.
+// A tile is addressed as  wave-uniform base (128-bit buffer resource in SGPRs) + wave-uniform scalar offset
+// + ONE 32-bit per-lane byte offset, instead of a 64-bit address per element: ~2 VGPRs and 2-4 VALU ops
+// less per element, and lanes outside a partial tile are simply given an out-of-range offset (loads return 0,
+// stores are dropped by the hardware range check) — no divergent branches.
+#pragma once
+#include "common.h"
+
+namespace vkfft_mi355x {
+
+constexpr uint32_t kGbRange = 0x7FFFFFF0u;  // bytes addressable through one resource
+constexpr uint32_t kGbInvalid = 0x7FFFFFF8u; // per-lane offset that is always out of range
+
+#if defined(VKFFT_HOSTEMU)
+struct GBuf { char* base; };
+inline GBuf make_gbuf(const void* p) { return {(char*)p}; }
+template <typename T> inline cx<T> gb_load(GBuf b, uint32_t voff, uint32_t soff) {
+	if (voff >= kGbRange) return cx<T>{(T)0, (T)0};
+	return *(const cx<T>*)(b.base + (uint64_t)voff + soff);
+}
+template <typename T> inline void gb_store(GBuf b, uint32_t voff, uint32_t soff, cx<T> v) {
+	if (voff >= kGbRange) return;
+	*(cx<T>*)(b.base + (uint64_t)voff + soff) = v;
+}
+#else
+typedef unsigned int vk_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int vk_u32x4 __attribute__((ext_vector_type(4)));
+struct GBuf { __amdgpu_buffer_rsrc_t r; };
+__device__ inline GBuf make_gbuf(const void* p) {
+	// the base is wave-uniform by construction (kernel arguments + blockIdx); readfirstlane makes that provable,
+	// otherwise the compiler wraps every buffer op in a waterfall loop
+	const uint64_t a = (uint64_t)p;
+	const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+	GBuf b;
+	b.r = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), (short)0, (int)kGbRange, 0x00020000);
+	return b;
+}
+template <typename T> __device__ inline cx<T> gb_load(GBuf b, uint32_t voff, uint32_t soff);
+template <> __device__ inline cx<float> gb_load<float>(GBuf b, uint32_t voff, uint32_t soff) {
+	vk_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 0);
+	return cx<float>{__uint_as_float(t.x), __uint_as_float(t.y)};
+}
+template <> __device__ inline cx<double> gb_load<double>(GBuf b, uint32_t voff, uint32_t soff) {
+	vk_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, soff, 0);
+	return cx<double>{__hiloint2double((int)t.y, (int)t.x), __hiloint2double((int)t.w, (int)t.z)};
+}
+template <typename T> __device__ inline void gb_store(GBuf b, uint32_t voff, uint32_t soff, cx<T> v);
+template <> __device__ inline void gb_store<float>(GBuf b, uint32_t voff, uint32_t soff, cx<float> v) {
+	vk_u32x2 t; t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
+	__builtin_amdgcn_raw_buffer_store_b64(t, b.r, voff, soff, 0);
+}
+template <> __device__ inline void gb_store<double>(GBuf b, uint32_t voff, uint32_t soff, cx<double> v) {
+	vk_u32x4 t;
+	t.x = (unsigned)__double2loint(v.x); t.y = (unsigned)__double2hiint(v.x);
+	t.z = (unsigned)__double2loint(v.y); t.w = (unsigned)__double2hiint(v.y);
+	__builtin_amdgcn_raw_buffer_store_b128(t, b.r, voff, soff, 0);
+}
+#endif
+
+} // namespace vkfft_mi355x

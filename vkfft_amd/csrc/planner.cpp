@@ -7,6 +7,7 @@
 // 160 KiB LDS per workgroup, 256-byte coalescing segments for strided tiles, Infinity-Cache chunking.
 #include "engine.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <complex>
@@ -224,6 +225,8 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.opN = b.opN;
 	p.fsN = (uint32_t)b.fsN;
 	p.fsColDiv = make_fastdiv(b.fsColDiv);
+	p.fsInv2 = (b.fsN && (b.fsN & (b.fsN - 1)) == 0 && b.fsN <= (1ull << 24) && !b.dp) ? (float)(2.0 / (double)b.fsN) : 0.f; // sincospi path only where exact
+	if (const char* e = getenv("VKFFT_MI355X_DEBUG")) p.debugFlags = (uint32_t)atoi(e);
 	p.scale = b.scale;
 	p.divL = make_fastdiv((uint32_t)b.L);
 	p.divOutLen = make_fastdiv(p.outLen);
