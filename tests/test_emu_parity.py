@@ -32,7 +32,7 @@ def test_rader_direct_primes(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 2, False)
 
 
-@pytest.mark.parametrize("N", [67, 127, 251, 1009, 2039, 67 * 4])
+@pytest.mark.parametrize("N", [67, 127, 251, 1009, 2039, 4093, 15319, 67 * 4])
 @pytest.mark.parametrize("dp", [False, True])
 def test_bluestein(run, oracle, N, dp):
     parity.check_c2c(run, oracle, (N,), 2, dp, kind="bluestein")

@@ -112,12 +112,12 @@ def test_rader_primes(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 8, False)
 
 
-@pytest.mark.parametrize("N", [67, 89, 127, 251, 509, 1021, 2039, 4093, 67 * 8])
+@pytest.mark.parametrize("N", [67, 89, 127, 251, 509, 1021, 2039, 4093, 67 * 8, 15319, 21269, 2000083])
 def test_bluestein_fp32(run, oracle, N):
-    parity.check_c2c(run, oracle, (N,), 4, False, kind="bluestein")
+    parity.check_c2c(run, oracle, (N,), 4 if N < 100000 else 1, False, kind="bluestein", use_c_oracle=N < 5000)
 
 
-@pytest.mark.parametrize("N", [127, 1021, 2039])
+@pytest.mark.parametrize("N", [127, 1021, 2039, 4093, 15319])
 def test_bluestein_fp64(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 4, True, kind="bluestein")
 

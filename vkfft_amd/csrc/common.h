@@ -97,6 +97,7 @@ struct PassParams {
 	const void* lut;     // stage twiddles, cx<T>
 	const void* aux;     // op-specific table (4-step two-level LUT, R2C/DCT twiddles, chirp, ...)
 	const void* aux2;    // second op-specific table (Bluestein FFT(chirp), DCT-IV post twiddles)
+	const void* aux3;    // pre-op table when aux is taken by the Four-Step LUT (multi-pass Bluestein chirp)
 	uint32_t L;          // sub-FFT length computed by the stages
 	uint32_t nStages;
 	StageDesc st[kMaxStages];
@@ -116,6 +117,7 @@ struct PassParams {
 	uint32_t bluesteinSwapIn, bluesteinSwapOut;
 	uint32_t inLen, outLen; // elements gathered / stored per sub-FFT (differ from L for real transforms, Bluestein)
 	uint32_t opN;        // logical transform size of the pre/post op (e.g. real length N of R2C / DCT)
+	uint32_t opStrideJ, opStride0, opStride1; // position-indexed ops (Bluestein chirp, pointwise LUT): natural index = j*opStrideJ + g0*opStride0 + g1*opStride1
 	uint32_t fsN;        // 4-step: twiddle exponent denominator (product of all pass lengths of this decomposition level)
 	uint32_t fsLoBits;   // 4-step two-level LUT: aux = 2^fsLoBits low entries followed by the high entries
 	FastDiv fsColDiv;    // 4-step: column index used in the twiddle = g0 / fsColDiv

@@ -34,7 +34,7 @@ template <typename T> __device__ inline cx<T> twiddle4(const PassParams& p, uint
 
 // value that goes to LDS position `pos` of sub-FFT f (before the optional inverse swap)
 template <typename T>
-__device__ inline cx<T> pre_gather(const PassParams& p, const void* in, int64_t base, uint32_t pos) {
+__device__ inline cx<T> pre_gather(const PassParams& p, const void* in, int64_t base, uint32_t pos, uint32_t natBase) {
 	using IO = GlobalIO<T>;
 	const int64_t sj = p.inStrideJ;
 	const cx<T> zero = {(T)0, (T)0};
@@ -103,17 +103,18 @@ __device__ inline cx<T> pre_gather(const PassParams& p, const void* in, int64_t 
 		return cscale(((const cx<T>*)p.aux)[pos], a);
 	}
 	case OP_BLUESTEIN_PRE: {
-		if (pos >= p.inLen) return zero;
+		const uint32_t n = natBase + pos * p.opStrideJ; // natural position inside the transform
+		if (n >= p.opN) return zero;
 		cx<T> v = IO::ldc(in, base + (int64_t)pos * sj);
 		if (p.bluesteinSwapIn) v = cswap(v);
-		return cmulc(v, ((const cx<T>*)p.aux)[pos]);
+		return cmulc(v, ((const cx<T>*)(p.aux3 ? p.aux3 : p.aux))[n]);
 	}
 	}
 }
 
 // output element k of sub-FFT f, gathered from LDS buffer `buf` (values already un-swapped by `rd`)
 template <typename T, typename RD>
-__device__ inline void post_store(const PassParams& p, void* out, int64_t base, uint32_t k, uint32_t colIdx, RD rd) {
+__device__ inline void post_store(const PassParams& p, void* out, int64_t base, uint32_t k, uint32_t colIdx, uint32_t natBase, RD rd) {
 	using IO = GlobalIO<T>;
 	const int64_t sj = p.outStrideJ;
 	const T sc = (T)p.scale;
@@ -129,8 +130,8 @@ __device__ inline void post_store(const PassParams& p, void* out, int64_t base, 
 		IO::stc(out, base + (int64_t)k * sj, cscale(v, sc));
 		return;
 	}
-	case OP_MUL_LUT: {
-		cx<T> v = cmul(rd(k), ((const cx<T>*)p.aux2)[k]);
+	case OP_MUL_LUT: { // pointwise multiply by a table indexed with the natural position (Bluestein: FFT(chirp)/M)
+		cx<T> v = cmul(rd(k), ((const cx<T>*)p.aux2)[natBase + k * p.opStrideJ]);
 		IO::stc(out, base + (int64_t)k * sj, cscale(v, sc));
 		return;
 	}
@@ -188,7 +189,9 @@ __device__ inline void post_store(const PassParams& p, void* out, int64_t base, 
 		return;
 	}
 	case OP_BLUESTEIN_POST: {
-		cx<T> v = cmulc(rd(k), ((const cx<T>*)p.aux)[k]);
+		const uint32_t n = natBase + k * p.opStrideJ;
+		if (n >= p.opN) return;
+		cx<T> v = cmulc(rd(k), ((const cx<T>*)p.aux)[n]);
 		if (p.bluesteinSwapOut) v = cswap(v);
 		IO::stc(out, base + (int64_t)k * sj, cscale(v, sc));
 		return;
@@ -294,7 +297,7 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 			if (p.colMode) { f = idx & (p.T - 1); pos = idx >> p.logT; }
 			else p.divL.divmod(idx, f, pos);
 			cx<T> v = {(T)0, (T)0};
-			if (f < nvalid) v = pre_gather<T>(p, p.in, inBase + (int64_t)f * p.dim[0].inStride, pos);
+			if (f < nvalid) v = pre_gather<T>(p, p.in, inBase + (int64_t)f * p.dim[0].inStride, pos, (g0base + f) * p.opStride0 + g1 * p.opStride1);
 			if (p.swapIn) v = cswap(v);
 			bufA[(pos + (pos >> ps)) * Tp + f] = v;
 		}
@@ -354,7 +357,7 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 			};
 			uint32_t colIdx = 0;
 			if (p.postOp == OP_TWIDDLE_4STEP) { uint32_t qq, rr; p.fsColDiv.divmod(g0base + f, qq, rr); colIdx = qq; }
-			post_store<T>(p, p.out, outBase + (int64_t)f * p.dim[0].outStride, k, colIdx, rd);
+			post_store<T>(p, p.out, outBase + (int64_t)f * p.dim[0].outStride, k, colIdx, (g0base + f) * p.opStride0 + g1 * p.opStride1, rd);
 		}
 	}
 }

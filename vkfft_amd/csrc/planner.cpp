@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <complex>
 #include <map>
+#include <mutex>
 
 namespace vkfft_mi355x {
 
@@ -91,6 +92,8 @@ struct PassBuild {
 	uint32_t inLen = 0, outLen = 0, opN = 0;
 	bool swapIn = false, swapOut = false, bsSwapIn = false, bsSwapOut = false;
 	uint64_t fsN = 0; uint32_t fsColDiv = 1;
+	uint32_t opStrideJ = 1, opStride0 = 0, opStride1 = 0; // natural-position index of element j of sub-FFT (g0,g1) for position-indexed ops
+	size_t auxOff2ForPre = (size_t)-1;
 	double scale = 1.0;
 	int inRole = ROLE_BUFFER, outRole = ROLE_BUFFER;
 	int64_t inOffset = 0, outOffset = 0;
@@ -171,7 +174,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		S *= R;
 	}
 	pp.lutOff = lutOff;
-	pp.auxOff = b.auxOff; pp.aux2Off = b.aux2Off;
+	pp.auxOff = b.auxOff; pp.aux2Off = b.aux2Off; pp.aux3Off = b.auxOff2ForPre;
 
 	std::vector<HostDim> dims = b.dims;
 	if (dims.empty()) dims.push_back({1, 0, 0});
@@ -223,6 +226,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.inLen = b.inLen ? b.inLen : (uint32_t)b.L;
 	p.outLen = b.outLen ? b.outLen : (uint32_t)b.L;
 	p.opN = b.opN;
+	p.opStrideJ = b.opStrideJ; p.opStride0 = b.opStride0; p.opStride1 = b.opStride1;
 	p.fsN = (uint32_t)b.fsN;
 	p.fsColDiv = make_fastdiv(b.fsColDiv);
 	p.fsInv2 = (b.fsN && (b.fsN & (b.fsN - 1)) == 0 && b.fsN <= (1ull << 24) && !b.dp) ? (float)(2.0 / (double)b.fsN) : 0.f; // sincospi path only where exact
@@ -329,26 +333,33 @@ struct AxisJob {
 
 static uint32_t direct_max(const TransformDesc& d) { return (uint32_t)std::min<uint64_t>(d.raderMultMax, 61); }
 
-// host-side mixed-radix FFT in long double (for Bluestein's FFT(chirp))
-static void host_fft(std::vector<cld>& a) {
-	size_t n = a.size();
+// host-side mixed-radix FFT in long double (for Bluestein's FFT(chirp)); roots = exp(-2 pi i k / M) for the top-level M
+static void host_fft_rec(std::vector<cld>& a, const std::vector<cld>& roots) {
+	const size_t n = a.size(), M = roots.size();
 	if (n <= 1) return;
 	size_t p = 0;
 	for (size_t q : {2, 3, 5, 7, 11, 13}) if (n % q == 0) { p = q; break; }
-	if (!p) { // naive
+	const size_t rs = M / n; // roots[(k * rs) % M] = exp(-2 pi i k / n)
+	if (!p) {
 		std::vector<cld> r(n);
-		for (size_t k = 0; k < n; k++) { cld s = 0; for (size_t j = 0; j < n; j++) s += a[j] * unit_root((uint64_t)j * k % n, n); r[k] = s; }
+		for (size_t k = 0; k < n; k++) { cld s = 0; for (size_t j = 0; j < n; j++) s += a[j] * roots[((j * k) % n) * rs]; r[k] = s; }
 		a = r; return;
 	}
-	size_t m = n / p;
+	const size_t m = n / p;
 	std::vector<std::vector<cld>> sub(p, std::vector<cld>(m));
 	for (size_t j = 0; j < n; j++) sub[j % p][j / p] = a[j];
-	for (auto& s : sub) host_fft(s);
+	for (auto& s2 : sub) host_fft_rec(s2, roots);
 	for (size_t k = 0; k < n; k++) {
-		cld acc = 0;
-		for (size_t r = 0; r < p; r++) acc += sub[r][k % m] * unit_root((uint64_t)r * k % n, n);
+		cld acc = sub[0][k % m];
+		for (size_t r = 1; r < p; r++) acc += sub[r][k % m] * roots[((r * k) % n) * rs];
 		a[k] = acc;
 	}
+}
+static void host_fft(std::vector<cld>& a) {
+	const size_t M = a.size();
+	std::vector<cld> roots(M);
+	for (size_t k = 0; k < M; k++) roots[k] = unit_root(k, M);
+	host_fft_rec(a, roots);
 }
 
 static uint64_t next_smooth(uint64_t n, int maxPrime) {
@@ -357,6 +368,101 @@ static uint64_t next_smooth(uint64_t n, int maxPrime) {
 		for (int p : {2, 3, 5, 7, 11, 13}) { if (p > maxPrime) break; while (r % p == 0) r /= p; }
 		if (r == 1) return m;
 	}
+}
+
+// ---- multi-pass (Four-Step) emitter ---------------------------------------------------------------------
+// N = n0*M (M = n1*n2 for three passes).  Pass A reads the input as an n0 x M matrix column-wise and stores every
+// column as a contiguous run into scratch region T1; the last pass reads T1 column-wise again and writes natural
+// order to the output (reference: vkFFT_4step.h:31, vkFFT_ReadWrite.h:1405-1476; execution order RunApp.h:114).
+struct MultiPassIO {
+	std::vector<HostDim> othersIn, othersOut;  // the other dims (batch, ...) with the strides of the input / output side
+	int inRole = ROLE_BUFFER, outRole = ROLE_BUFFER;
+	int64_t inOffset = 0, outOffset = 0, t1Offset = 0; // element offsets (T1 lives in ROLE_TEMP)
+	bool swapIn = false, swapOut = false;
+	double scale = 1.0;
+	bool chunkable = false;
+	// hooks for Bluestein: operation on the very first load / the very last store, indexed by the natural position
+	uint32_t firstPre = OP_NONE, lastPost = OP_NONE;
+	size_t firstAux = (size_t)-1, lastAux = (size_t)-1, lastAux2 = (size_t)-1;
+	bool bsSwapIn = false, bsSwapOut = false;
+	uint32_t opN = 0;
+};
+
+static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<uint64_t>& sp, const MultiPassIO& io, Arena& ar, std::vector<PassPlan>& passes) {
+	const size_t nOthers = io.othersIn.size();
+	std::vector<HostDim> othersTmp = io.othersIn;
+	{ int64_t run = (int64_t)N; for (auto& o : othersTmp) { o.inStride = o.outStride = run; run *= (int64_t)o.count; } }
+	auto dimsFor = [&](const HostDim& tiled, std::vector<HostDim> extra, int inKind, int outKind) {
+		// inKind/outKind: 0 = caller's layout (input / output side), 1 = scratch layout
+		std::vector<HostDim> r; r.push_back(tiled);
+		for (auto& e : extra) r.push_back(e);
+		for (size_t i = 0; i < nOthers; i++) {
+			HostDim h; h.count = io.othersIn[i].count;
+			h.inStride = inKind == 0 ? io.othersIn[i].inStride : othersTmp[i].inStride;
+			h.outStride = outKind == 0 ? io.othersOut[i].outStride : othersTmp[i].outStride;
+			r.push_back(h);
+		}
+		return r;
+	};
+	const int chunkBase = io.chunkable ? (int)nOthers : -1;
+	const uint64_t n0 = sp[0];
+	const uint64_t M = N / n0;
+	// pass A: x[n0][M] columns, FFT over n0, twiddle, store transposed Y^T[m][k0] into T1
+	PassBuild a = proto;
+	a.L = n0; a.inStrideJ = (int64_t)M; a.outStrideJ = 1;
+	a.colIn = true; a.colOut = false;
+	a.dims = dimsFor({M, 1, (int64_t)n0}, {}, 0, 1);
+	a.swapIn = io.swapIn; a.postOp = OP_TWIDDLE_4STEP; a.fsN = N; a.fsColDiv = 1;
+	a.inRole = io.inRole; a.inOffset = io.inOffset; a.outRole = ROLE_TEMP; a.outOffset = io.t1Offset;
+	a.label = "4step-A"; a.noCollapse = true; a.chunkDim = chunkBase;
+	if (io.firstPre != OP_NONE) {
+		a.preOp = io.firstPre; a.auxOff2ForPre = io.firstAux; a.bsSwapIn = io.bsSwapIn; a.opN = io.opN;
+		a.opStrideJ = (uint32_t)M; a.opStride0 = 1; a.opStride1 = 0;
+	}
+	PassPlan pa; int r = finish_pass(a, ar, pa); if (r) return r;
+	passes.push_back(pa);
+	if (sp.size() == 2) {
+		// pass B: T1[m][k0]: FFT over m (stride n0) for T adjacent k0; X[k0 + n0*k1]
+		PassBuild c = proto;
+		c.L = M; c.inStrideJ = (int64_t)n0; c.outStrideJ = (int64_t)n0;
+		c.colIn = c.colOut = true;
+		c.dims = dimsFor({n0, 1, 1}, {}, 1, 0);
+		c.swapOut = io.swapOut; c.scale = io.scale;
+		c.inRole = ROLE_TEMP; c.inOffset = io.t1Offset; c.outRole = io.outRole; c.outOffset = io.outOffset;
+		c.label = "4step-B"; c.noCollapse = true; c.chunkDim = chunkBase;
+		if (io.lastPost != OP_NONE) {
+			c.postOp = io.lastPost; c.auxOff = io.lastAux; c.aux2Off = io.lastAux2; c.bsSwapOut = io.bsSwapOut; c.opN = io.opN;
+			c.opStrideJ = (uint32_t)n0; c.opStride0 = 1; c.opStride1 = 0;
+		}
+		PassPlan pb; r = finish_pass(c, ar, pb); if (r) return r;
+		passes.push_back(pb);
+	} else {
+		const uint64_t n1 = sp[1], n2 = sp[2];
+		// pass B (in place on T1): layout [m = i1*n2 + i2][k0]; FFT over i1 (stride n2*n0); tiled dim c = i2*n0 + k0
+		PassBuild bb = proto;
+		bb.L = n1; bb.inStrideJ = bb.outStrideJ = (int64_t)(n2 * n0);
+		bb.colIn = bb.colOut = true;
+		bb.dims = dimsFor({n2 * n0, 1, 1}, {}, 1, 1);
+		bb.postOp = OP_TWIDDLE_4STEP; bb.fsN = M; bb.fsColDiv = (uint32_t)n0;
+		bb.inRole = bb.outRole = ROLE_TEMP; bb.inOffset = bb.outOffset = io.t1Offset;
+		bb.label = "4step3-B"; bb.noCollapse = true; bb.chunkDim = chunkBase;
+		PassPlan pb; r = finish_pass(bb, ar, pb); if (r) return r;
+		// pass C: T1 [k1][i2][k0]: FFT over i2 (stride n0); out X[k0 + n0*(k1 + n1*k2)]
+		PassBuild c = proto;
+		c.L = n2; c.inStrideJ = (int64_t)n0; c.outStrideJ = (int64_t)(n1 * n0);
+		c.colIn = c.colOut = true;
+		c.dims = dimsFor({n0, 1, 1}, {{n1, (int64_t)(n2 * n0), (int64_t)n0}}, 1, 0);
+		c.swapOut = io.swapOut; c.scale = io.scale;
+		c.inRole = ROLE_TEMP; c.inOffset = io.t1Offset; c.outRole = io.outRole; c.outOffset = io.outOffset;
+		c.label = "4step3-C"; c.noCollapse = true; c.chunkDim = io.chunkable ? chunkBase + 1 : -1;
+		if (io.lastPost != OP_NONE) {
+			c.postOp = io.lastPost; c.auxOff = io.lastAux; c.aux2Off = io.lastAux2; c.bsSwapOut = io.bsSwapOut; c.opN = io.opN;
+			c.opStrideJ = (uint32_t)(n0 * n1); c.opStride0 = 1; c.opStride1 = (uint32_t)n0;
+		}
+		PassPlan pc; r = finish_pass(c, ar, pc); if (r) return r;
+		passes.push_back(pb); passes.push_back(pc);
+	}
+	return 0;
 }
 
 // ---- C2C along one axis -------------------------------------------------------------------------------
@@ -376,21 +482,64 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		const uint64_t N = j.N;
 		uint64_t M = d.forceBluesteinSize ? d.forceBluesteinSize : next_smooth(2 * N - 1, d.fixMaxRadixBluestein ? d.fixMaxRadixBluestein : 7);
 		uint64_t cap = unit ? rowCap : max_col_len(dp, d.maxLds, 1);
-		if (M > cap) return 3002; // multi-pass Bluestein: not yet
+		std::vector<uint64_t> spM;
+		if (M > cap) {
+			if (!unit) return 3002;
+			// M must split into column-kernel lengths; prefer a power of two when the smooth size does not split well
+			if (!choose_split(M, dp, d.maxLds, dmax, !d.disableFastKernels, spM)) {
+				if (d.forceBluesteinSize) return 3002;
+				M = 1; while (M < 2 * N - 1) M *= 2;
+				if (!choose_split(M, dp, d.maxLds, dmax, !d.disableFastKernels, spM)) return 3002;
+			}
+		}
 		const size_t es = dp ? 16 : 8;
 		size_t chirpOff = ar.alloc(N * es), bhatOff = ar.alloc(M * es);
-		std::vector<cld> bext(M, cld(0, 0));
-		for (uint64_t n = 0; n < N; n++) {
-			unsigned __int128 sq = (unsigned __int128)n * n;
-			uint64_t e = (uint64_t)(sq % (2 * N));
-			cld c = std::conj(unit_root_pi(e, N)); // exp(+i pi n^2 / N)
-			ar.putc(chirpOff, n, c, dp);
-			bext[n] = c;
-			if (n) bext[M - n] = c;
+		{
+			// FFT(chirp) is identical for the forward and the inverse plan of an application: keep the last one
+			static std::mutex mtx; static uint64_t cN = 0, cM = 0; static std::vector<cld> cChirp, cBhat;
+			std::lock_guard<std::mutex> lock(mtx);
+			if (cN != N || cM != M) {
+				cChirp.assign(N, cld(0, 0));
+				std::vector<cld> bext(M, cld(0, 0));
+				for (uint64_t n = 0; n < N; n++) {
+					unsigned __int128 sq = (unsigned __int128)n * n;
+					uint64_t e = (uint64_t)(sq % (2 * N));
+					cld c = std::conj(unit_root_pi(e, N)); // exp(+i pi n^2 / N), vkFFT_RecursiveFFTGenerators.h:139-148
+					cChirp[n] = c;
+					bext[n] = c;
+					if (n) bext[M - n] = c;
+				}
+				host_fft(bext);
+				cBhat.swap(bext); cN = N; cM = M;
+			}
+			for (uint64_t n = 0; n < N; n++) ar.putc(chirpOff, n, cChirp[n], dp);
+			for (uint64_t k = 0; k < M; k++) ar.putc(bhatOff, k, cBhat[k] / (ld)M, dp);
 		}
-		host_fft(bext);
-		for (uint64_t k = 0; k < M; k++) ar.putc(bhatOff, k, bext[k] / (ld)M, dp);
-		b.L = M; b.inLen = (uint32_t)N; b.outLen = (uint32_t)N;
+		if (!spM.empty()) {
+			// multi-pass Bluestein: FFT_M (Four-Step) with the chirp fused into its first load and FFT(chirp) into its last
+			// store, then the inverse FFT_M with the second chirp fused into its last store.  Scratch: T1 | T2.
+			uint64_t nsub = 1;
+			for (auto& o : j.others) nsub *= o.count;
+			auto dense = [&](std::vector<HostDim> v) { int64_t run = (int64_t)M; for (auto& o : v) { o.inStride = o.outStride = run; run *= (int64_t)o.count; } return v; };
+			MultiPassIO f;
+			f.othersIn = j.others; for (auto& o : f.othersIn) o.outStride = o.inStride;
+			f.othersOut = dense(j.others);
+			f.inRole = j.inRole; f.outRole = ROLE_TEMP; f.outOffset = (int64_t)(nsub * M); f.t1Offset = 0;
+			f.firstPre = OP_BLUESTEIN_PRE; f.firstAux = chirpOff; f.bsSwapIn = j.inverse; f.opN = (uint32_t)N;
+			f.lastPost = OP_MUL_LUT; f.lastAux2 = bhatOff;
+			int r = emit_multipass(b, M, spM, f, ar, passes); if (r) return r;
+			MultiPassIO g;
+			g.othersIn = dense(j.others);
+			g.othersOut = j.others; for (auto& o : g.othersOut) o.inStride = o.outStride;
+			g.inRole = ROLE_TEMP; g.inOffset = (int64_t)(nsub * M); g.outRole = j.outRole; g.t1Offset = 0;
+			g.swapIn = g.swapOut = true; g.scale = j.scale;
+			g.lastPost = OP_BLUESTEIN_POST; g.lastAux = chirpOff; g.bsSwapOut = j.inverse; g.opN = (uint32_t)N;
+			r = emit_multipass(b, M, spM, g, ar, passes); if (r) return r;
+			out.uploadsPerAxis[j.axisIndex] = (uint32_t)(2 * spM.size());
+			out.tempBytes = std::max<uint64_t>(out.tempBytes, 2 * nsub * M * es);
+			return 0;
+		}
+		b.L = M; b.inLen = (uint32_t)N; b.outLen = (uint32_t)N; b.opN = (uint32_t)N;
 		b.preOp = OP_BLUESTEIN_PRE; b.midOp = OP_BLUESTEIN_MID; b.postOp = OP_BLUESTEIN_POST;
 		b.bsSwapIn = b.bsSwapOut = j.inverse;
 		b.auxOff = chirpOff; b.aux2Off = bhatOff;
@@ -433,78 +582,20 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	if (!choose_split(j.N, dp, d.maxLds, dmax, !d.disableFastKernels, sp)) return 3002;
 	out.uploadsPerAxis[j.axisIndex] = (uint32_t)sp.size();
 	for (size_t i = 0; i < sp.size(); i++) out.axisSplit[j.axisIndex][i] = sp[sp.size() - 1 - i];
-	const uint64_t N = j.N;
-	// every "other" dim of the job has stride multiples of N on a dense layout in temp; temp keeps the batch
-	// layout of the *input* side compacted: sub-transform b lives at b*N.
-	std::vector<HostDim> othersIn = j.others, othersTmp = j.others;
-	{ // dense enumeration of the other dims inside temp
-		int64_t run = (int64_t)N;
-		for (auto& o : othersTmp) { o.inStride = run; o.outStride = run; run *= (int64_t)o.count; }
-	}
-	auto dimsFor = [&](const HostDim& tiled, std::vector<HostDim> extra, int inKind, int outKind) {
-		// inKind/outKind: 0 = user layout of the axis job (in / out side), 1 = temp layout
-		std::vector<HostDim> r; r.push_back(tiled);
-		for (auto& e : extra) r.push_back(e);
-		for (size_t i = 0; i < j.others.size(); i++) {
-			HostDim h; h.count = j.others[i].count;
-			h.inStride = inKind == 0 ? j.others[i].inStride : othersTmp[i].inStride;
-			h.outStride = outKind == 0 ? j.others[i].outStride : othersTmp[i].outStride;
-			r.push_back(h);
-		}
-		return r;
-	};
-	if (sp.size() == 2) {
-		const uint64_t n0 = sp[0], M = sp[1];
-		// pass A: x[n0][M] columns, FFT over n0, twiddle, store transposed Y^T[m][k0] into temp
-		PassBuild a = b;
-		a.L = n0; a.inStrideJ = (int64_t)M; a.outStrideJ = 1;
-		a.colIn = true; a.colOut = false;
-		a.dims = dimsFor({M, 1, (int64_t)n0}, {}, 0, 1);
-		a.swapIn = j.inverse; a.postOp = OP_TWIDDLE_4STEP; a.fsN = N; a.fsColDiv = 1;
-		a.inRole = j.inRole; a.outRole = ROLE_TEMP; a.label = "4step-A"; a.noCollapse = true; a.chunkDim = (int)j.others.size();
-		PassPlan pa; int r = finish_pass(a, ar, pa); if (r) return r;
-		// pass B: temp[m][k0]: FFT over m (stride n0) for T adjacent k0; X[k0 + n0*k1]
-		PassBuild c = b;
-		c.L = M; c.inStrideJ = (int64_t)n0; c.outStrideJ = (int64_t)n0;
-		c.colIn = c.colOut = true;
-		c.dims = dimsFor({n0, 1, 1}, {}, 1, 0);
-		c.swapOut = j.inverse; c.scale = j.scale;
-		c.inRole = ROLE_TEMP; c.outRole = j.outRole; c.label = "4step-B"; c.noCollapse = true; c.chunkDim = (int)j.others.size();
-		PassPlan pb; r = finish_pass(c, ar, pb); if (r) return r;
-		passes.push_back(pa); passes.push_back(pb);
-	} else {
-		const uint64_t n0 = sp[0], n1 = sp[1], n2 = sp[2], M = n1 * n2;
-		PassBuild a = b;
-		a.L = n0; a.inStrideJ = (int64_t)M; a.outStrideJ = 1;
-		a.colIn = true; a.colOut = false;
-		a.dims = dimsFor({M, 1, (int64_t)n0}, {}, 0, 1);
-		a.swapIn = j.inverse; a.postOp = OP_TWIDDLE_4STEP; a.fsN = N; a.fsColDiv = 1;
-		a.inRole = j.inRole; a.outRole = ROLE_TEMP; a.label = "4step3-A"; a.noCollapse = true; a.chunkDim = (int)j.others.size();
-		PassPlan pa; int r = finish_pass(a, ar, pa); if (r) return r;
-		// pass B (in place on temp): layout [m = i1*n2 + i2][k0]; FFT over i1 (stride n2*n0); tiled dim c = i2*n0 + k0
-		PassBuild bb = b;
-		bb.L = n1; bb.inStrideJ = bb.outStrideJ = (int64_t)(n2 * n0);
-		bb.colIn = bb.colOut = true;
-		bb.dims = dimsFor({n2 * n0, 1, 1}, {}, 1, 1);
-		bb.postOp = OP_TWIDDLE_4STEP; bb.fsN = M; bb.fsColDiv = (uint32_t)n0;
-		bb.inRole = bb.outRole = ROLE_TEMP; bb.label = "4step3-B"; bb.noCollapse = true; bb.chunkDim = (int)j.others.size();
-		PassPlan pb; r = finish_pass(bb, ar, pb); if (r) return r;
-		// pass C: temp [k1][i2][k0]: FFT over i2 (stride n0); out X[k0 + n0*(k1 + n1*k2)]
-		PassBuild c = b;
-		c.L = n2; c.inStrideJ = (int64_t)n0; c.outStrideJ = (int64_t)(n1 * n0);
-		c.colIn = c.colOut = true;
-		c.dims = dimsFor({n0, 1, 1}, {{n1, (int64_t)(n2 * n0), (int64_t)n0}}, 1, 0);
-		c.swapOut = j.inverse; c.scale = j.scale;
-		c.inRole = ROLE_TEMP; c.outRole = j.outRole; c.label = "4step3-C"; c.noCollapse = true; c.chunkDim = (int)j.others.size() + 1;
-		PassPlan pc; r = finish_pass(c, ar, pc); if (r) return r;
-		passes.push_back(pa); passes.push_back(pb); passes.push_back(pc);
-	}
+	MultiPassIO io;
+	io.othersIn = j.others; io.othersOut = j.others;
+	for (auto& o : io.othersIn) o.outStride = o.inStride;
+	for (auto& o : io.othersOut) o.inStride = o.outStride;
+	io.inRole = j.inRole; io.outRole = j.outRole;
+	io.swapIn = io.swapOut = j.inverse; io.scale = j.scale;
+	io.chunkable = true;
+	int r = emit_multipass(b, j.N, sp, io, ar, passes);
+	if (r) return r;
 	uint64_t nsub = 1;
 	for (auto& o : j.others) nsub *= o.count;
-	out.tempBytes = std::max<uint64_t>(out.tempBytes, nsub * N * (dp ? 16 : 8));
+	out.tempBytes = std::max<uint64_t>(out.tempBytes, nsub * j.N * (dp ? 16 : 8));
 	return 0;
 }
-
 
 // ---- real transforms ---------------------------------------------------------------------------------------
 // R2C/C2R along axis 0 (reference: two-sequences packing vkFFT_R2C.h:450/:178 for single-upload, even
