@@ -44,6 +44,12 @@ def test_fourstep(run, oracle, N, passes):
     assert up == [passes]
 
 
+@pytest.mark.parametrize("shape,dp,passes", [((32, 32768), False, 2), ((8, 3 ** 10), True, 2), ((4, 4, 32768), False, 2)])
+def test_fourstep_along_strided_axis(run, oracle, shape, dp, passes):
+    up = parity.check_c2c(run, oracle, shape, 1, dp, use_c_oracle=False)
+    assert up[-1] == passes
+
+
 def test_fourstep_fp64_and_batch(run, oracle):
     assert parity.check_c2c(run, oracle, (1 << 14,), 3, True) == [2]
 
@@ -54,7 +60,7 @@ def test_multidim(run, oracle, shape, dp):
     parity.check_c2c(run, oracle, shape, 2, dp)
 
 
-@pytest.mark.parametrize("shape", [(2,), (16,), (15,), (256,), (1000,), (243,), (64, 32), (30, 20, 10), (33, 8)])
+@pytest.mark.parametrize("shape", [(2,), (16,), (15,), (256,), (1000,), (243,), (64, 32), (30, 20, 10), (33, 8), (65536,), (2 * 3 ** 9, 3)])
 @pytest.mark.parametrize("dp", [False, True])
 def test_r2c_c2r(run, oracle, shape, dp):
     parity.check_r2c(run, oracle, shape, 2, dp)

@@ -134,6 +134,11 @@ def test_multidim_c2c(run, oracle, shape, b, dp):
     parity.check_c2c(run, oracle, shape, b, dp, use_c_oracle=int(np.prod(shape)) * b <= (1 << 14))
 
 
+@pytest.mark.parametrize("shape,b,dp", [((32, 32768), 2, False), ((64, 1 << 20), 1, False), ((16, 3 ** 10), 1, True), ((8, 8, 1 << 16), 1, False), ((64, 1 << 22), 1, False)])
+def test_long_strided_axes(run, oracle, shape, b, dp):
+    parity.check_c2c(run, oracle, shape, b, dp, use_c_oracle=False)
+
+
 def test_3d_512cubed(product_lib):
     """BASELINE config 4: 3D C2C fp32 512^3 (1 GiB): spot lines + round trip."""
     import torch
@@ -157,7 +162,7 @@ def test_3d_512cubed(product_lib):
     app.delete()
 
 
-@pytest.mark.parametrize("shape,b", [((2,), 2), ((16,), 4), ((15,), 4), ((256,), 8), ((1000,), 3), ((243,), 3), ((4096,), 2), ((8192,), 2), ((1024, 1024), 1), ((64, 32), 2), ((30, 20, 10), 2), ((33, 8), 2)])
+@pytest.mark.parametrize("shape,b", [((2,), 2), ((16,), 4), ((15,), 4), ((256,), 8), ((1000,), 3), ((243,), 3), ((4096,), 2), ((8192,), 2), ((1024, 1024), 1), ((64, 32), 2), ((30, 20, 10), 2), ((33, 8), 2), ((65536,), 2), ((1 << 20,), 2), ((1 << 22,), 1), ((2 * 3 ** 9, 3), 2)])
 @pytest.mark.parametrize("dp", [False, True])
 def test_r2c_c2r(run, oracle, shape, b, dp):
     parity.check_r2c(run, oracle, shape, b, dp)

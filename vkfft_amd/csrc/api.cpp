@@ -55,6 +55,7 @@ VkFFTResult make_direction(VkFFTApplication* app, const TransformDesc& base, boo
 		for (uint64_t k = 0; k < VKFFT_MAX_FFT_DIMENSIONS; k++) pl->actualFFTSizePerAxis[i][k] = app->configuration.size[k];
 		if (app->configuration.FFTdim == 1 && app->actualNumBatches > 1) pl->actualFFTSizePerAxis[i][1] = app->actualNumBatches;
 		pl->actualPerformR2CPerAxis[i] = (i == 0) ? app->configuration.performR2C : 0;
+		pl->bigSequenceEvenR2C = dp->bigSequenceEvenR2C;
 	}
 	*outPlan = pl;
 	return VKFFT_SUCCESS;

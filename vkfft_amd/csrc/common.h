@@ -121,6 +121,7 @@ struct PassParams {
 	uint32_t fsN;        // 4-step: twiddle exponent denominator (product of all pass lengths of this decomposition level)
 	uint32_t fsLoBits;   // 4-step two-level LUT: aux = 2^fsLoBits low entries followed by the high entries
 	FastDiv fsColDiv;    // 4-step: column index used in the twiddle = g0 / fsColDiv
+	uint32_t fsColFromDim1; // 4-step along a strided axis: the twiddle's column index is g1 (dim[1]) instead
 	double scale;        // multiplied into the output (1/N normalisation); 1.0 = off
 	FastDiv divL, divOutLen;
 	FastDiv divNb[kMaxStages]; // L / radix per stage

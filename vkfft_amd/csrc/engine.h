@@ -11,7 +11,7 @@
 namespace vkfft_mi355x {
 
 enum BufRole : int { ROLE_BUFFER = 0, ROLE_TEMP = 1, ROLE_INPUT = 2, ROLE_OUTPUT = 3 };
-enum KernelKind : int { KERNEL_GENERIC = 0, KERNEL_POW2_ROW = 1, KERNEL_POW2_COL = 2 };
+enum KernelKind : int { KERNEL_GENERIC = 0, KERNEL_POW2_ROW = 1, KERNEL_POW2_COL = 2, KERNEL_R2C_PAIR = 3 };
 
 struct HostDim {
 	uint64_t count;
@@ -48,6 +48,7 @@ struct DirectionPlan {
 	uint64_t chunkBatch = 0, totalBatch = 0;
 	uint64_t chunkTempStrideBytes = 0;
 	uint32_t uploadsPerAxis[4] = {0, 0, 0, 0};
+	uint32_t bigSequenceEvenR2C = 0;
 	uint64_t axisSplit[4][4] = {};
 };
 

@@ -356,8 +356,52 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 				return swapO ? cswap(v) : v;
 			};
 			uint32_t colIdx = 0;
-			if (p.postOp == OP_TWIDDLE_4STEP) { uint32_t qq, rr; p.fsColDiv.divmod(g0base + f, qq, rr); colIdx = qq; }
+			if (p.postOp == OP_TWIDDLE_4STEP) { if (p.fsColFromDim1) colIdx = g1; else { uint32_t qq, rr; p.fsColDiv.divmod(g0base + f, qq, rr); colIdx = qq; } }
 			post_store<T>(p, p.out, outBase + (int64_t)f * p.dim[0].outStride, k, colIdx, (g0base + f) * p.opStride0 + g1 * p.opStride1, rd);
+		}
+	}
+}
+
+// Post / pre pass of the even-length R2C / C2R decomposition for rows that need a multi-pass half-length FFT
+// (reference: shaderGen_R2C_even_decomposition, vkFFT_R2C_even_decomposition.h:40, math :132-230; plan
+// vkFFT_Plan_R2C.h:30).  In place on rows of H+1 complex (H = N/2): thread k handles the conjugate pair (k, H-k).
+//   forward: X_k = 1/2[(Z_k + conj Z_{H-k}) - i w^k (Z_k - conj Z_{H-k})],  w = exp(-2 pi i / N)
+//   inverse: Z_k = (X_k + conj X_{H-k}) + i conj(w^k) (X_k - conj X_{H-k})      (unnormalised, = 2x the packed spectrum)
+template <typename T> __global__ void __launch_bounds__(256) r2c_even_pair_kernel(const PassParams p) {
+	const uint32_t H = p.opN >> 1;
+	const uint32_t npair = H / 2 + 1;
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t row = blockIdx.y;
+	if (k >= npair) return;
+	const uint32_t g0 = row % p.dim[0].count; row /= p.dim[0].count;
+	const uint32_t g1 = row % p.dim[1].count, g2 = row / p.dim[1].count;
+	cx<T>* z = (cx<T>*)p.out + ((int64_t)g0 * p.dim[0].outStride + (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride);
+	const cx<T> w = twiddle4<T>(p, k); // exp(-2 pi i k / N)
+	const uint32_t km = H - k;
+	const T sc = (T)p.scale;
+	if (!p.swapIn) { // forward
+		const cx<T> a = z[k], b = k == 0 ? z[0] : z[km];
+		if (k == 0) {
+			z[0] = cx<T>{(a.x + a.y) * sc, (T)0};
+			z[H] = cx<T>{(a.x - a.y) * sc, (T)0};
+			return;
+		}
+		const cx<T> s = cadd(a, cconj(b)), d = cmul(w, csub(a, cconj(b)));
+		z[k] = cx<T>{(T)0.5 * sc * (s.x + d.y), (T)0.5 * sc * (s.y - d.x)};
+		if (km != k) {
+			const cx<T> w2 = cx<T>{-w.x, w.y}; // w^(H-k) = -conj(w^k)
+			const cx<T> s2 = cadd(b, cconj(a)), d2 = cmul(w2, csub(b, cconj(a)));
+			z[km] = cx<T>{(T)0.5 * sc * (s2.x + d2.y), (T)0.5 * sc * (s2.y - d2.x)};
+		}
+	} else { // inverse pre-pass
+		const cx<T> a = z[k], b = z[km];
+		const cx<T> wc = cconj(w);
+		const cx<T> s = cadd(a, cconj(b)), d = cmul(wc, csub(a, cconj(b)));
+		z[k] = cx<T>{(s.x - d.y) * sc, (s.y + d.x) * sc};
+		if (km != k && k != 0) {
+			const cx<T> wc2 = cx<T>{-w.x, -w.y}; // conj(w^(H-k)) = -w^k
+			const cx<T> s2 = cadd(b, cconj(a)), d2 = cmul(wc2, csub(b, cconj(a)));
+			z[km] = cx<T>{(s2.x - d2.y) * sc, (s2.y + d2.x) * sc};
 		}
 	}
 }

@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 		// Four-Step twiddle w^(k*col), k = tau + m*TPF: exponent e_m = e_0 + m*D with D = TPF*col.  Instead of one
 		// table look-up (2 gathers of the two-level LUT) per element, 2*sqrt(E)-1 look-ups feed a two-factor product.
 		uint32_t colIdx, rr;
-		p.fsColDiv.divmod(col0 + c, colIdx, rr);
+		if (p.fsColFromDim1) colIdx = g1; else p.fsColDiv.divmod(col0 + c, colIdx, rr);
 		const GBuf gtab = make_gbuf(p.aux);
 		const uint32_t loMask = (1u << p.fsLoBits) - 1u;
 		const uint32_t hiBase = (loMask + 1u) * ES;

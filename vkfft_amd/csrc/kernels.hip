@@ -22,6 +22,25 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	case KERNEL_POW2_ROW:
 	case KERNEL_POW2_COL:
 		return launch_pow2(pp, prm, stream);
+	case KERNEL_R2C_PAIR: {
+		const uint32_t npair = (prm.opN >> 2) + 1;
+		const uint64_t rows = (uint64_t)prm.dim[0].count * prm.dim[1].count * prm.dim[2].count;
+		if (rows > 65535) { // grid.y limit: split over dim[2]/dim[1] on the host
+			PassParams q = prm;
+			if (prm.dim[2].count > 1) {
+				for (uint32_t i = 0; i < prm.dim[2].count; i++) { q.dim[2].count = 1; q.out = (char*)prm.out + (int64_t)i * prm.dim[2].outStride * pp.outElemBytes; int r = launch_pass(pp, q, stream); if (r) return r; }
+			} else if (prm.dim[1].count > 1) {
+				for (uint32_t i = 0; i < prm.dim[1].count; i++) { q.dim[1].count = 1; q.out = (char*)prm.out + (int64_t)i * prm.dim[1].outStride * pp.outElemBytes; int r = launch_pass(pp, q, stream); if (r) return r; }
+			} else {
+				for (uint32_t i = 0; i < prm.dim[0].count; i += 32768) { q.dim[0].count = std::min<uint32_t>(32768, prm.dim[0].count - i); q.out = (char*)prm.out + (int64_t)i * prm.dim[0].outStride * pp.outElemBytes; int r = launch_pass(pp, q, stream); if (r) return r; }
+			}
+			return 0;
+		}
+		const dim3 g2((npair + 255) / 256, (uint32_t)rows);
+		if (pp.dp) hipLaunchKernelGGL(r2c_even_pair_kernel<double>, g2, dim3(256), 0, stream, prm);
+		else hipLaunchKernelGGL(r2c_even_pair_kernel<float>, g2, dim3(256), 0, stream, prm);
+		break;
+	}
 	default:
 		return 4039;
 	}

@@ -91,7 +91,7 @@ struct PassBuild {
 	uint32_t preOp = OP_NONE, midOp = OP_NONE, postOp = OP_NONE;
 	uint32_t inLen = 0, outLen = 0, opN = 0;
 	bool swapIn = false, swapOut = false, bsSwapIn = false, bsSwapOut = false;
-	uint64_t fsN = 0; uint32_t fsColDiv = 1;
+	uint64_t fsN = 0; uint32_t fsColDiv = 1; bool fsColFromDim1 = false;
 	uint32_t opStrideJ = 1, opStride0 = 0, opStride1 = 0; // natural-position index of element j of sub-FFT (g0,g1) for position-indexed ops
 	size_t auxOff2ForPre = (size_t)-1;
 	double scale = 1.0;
@@ -134,7 +134,12 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	if (b.allowFast && b.fastKernel == KERNEL_GENERIC && b.colIn && b.L >= 16 && b.L <= 1024 && (b.L & (b.L - 1)) == 0 && b.preOp == OP_NONE
 	    && b.midOp == OP_NONE && (b.postOp == OP_NONE || b.postOp == OP_TWIDDLE_4STEP) && !b.realIn && !b.realOut && !b.forceT) {
 		int variant, bits[4], tc, thr;
-		if (pow2_col_lookup(ilog2(b.L), b.dp, &variant, bits, &tc, &thr)) {
+		// buffer addressing of the fast kernels: a tile must span less than 2 GiB on both sides
+		const uint64_t esz = b.dp ? 16 : 8;
+		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
+		const uint64_t spanIn = (b.L * (uint64_t)std::llabs(b.inStrideJ) + 64 * (uint64_t)std::llabs(d0.inStride)) * esz;
+		const uint64_t spanOut = (b.L * (uint64_t)std::llabs(b.outStrideJ) + 64 * (uint64_t)std::llabs(d0.outStride)) * esz;
+		if (spanIn < 0x7FFFFF00ull && spanOut < 0x7FFFFF00ull && pow2_col_lookup(ilog2(b.L), b.dp, &variant, bits, &tc, &thr)) {
 			b.fastKernel = KERNEL_POW2_COL; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)tc;
 			b.radices.clear();
 			for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
@@ -229,6 +234,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.opStrideJ = b.opStrideJ; p.opStride0 = b.opStride0; p.opStride1 = b.opStride1;
 	p.fsN = (uint32_t)b.fsN;
 	p.fsColDiv = make_fastdiv(b.fsColDiv);
+	p.fsColFromDim1 = b.fsColFromDim1 ? 1 : 0;
 	p.fsInv2 = (b.fsN && (b.fsN & (b.fsN - 1)) == 0 && b.fsN <= (1ull << 24) && !b.dp) ? (float)(2.0 / (double)b.fsN) : 0.f; // sincospi path only where exact
 	if (const char* e = getenv("VKFFT_MI355X_DEBUG")) p.debugFlags = (uint32_t)atoi(e);
 	p.scale = b.scale;
@@ -465,6 +471,65 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 	return 0;
 }
 
+// Four-Step along a NON-unit-stride axis (element stride W, a unit-stride dimension x of extent nx beside it):
+// coalescing comes from x, so no transposition is needed; the decomposition index becomes an extra batch dim.
+//   2 passes: A  FFT over i0 for every (m, x), twiddle w_N^(k0*m)   [in -> T1, same shape]
+//             B  FFT over m  for every (k0, x), X[(k0 + n0*k1)]      [T1 -> out]
+static int emit_multipass_strided(const PassBuild& proto, uint64_t N, const std::vector<uint64_t>& sp, int64_t strideIn, int64_t strideOut,
+                                  const HostDim& xdim, const std::vector<HostDim>& rest, int inRole, int outRole, bool inverse, double scale,
+                                  Arena& ar, std::vector<PassPlan>& passes, uint64_t& tempElems) {
+	// scratch layout: dense [n][x] per sub-problem, sub-problems enumerated densely
+	const int64_t W = (int64_t)xdim.count;
+	std::vector<HostDim> restTmp = rest;
+	{ int64_t run = (int64_t)N * W; for (auto& o : restTmp) { o.inStride = o.outStride = run; run *= (int64_t)o.count; } tempElems = (uint64_t)run; }
+	auto withRest = [&](std::vector<HostDim> lead, int inKind, int outKind) {
+		for (size_t i = 0; i < rest.size(); i++) {
+			HostDim h; h.count = rest[i].count;
+			h.inStride = inKind == 0 ? rest[i].inStride : restTmp[i].inStride;
+			h.outStride = outKind == 0 ? rest[i].outStride : restTmp[i].outStride;
+			lead.push_back(h);
+		}
+		return lead;
+	};
+	const uint64_t n0 = sp[0], M = N / n0;
+	PassBuild a = proto;
+	a.L = n0; a.inStrideJ = (int64_t)M * strideIn; a.outStrideJ = (int64_t)M * W;
+	a.colIn = a.colOut = true;
+	a.dims = withRest({{(uint64_t)W, xdim.inStride, 1}, {M, strideIn, W}}, 0, 1);
+	a.swapIn = inverse; a.postOp = OP_TWIDDLE_4STEP; a.fsN = N; a.fsColFromDim1 = true;
+	a.inRole = inRole; a.outRole = ROLE_TEMP; a.label = "4step-strided-A"; a.noCollapse = true;
+	PassPlan pa; int r = finish_pass(a, ar, pa); if (r) return r;
+	passes.push_back(pa);
+	if (sp.size() == 2) {
+		PassBuild c = proto;
+		c.L = M; c.inStrideJ = W; c.outStrideJ = (int64_t)n0 * strideOut;
+		c.colIn = c.colOut = true;
+		c.dims = withRest({{(uint64_t)W, 1, xdim.outStride}, {n0, (int64_t)M * W, strideOut}}, 1, 0);
+		c.swapOut = inverse; c.scale = scale;
+		c.inRole = ROLE_TEMP; c.outRole = outRole; c.label = "4step-strided-B"; c.noCollapse = true;
+		PassPlan pb; r = finish_pass(c, ar, pb); if (r) return r;
+		passes.push_back(pb);
+	} else {
+		const uint64_t n1 = sp[1], n2 = sp[2];
+		PassBuild bb = proto;
+		bb.L = n1; bb.inStrideJ = bb.outStrideJ = (int64_t)n2 * W;
+		bb.colIn = bb.colOut = true;
+		bb.dims = withRest({{(uint64_t)W, 1, 1}, {n2, W, W}, {n0, (int64_t)M * W, (int64_t)M * W}}, 1, 1);
+		bb.postOp = OP_TWIDDLE_4STEP; bb.fsN = M; bb.fsColFromDim1 = true;
+		bb.inRole = bb.outRole = ROLE_TEMP; bb.label = "4step3-strided-B"; bb.noCollapse = true;
+		PassPlan pb; r = finish_pass(bb, ar, pb); if (r) return r;
+		PassBuild c = proto;
+		c.L = n2; c.inStrideJ = W; c.outStrideJ = (int64_t)(n0 * n1) * strideOut;
+		c.colIn = c.colOut = true;
+		c.dims = withRest({{(uint64_t)W, 1, xdim.outStride}, {n1, (int64_t)n2 * W, (int64_t)n0 * strideOut}, {n0, (int64_t)M * W, strideOut}}, 1, 0);
+		c.swapOut = inverse; c.scale = scale;
+		c.inRole = ROLE_TEMP; c.outRole = outRole; c.label = "4step3-strided-C"; c.noCollapse = true;
+		PassPlan pc; r = finish_pass(c, ar, pc); if (r) return r;
+		passes.push_back(pb); passes.push_back(pc);
+	}
+	return 0;
+}
+
 // ---- C2C along one axis -------------------------------------------------------------------------------
 static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
 	const bool dp = j.dp;
@@ -559,7 +624,8 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		b.L = j.N;
 		if (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N >= 4) {
 			int variant, bits[4], fpw, thr;
-			if (pow2_row_lookup(ilog2(j.N), dp, &variant, bits, &fpw, &thr)) {
+			uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
+			if ((rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && pow2_row_lookup(ilog2(j.N), dp, &variant, bits, &fpw, &thr)) {
 				b.fastKernel = KERNEL_POW2_ROW; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
 				for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
 			}
@@ -575,7 +641,20 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		out.uploadsPerAxis[j.axisIndex] = 1;
 		return 0;
 	}
-	if (!unit) return 3002; // multi-pass along a strided axis: not yet
+	if (!unit) {
+		// multi-pass along a strided axis: needs a unit-stride companion dimension (others[0]) to tile over
+		if (j.others.empty() || j.others[0].inStride != 1 || j.others[0].outStride != 1) return 3002;
+		std::vector<uint64_t> sps;
+		if (!choose_split(j.N, dp, d.maxLds, dmax, !d.disableFastKernels, sps)) return 3002;
+		std::vector<HostDim> rest(j.others.begin() + 1, j.others.end());
+		uint64_t tempElems = 0;
+		int r = emit_multipass_strided(b, j.N, sps, j.inStrideJ, j.outStrideJ, j.others[0], rest, j.inRole, j.outRole, j.inverse, j.scale, ar, passes, tempElems);
+		if (r) return r;
+		out.uploadsPerAxis[j.axisIndex] = (uint32_t)sps.size();
+		for (size_t i = 0; i < sps.size(); i++) out.axisSplit[j.axisIndex][i] = sps[sps.size() - 1 - i];
+		out.tempBytes = std::max<uint64_t>(out.tempBytes, tempElems * (dp ? 16 : 8));
+		return 0;
+	}
 
 	// ---- Four-Step on a unit-stride axis: N = n0 * M, recursively M = n1 * n2 -------------------------
 	std::vector<uint64_t> sp;
@@ -613,7 +692,7 @@ static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vecto
 	b.opN = (uint32_t)N; b.scale = scale;
 	const bool even = (N % 2 == 0);
 	b.L = even ? N / 2 : N;
-	if (!is_supported_len(b.L, dmax) || b.L > max_row_len(dp, d.maxLds)) return 3003;
+	if (!is_supported_len(b.L, dmax)) return 3003;
 	// rows: combine the real-side and complex-side strides per dim
 	std::vector<HostDim> dims;
 	for (size_t i = 0; i < othersReal.size(); i++) {
@@ -622,6 +701,46 @@ static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vecto
 		if (even) { if (rs % 2) return 3003; rs /= 2; } // real rows viewed as packed complex pairs
 		if (!inverse) { h.inStride = rs; h.outStride = cs; } else { h.inStride = cs; h.outStride = rs; }
 		dims.push_back(h);
+	}
+	if (b.L > max_row_len(dp, d.maxLds)) {
+		// long even rows: multi-pass half-length complex FFT + the pair pass of the even decomposition
+		// (reference: VkFFTPlanR2CMultiUploadDecomposition, vkFFT_Plan_R2C.h:30; kernel vkFFT_R2C_even_decomposition.h:40)
+		if (!even) return 3003;
+		const uint64_t H = N / 2;
+		std::vector<uint64_t> sp;
+		if (!choose_split(H, dp, d.maxLds, dmax, !d.disableFastKernels, sp)) return 3003;
+		PassBuild proto; proto.dp = dp; proto.maxLds = d.maxLds; proto.raderDirectMax = dmax; proto.allowFast = !d.disableFastKernels;
+		// pair pass descriptor (in place on the complex rows)
+		PassPlan pair; memset(&pair.prm, 0, sizeof(pair.prm));
+		{
+			PassParams& q = pair.prm;
+			std::vector<HostDim> cd; for (auto& o : othersCplx) cd.push_back(o);
+			collapse_dims(cd);
+			while (cd.size() < 3) cd.push_back({1, 0, 0});
+			if (cd.size() > 3) return 3003;
+			for (int i = 0; i < 3; i++) { q.dim[i].count = (uint32_t)cd[i].count; q.dim[i].inStride = q.dim[i].outStride = cd[i].inStride; }
+			q.opN = (uint32_t)N; q.fsN = (uint32_t)N; q.scale = 1.0; q.swapIn = inverse ? 1 : 0;
+			uint32_t lo = (ceil_log2(N) + 1) / 2; uint64_t nlo = 1ull << lo, nhi = (N + nlo - 1) / nlo;
+			size_t off = ar.alloc((nlo + nhi) * es);
+			for (uint64_t i = 0; i < nlo; i++) ar.putc(off, i, unit_root(i, N), dp);
+			for (uint64_t i = 0; i < nhi; i++) ar.putc(off, nlo + i, unit_root(i * nlo, N), dp);
+			q.fsLoBits = lo; pair.auxOff = off;
+			q.tilesPerG0 = 1;
+			pair.kernel = KERNEL_R2C_PAIR; pair.dp = dp; pair.inRole = pair.outRole = cplxRole;
+			pair.inElemBytes = pair.outElemBytes = (int)es; pair.threads = 256; pair.label = inverse ? "c2r-pair" : "r2c-pair";
+		}
+		MultiPassIO io;
+		for (auto& h : dims) { io.othersIn.push_back({h.count, h.inStride, h.inStride}); io.othersOut.push_back({h.count, h.outStride, h.outStride}); }
+		io.inRole = inverse ? cplxRole : realRole; io.outRole = inverse ? realRole : cplxRole;
+		io.swapIn = io.swapOut = inverse; io.scale = scale;
+		if (inverse) passes.push_back(pair);
+		int r = emit_multipass(proto, H, sp, io, ar, passes); if (r) return r == 3002 ? 3003 : r;
+		if (!inverse) passes.push_back(pair);
+		uint64_t nsub = 1; for (auto& h : dims) nsub *= h.count;
+		out.tempBytes = std::max<uint64_t>(out.tempBytes, nsub * H * es);
+		out.uploadsPerAxis[0] = (uint32_t)sp.size() + 1;
+		out.axisSplit[0][0] = N; out.bigSequenceEvenR2C = 1;
+		return 0;
 	}
 	b.dims = dims;
 	b.inStrideJ = b.outStrideJ = 1;
