@@ -32,7 +32,15 @@ def test_rader_direct_primes(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 2, False)
 
 
-@pytest.mark.parametrize("N", [67, 127, 251, 1009, 2039, 4093, 15319, 67 * 4])
+@pytest.mark.parametrize("N", [67, 71, 73, 89, 97, 127, 257, 641, 2311, 7681, 67 * 8, 4 * 97 * 3, 67 * 67])
+@pytest.mark.parametrize("dp", [False, True])
+def test_rader_fft_convolution_primes(run, oracle, N, dp):
+    """primes whose P-1 is 13-smooth run as an FFT-convolution Rader stage inside the Stockham pass"""
+    up = parity.check_c2c(run, oracle, (N,), 2, dp, kind="bluestein")
+    assert up == [1] or (dp and N > 4096)  # fp64 rows longer than the one-pass capacity fall back to multi-pass Bluestein
+
+
+@pytest.mark.parametrize("N", [83, 107, 251, 1009, 2039, 4093, 15319, 83 * 4])
 @pytest.mark.parametrize("dp", [False, True])
 def test_bluestein(run, oracle, N, dp):
     parity.check_c2c(run, oracle, (N,), 2, dp, kind="bluestein")

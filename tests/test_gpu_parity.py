@@ -112,7 +112,13 @@ def test_rader_primes(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 8, False)
 
 
-@pytest.mark.parametrize("N", [67, 89, 127, 251, 509, 1021, 2039, 4093, 67 * 8, 15319, 21269, 2000083])
+@pytest.mark.parametrize("N", [67, 71, 73, 79, 89, 97, 101, 113, 127, 257, 641, 769, 2311, 4099 - 2, 7681, 67 * 8, 4 * 97 * 3, 67 * 67, 127 * 64])
+@pytest.mark.parametrize("dp", [False, True])
+def test_rader_fft_convolution_primes(run, oracle, N, dp):
+    parity.check_c2c(run, oracle, (N,), 8, dp, kind="bluestein")
+
+
+@pytest.mark.parametrize("N", [83, 107, 251, 509, 1021, 2039, 4093, 83 * 8, 15319, 21269, 2000083])
 def test_bluestein_fp32(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 4 if N < 100000 else 1, False, kind="bluestein", use_c_oracle=N < 5000)
 

@@ -91,6 +91,20 @@ struct BatchDim {
 	int64_t inStride, outStride;
 };
 
+// FFT-convolution Rader stage (one prime per pass): sub-FFT of length P-1 run over the butterflies as columns
+struct RaderDesc {
+	uint32_t P;          // the prime
+	uint32_t nSub;       // radix stages of the length P-1 sub-FFT
+	StageDesc sub[8];    // lutOff relative to subLutOff
+	uint32_t subLutOff;  // sub-FFT stage twiddles, complex elements from PassParams::lut
+	uint32_t bhatOff;    // FFT(b)/(P-1), b_q = exp(-2 pi i g^-q / P): complex elements from PassParams::lut
+	uint32_t gpowOff;    // uint32 tables (from PassParams::rader): g^q mod P, q < P-1
+	uint32_t ginvOff;    // g^-m mod P, m < P-1
+	uint32_t tailElems;  // extra LDS elements holding x_0 / X_0 of every butterfly
+	FastDiv divU;        // butterflies per workgroup (columns of the sub-FFT)
+	FastDiv divSubNb[8], divSubS[8];
+};
+
 struct PassParams {
 	const void* in;
 	void* out;
@@ -98,6 +112,8 @@ struct PassParams {
 	const void* aux;     // op-specific table (4-step two-level LUT, R2C/DCT twiddles, chirp, ...)
 	const void* aux2;    // second op-specific table (Bluestein FFT(chirp), DCT-IV post twiddles)
 	const void* aux3;    // pre-op table when aux is taken by the Four-Step LUT (multi-pass Bluestein chirp)
+	const void* rader;   // uint32 tables of the FFT-Rader stage
+	RaderDesc rd;
 	uint32_t L;          // sub-FFT length computed by the stages
 	uint32_t nStages;
 	StageDesc st[kMaxStages];

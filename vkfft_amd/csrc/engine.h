@@ -31,7 +31,7 @@ struct PassPlan {
 	size_t ldsBytes = 0;
 	std::vector<HostDim> hostLoop; // outer dims iterated on the host (rare: >3 non-collapsible batch dims)
 	// arena offsets (bytes) of the tables, SIZE_MAX = none
-	size_t lutOff = (size_t)-1, auxOff = (size_t)-1, aux2Off = (size_t)-1, aux3Off = (size_t)-1;
+	size_t lutOff = (size_t)-1, auxOff = (size_t)-1, aux2Off = (size_t)-1, aux3Off = (size_t)-1, raderOff = (size_t)-1;
 	// chunking: this pass's dim index whose range the executor may split ( -1: none )
 	int chunkDim = -1;
 	std::string label;

@@ -271,6 +271,113 @@ __device__ inline void run_stage_direct(const PassParams& p, const StageDesc& sd
 	}
 }
 
+// one radix stage of the Rader sub-FFT: length P1 = P-1 over `U` columns (column = one radix-P butterfly), data laid
+// out [q][u] (u fastest) inside the ping-pong buffers
+template <int R, typename T>
+__device__ inline void run_substage(const PassParams& p, int si, const cx<T>* __restrict__ src, cx<T>* __restrict__ dst, uint32_t U, uint32_t tid, uint32_t nthr) {
+	const StageDesc& sd = p.rd.sub[si];
+	const uint32_t P1 = p.rd.P - 1, nbq = P1 / R, S = sd.S;
+	const cx<T>* lut = (const cx<T>*)p.lut + p.rd.subLutOff + sd.lutOff;
+	const uint32_t total = nbq * U;
+	for (uint32_t v = tid; v < total; v += nthr) {
+		uint32_t tt, u;
+		p.rd.divU.divmod(v, tt, u);
+		uint32_t q, s;
+		if (S == 1) { q = tt; s = 0; }
+		else p.rd.divSubS[si].divmod(tt, q, s);
+		cx<T> x[R];
+#pragma unroll
+		for (int i = 0; i < R; i++) x[i] = src[(tt + i * nbq) * U + u];
+		if (S > 1) {
+#pragma unroll
+			for (int i = 1; i < R; i++) x[i] = cmul(x[i], lut[(i - 1) * S + s]);
+		}
+		dft<R, T>(x);
+		const uint32_t ob = q * S * R + s;
+#pragma unroll
+		for (int k = 0; k < R; k++) dst[(ob + k * S) * U + u] = x[k];
+	}
+}
+template <typename T>
+__device__ inline void run_subfft(const PassParams& p, cx<T>*& cur, cx<T>*& oth, uint32_t U, uint32_t tid, uint32_t nthr) {
+	for (uint32_t si = 0; si < p.rd.nSub; si++) {
+		switch (p.rd.sub[si].radix) {
+			case 2: run_substage<2, T>(p, si, cur, oth, U, tid, nthr); break;
+			case 3: run_substage<3, T>(p, si, cur, oth, U, tid, nthr); break;
+			case 4: run_substage<4, T>(p, si, cur, oth, U, tid, nthr); break;
+			case 5: run_substage<5, T>(p, si, cur, oth, U, tid, nthr); break;
+			case 7: run_substage<7, T>(p, si, cur, oth, U, tid, nthr); break;
+			case 8: run_substage<8, T>(p, si, cur, oth, U, tid, nthr); break;
+			case 11: run_substage<11, T>(p, si, cur, oth, U, tid, nthr); break;
+			case 13: run_substage<13, T>(p, si, cur, oth, U, tid, nthr); break;
+			case 16: run_substage<16, T>(p, si, cur, oth, U, tid, nthr); break;
+			default: break;
+		}
+		__syncthreads();
+		cx<T>* t = cur; cur = oth; oth = t;
+	}
+}
+
+// Rader stage, FFT-convolution form (reference: appendFFTRaderStage, vkFFT_RaderKernels.h:30; tree construction
+// vkFFT_Scheduler.h:1733-1873; kernel precompute vkFFT_RecursiveFFTGenerators.h:996-1048).  For prime radix P with
+// generator g:  X_0 = sum x_i;  X_{g^-m} = x_0 + (a (*) b)_m,  a_q = x_{g^q},  b_q = exp(-2 pi i g^-q / P),
+// the cyclic convolution of length P-1 evaluated as IFFT(FFT(a) . FFT(b)).  All butterflies of the workgroup are
+// convolved together: they are the columns of one batched sub-FFT held in the ping-pong buffers.
+// Returns the buffer that holds the stage's output.
+template <typename T>
+__device__ inline cx<T>* run_stage_rader_fft(const PassParams& p, const StageDesc& sd, int si, cx<T>* A, cx<T>* B, cx<T>* tail, uint32_t tid, uint32_t nthr) {
+	const uint32_t P = sd.radix, P1 = P - 1;
+	const uint32_t nb = p.L / P, S = sd.S;
+	const uint32_t U = nb << p.logT; // butterflies (columns)
+	const uint32_t Tp = p.Tp, ps = p.padShift;
+	const cx<T>* lut = (const cx<T>*)p.lut + sd.lutOff;
+	const cx<T>* bhat = (const cx<T>*)p.lut + p.rd.bhatOff;
+	const uint32_t* gpow = (const uint32_t*)p.rader + p.rd.gpowOff;
+	const uint32_t* ginv = (const uint32_t*)p.rader + p.rd.ginvOff;
+	// (1) gather a_q = x_{g^q} * twiddle into B[q][u], x_0 into the tail
+	for (uint32_t v = tid; v < P1 * U; v += nthr) {
+		uint32_t q, u;
+		p.rd.divU.divmod(v, q, u);
+		const uint32_t f = u & (p.T - 1), t = u >> p.logT;
+		const uint32_t i = gpow[q];
+		const uint32_t a = t + i * nb;
+		cx<T> x = A[(a + (a >> ps)) * Tp + f];
+		if (S > 1) { uint32_t qq, s; p.divS[si].divmod(t, qq, s); x = cmul(x, lut[(i - 1) * S + s]); }
+		B[q * U + u] = x;
+		if (q == 0) tail[u] = A[(t + (t >> ps)) * Tp + f];
+	}
+	__syncthreads();
+	cx<T>* cur = B; cx<T>* oth = A;
+	run_subfft<T>(p, cur, oth, U, tid, nthr);
+	// (2) pointwise product with FFT(b)/(P-1); x_0 enters the zero bin so that every convolution output carries it;
+	//     X_0 = x_0 + A_0 replaces x_0 in the tail.  Result is swapped for the inverse transform (swap identity).
+	for (uint32_t v = tid; v < P1 * U; v += nthr) {
+		uint32_t m, u;
+		p.rd.divU.divmod(v, m, u);
+		cx<T> a = cur[m * U + u];
+		cx<T> c = cmul(a, bhat[m]);
+		if (m == 0) { const cx<T> x0 = tail[u]; tail[u] = cadd(x0, a); c = cadd(c, x0); }
+		cur[m * U + u] = cswap(c);
+	}
+	__syncthreads();
+	run_subfft<T>(p, cur, oth, U, tid, nthr);
+	// (3) scatter X_{g^-m} = conv_m (+x_0 already inside) and X_0 to the Stockham output positions in the other buffer
+	for (uint32_t v = tid; v < P * U; v += nthr) {
+		uint32_t kk, u;
+		p.rd.divU.divmod(v, kk, u); // kk = 0: X_0, else m = kk-1
+		const uint32_t f = u & (p.T - 1), t = u >> p.logT;
+		uint32_t qq, s;
+		if (S == 1) { qq = t; s = 0; } else p.divS[si].divmod(t, qq, s);
+		cx<T> val; uint32_t k;
+		if (kk == 0) { val = tail[u]; k = 0; }
+		else { val = cswap(cur[(kk - 1) * U + u]); k = ginv[kk - 1]; }
+		const uint32_t a = qq * S * P + s + k * S;
+		oth[(a + (a >> ps)) * Tp + f] = val;
+	}
+	__syncthreads();
+	return oth;
+}
+
 template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kernel(const PassParams p) {
 	VKFFT_DYN_SMEM(smem_raw)
 	cx<T>* bufA = (cx<T>*)smem_raw;
@@ -310,6 +417,12 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 	for (int rep = 0; rep < reps; rep++) {
 		for (uint32_t si = 0; si < p.nStages; si++) {
 			const StageDesc& sd = p.st[si];
+			if (sd.kind == 2) {
+				cx<T>* res = run_stage_rader_fft<T>(p, sd, si, src, dst, bufA + 2 * (size_t)p.ldsElems, tid, nthr);
+				cx<T>* other = (res == dst) ? src : dst;
+				src = res; dst = other; // the next stage reads the buffer the Rader stage finished in
+				continue;
+			}
 			if (sd.kind == 1) run_stage_direct<T>(p, sd, si, src, dst, tid, nthr);
 			else switch (sd.radix) {
 				case 2: run_stage<2, T>(p, sd, si, src, dst, tid, nthr); break;

@@ -79,8 +79,27 @@ static std::vector<uint32_t> radix_schedule(uint64_t L) {
 	return rad;
 }
 
+static bool smooth13(uint64_t n) {
+	for (uint64_t q : {2, 3, 5, 7, 11, 13}) while (n % q == 0) n /= q;
+	return n == 1;
+}
+static bool is_prime_u(uint64_t n) { if (n < 2) return false; for (uint64_t d = 2; d * d <= n; d++) if (n % d == 0) return false; return true; }
+// FFT-convolution Rader is available for primes whose P-1 is {2..13}-smooth (reference: VkFFTConstructRaderTree,
+// vkFFT_Scheduler.h:1764-1777) and small enough to sit in LDS beside the data
+static bool rader_fft_ok(uint64_t p) { return p > 16 && p <= 8191 && is_prime_u(p) && smooth13(p - 1); }
+static uint64_t powmod(uint64_t b, uint64_t e, uint64_t m) { uint64_t r = 1; b %= m; while (e) { if (e & 1) r = r * b % m; b = b * b % m; e >>= 1; } return r; }
+static uint64_t primitive_root(uint64_t p) { // brute force as the reference does (vkFFT_Scheduler.h:1818-1831)
+	std::vector<uint64_t> pf; uint64_t n = p - 1;
+	for (uint64_t q = 2; q * q <= n; q++) if (n % q == 0) { pf.push_back(q); while (n % q == 0) n /= q; }
+	if (n > 1) pf.push_back(n);
+	for (uint64_t g = 2; g < p; g++) { bool ok = true; for (uint64_t q : pf) if (powmod(g, (p - 1) / q, p) == 1) { ok = false; break; } if (ok) return g; }
+	return 0;
+}
+
 static uint32_t ilog2(uint64_t v) { uint32_t l = 0; while ((1ull << (l + 1)) <= v) l++; return l; }
 static uint32_t ceil_log2(uint64_t v) { uint32_t l = 0; while ((1ull << l) < v) l++; return l; }
+
+static void host_fft(std::vector<cld>& a);
 
 struct PassBuild {
 	uint64_t L = 0;
@@ -154,22 +173,38 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	if (b.L == 1) rad.clear();
 	if (rad.size() > (size_t)kMaxStages) return 3002;
 	p.nStages = (uint32_t)rad.size();
-	// stage twiddles
+	// stage twiddles (+ the tables of an FFT-Rader stage)
 	uint64_t lutElems = 0, S = 1;
-	for (uint32_t R : rad) { if (S > 1) lutElems += (uint64_t)(R - 1) * S; if (R > 16) lutElems += R; S *= R; }
+	uint32_t raderP = 0;
+	for (uint32_t R : rad) {
+		if (S > 1) lutElems += (uint64_t)(R - 1) * S;
+		if (R > 16 && R <= b.raderDirectMax) lutElems += R;
+		if (R > 16 && R > b.raderDirectMax) raderP = R;
+		S *= R;
+	}
+	std::vector<uint32_t> subRad;
+	uint64_t subLutElems = 0;
+	if (raderP) {
+		if (!rader_fft_ok(raderP)) return 3002;
+		subRad = radix_schedule(raderP - 1);
+		if (subRad.size() > 8) return 3002;
+		uint64_t S2 = 1;
+		for (uint32_t R : subRad) { if (S2 > 1) subLutElems += (uint64_t)(R - 1) * S2; S2 *= R; }
+		lutElems += subLutElems + (raderP - 1);
+	}
 	size_t lutOff = ar.alloc((lutElems + 1) * es);
 	uint64_t cur = 0; S = 1;
 	for (size_t si = 0; si < rad.size(); si++) {
 		uint32_t R = rad[si];
 		StageDesc& sd = p.st[si];
-		sd.radix = R; sd.S = (uint32_t)S; sd.lutOff = (uint32_t)cur; sd.kind = R > 16 ? 1 : 0;
-		if (R > 16 && R > b.raderDirectMax) return 3002;
+		sd.radix = R; sd.S = (uint32_t)S; sd.lutOff = (uint32_t)cur;
+		sd.kind = R <= 16 ? 0 : (R <= b.raderDirectMax ? 1 : 2);
 		if (S > 1) {
 			for (uint32_t i = 1; i < R; i++)
 				for (uint64_t s = 0; s < S; s++) ar.putc(lutOff, cur + (uint64_t)(i - 1) * S + s, unit_root((uint64_t)i * s, (uint64_t)R * S), dp);
 			cur += (uint64_t)(R - 1) * S;
 		}
-		if (R > 16) {
+		if (sd.kind == 1) {
 			sd.aux0 = (uint32_t)cur;
 			for (uint32_t m = 0; m < R; m++) ar.putc(lutOff, cur + m, unit_root(m, R), dp);
 			cur += R;
@@ -177,6 +212,39 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		p.divNb[si] = make_fastdiv((uint32_t)(b.L / R));
 		p.divS[si] = make_fastdiv((uint32_t)S);
 		S *= R;
+	}
+	if (raderP) {
+		RaderDesc& rd = p.rd;
+		const uint32_t P = raderP, P1 = P - 1;
+		rd.P = P; rd.nSub = (uint32_t)subRad.size();
+		rd.subLutOff = (uint32_t)cur;
+		uint64_t c2 = 0, S2 = 1;
+		for (size_t si = 0; si < subRad.size(); si++) {
+			uint32_t R = subRad[si];
+			rd.sub[si].radix = R; rd.sub[si].S = (uint32_t)S2; rd.sub[si].lutOff = (uint32_t)c2; rd.sub[si].kind = 0;
+			if (S2 > 1) {
+				for (uint32_t i = 1; i < R; i++)
+					for (uint64_t s = 0; s < S2; s++) ar.putc(lutOff, cur + c2 + (uint64_t)(i - 1) * S2 + s, unit_root((uint64_t)i * s, (uint64_t)R * S2), dp);
+				c2 += (uint64_t)(R - 1) * S2;
+			}
+			rd.divSubNb[si] = make_fastdiv(P1 / R);
+			rd.divSubS[si] = make_fastdiv((uint32_t)S2);
+			S2 *= R;
+		}
+		cur += subLutElems;
+		// generator tables and FFT of the convolution kernel b_q = exp(-2 pi i g^-q / P)  (RecursiveFFTGenerators.h:1021-1048)
+		const uint64_t g = primitive_root(P), gi = powmod(g, P - 2, P);
+		size_t tabOff = ar.alloc(2 * (size_t)P1 * sizeof(uint32_t));
+		uint32_t* tab = (uint32_t*)(ar.b.data() + tabOff);
+		std::vector<cld> bk(P1);
+		uint64_t gp = 1, gm = 1;
+		for (uint32_t q = 0; q < P1; q++) { tab[q] = (uint32_t)gp; tab[P1 + q] = (uint32_t)gm; bk[q] = unit_root(gm, P); gp = gp * g % P; gm = gm * gi % P; }
+		host_fft(bk);
+		rd.bhatOff = (uint32_t)cur;
+		for (uint32_t m = 0; m < P1; m++) ar.putc(lutOff, cur + m, bk[m] / (ld)P1, dp);
+		cur += P1;
+		rd.gpowOff = 0; rd.ginvOff = P1;
+		pp.raderOff = tabOff;
 	}
 	pp.lutOff = lutOff;
 	pp.auxOff = b.auxOff; pp.aux2Off = b.aux2Off; pp.aux3Off = b.auxOff2ForPre;
@@ -243,7 +311,8 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	const uint64_t padded = p.padShift >= 31 ? b.L : b.L + (b.L >> p.padShift);
 	p.ldsElems = (uint32_t)((padded + 1) * p.Tp);
 	p.tilesPerG0 = (uint32_t)((dims[0].count + T - 1) / T);
-	pp.ldsBytes = 2 * (size_t)p.ldsElems * es;
+	if (p.rd.P) { p.rd.tailElems = (uint32_t)((b.L / p.rd.P) * T + 1); p.rd.divU = make_fastdiv((uint32_t)((b.L / p.rd.P) * T)); }
+	pp.ldsBytes = (2 * (size_t)p.ldsElems + p.rd.tailElems) * es;
 	if (pp.ldsBytes > b.maxLds && b.fastKernel == KERNEL_GENERIC) return 3002;
 	// threads: about one radix-8 butterfly per thread per stage
 	uint64_t work = (uint64_t)T * b.L / 8;
@@ -290,7 +359,12 @@ static uint64_t max_col_len(bool dp, uint64_t maxLds, uint32_t T) {
 
 static bool is_supported_len(uint64_t L, uint32_t directMax) {
 	std::vector<uint32_t> pf = factorize_radices(L, nullptr);
-	for (uint32_t p : pf) if (p > 13 && p > directMax) return false;
+	uint32_t fftPrime = 0;
+	for (uint32_t p : pf) if (p > 13 && p > directMax) {
+		if (!rader_fft_ok(p)) return false;
+		if (fftPrime && fftPrime != p) return false; // one FFT-Rader prime per pass
+		fftPrime = p;
+	}
 	return true;
 }
 
@@ -542,6 +616,12 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	b.inRole = j.inRole; b.outRole = j.outRole;
 	out.axisSplit[j.axisIndex][0] = j.N;
 
+	{ // a supported length that neither fits one pass nor splits into supported factors (large Rader primes) also goes to Bluestein
+		const uint64_t cap1 = unit ? rowCap : max_col_len(dp, d.maxLds, 1);
+		const bool fastRow = unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N <= (dp ? 8192u : 16384u);
+		std::vector<uint64_t> probe;
+		if (smoothOK && j.N > cap1 && !fastRow && !choose_split(j.N, dp, d.maxLds, dmax, !d.disableFastKernels, probe)) smoothOK = false;
+	}
 	if (!smoothOK) {
 		// Bluestein (chirp-z) through a padded smooth length M >= 2N-1
 		const uint64_t N = j.N;
