@@ -1,5 +1,5 @@
 // In-register forward DFT butterflies (sign -), natural-order in, natural-order out.
-// Radix set of the reference's Stockham stages (vkFFT_RadixKernels.h:43-2747): 2,3,4,5,7,8,11,13 (+16,
+// Radix set of the reference's Stockham stages (vkFFT_RadixKernels.h:43-2747): 2,3,4,5,7,8,11,13 (+16, 32,
 // which the reference also builds from radix-2 layers).  The inverse direction never needs its own
 // butterflies: the kernels use IFFT(x) = swap(FFT(swap(x))).
 //
@@ -30,16 +30,12 @@ __host__ __device__ constexpr double prime_sin(int P, int i) {
 	return 0.0;
 }
 
-// cos/sin(2*pi*k/16), k = 0..7  (w16^k = c - i s)
-__host__ __device__ constexpr double pow2_cos16(int k) {
-	return k == 0 ? 1.0 : k == 1 ? 9.23879532511286756128183189396788e-01 : k == 2 ? 7.07106781186547524400844362104849e-01
-	     : k == 3 ? 3.82683432365089771728459984030399e-01 : k == 4 ? 0.0 : k == 5 ? -3.82683432365089771728459984030399e-01
-	     : k == 6 ? -7.07106781186547524400844362104849e-01 : -9.23879532511286756128183189396788e-01;
+// cos/sin(2*pi*k/32), k = 0..15  (w32^k = c - i s)
+__host__ __device__ constexpr double pow2_cos32(int k) {
+	return k == 0 ? 1.00000000000000000000e+00 : k == 1 ? 9.80785280403230430579e-01 : k == 2 ? 9.23879532511286738483e-01 : k == 3 ? 8.31469612302545235671e-01 : k == 4 ? 7.07106781186547572737e-01 : k == 5 ? 5.55570233019602288671e-01 : k == 6 ? 3.82683432365089837290e-01 : k == 7 ? 1.95090322016128331351e-01 : k == 8 ? 6.12323399573676603587e-17 : k == 9 ? -1.95090322016128192573e-01 : k == 10 ? -3.82683432365089726268e-01 : k == 11 ? -5.55570233019601955604e-01 : k == 12 ? -7.07106781186547461715e-01 : k == 13 ? -8.31469612302545346694e-01 : k == 14 ? -9.23879532511286738483e-01 : -9.80785280403230430579e-01;
 }
-__host__ __device__ constexpr double pow2_sin16(int k) {
-	return k == 0 ? 0.0 : k == 1 ? 3.82683432365089771728459984030399e-01 : k == 2 ? 7.07106781186547524400844362104849e-01
-	     : k == 3 ? 9.23879532511286756128183189396788e-01 : k == 4 ? 1.0 : k == 5 ? 9.23879532511286756128183189396788e-01
-	     : k == 6 ? 7.07106781186547524400844362104849e-01 : 3.82683432365089771728459984030399e-01;
+__host__ __device__ constexpr double pow2_sin32(int k) {
+	return k == 0 ? 0.00000000000000000000e+00 : k == 1 ? 1.95090322016128248084e-01 : k == 2 ? 3.82683432365089781779e-01 : k == 3 ? 5.55570233019602177649e-01 : k == 4 ? 7.07106781186547461715e-01 : k == 5 ? 8.31469612302545235671e-01 : k == 6 ? 9.23879532511286738483e-01 : k == 7 ? 9.80785280403230430579e-01 : k == 8 ? 1.00000000000000000000e+00 : k == 9 ? 9.80785280403230430579e-01 : k == 10 ? 9.23879532511286738483e-01 : k == 11 ? 8.31469612302545457716e-01 : k == 12 ? 7.07106781186547572737e-01 : k == 13 ? 5.55570233019602177649e-01 : k == 14 ? 3.82683432365089892802e-01 : 1.95090322016128608906e-01;
 }
 
 // ---- power-of-two radices -----------------------------------------------------------------------------
@@ -54,13 +50,13 @@ template <int R, typename T> struct DftPow2 {
 		DftPow2<H, T>::run(o);
 #pragma unroll
 		for (int k = 0; k < H; k++) {
-			constexpr int step = 16 / R; // index into the w16 table
+			constexpr int step = 32 / R; // index into the w32 table
 			cx<T> w;
 			const int kk = k * step;
 			cx<T> t;
 			if (kk == 0) t = o[k];
-			else if (kk == 4) t = cmul_mi(o[k]);
-			else { w.x = (T)pow2_cos16(kk); w.y = (T)(-pow2_sin16(kk)); t = cmul(o[k], w); }
+			else if (kk == 8) t = cmul_mi(o[k]);
+			else { w.x = (T)pow2_cos32(kk); w.y = (T)(-pow2_sin32(kk)); t = cmul(o[k], w); }
 			v[k] = cadd(e[k], t);
 			v[k + H] = csub(e[k], t);
 		}
@@ -120,7 +116,7 @@ template <int P, typename T> struct DftPrime {
 
 template <int R, typename T> __host__ __device__ inline void dft(cx<T>* v) {
 	if constexpr (R == 1) { }
-	else if constexpr (R == 2 || R == 4 || R == 8 || R == 16) DftPow2<R, T>::run(v);
+	else if constexpr (R == 2 || R == 4 || R == 8 || R == 16 || R == 32) DftPow2<R, T>::run(v);
 	else DftPrime<R, T>::run(v);
 }
 

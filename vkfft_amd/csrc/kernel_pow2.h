@@ -299,13 +299,13 @@ static const Pow2Variant kPow2Variants[] = {
 	VKFFT_P2(float, false, 3, 2, 0, 0, 32),
 	VKFFT_P2(float, false, 3, 3, 0, 0, 32),
 	VKFFT_P2(float, false, 4, 3, 0, 0, 16), VKFFT_P2(float, false, 3, 2, 2, 0, 16),
-	VKFFT_P2(float, false, 3, 3, 2, 0, 8), VKFFT_P2(float, false, 4, 4, 0, 0, 16), VKFFT_P2(float, false, 4, 4, 0, 0, 8), VKFFT_P2(float, false, 3, 3, 2, 0, 4),
-	VKFFT_P2(float, false, 3, 3, 3, 0, 4), VKFFT_P2(float, false, 4, 3, 2, 0, 8), VKFFT_P2(float, false, 4, 3, 2, 0, 4), VKFFT_P2(float, false, 3, 3, 3, 0, 2),
-	VKFFT_P2(float, false, 4, 3, 3, 0, 4), VKFFT_P2(float, false, 4, 3, 3, 0, 2), VKFFT_P2(float, false, 4, 4, 2, 0, 4), VKFFT_P2(float, false, 3, 3, 2, 2, 2),
-	VKFFT_P2(float, false, 4, 4, 3, 0, 2), VKFFT_P2(float, false, 4, 4, 3, 0, 1), VKFFT_P2(float, false, 3, 3, 3, 2, 1), VKFFT_P2(float, false, 4, 4, 3, 0, 4),
-	VKFFT_P2(float, false, 4, 4, 4, 0, 1), VKFFT_P2(float, false, 3, 3, 3, 3, 1), VKFFT_P2(float, false, 4, 4, 4, 0, 2),
-	VKFFT_P2(float, false, 4, 3, 3, 3, 1), VKFFT_P2(float, false, 4, 4, 4, 1, 1),
-	VKFFT_P2(float, false, 4, 4, 3, 3, 1), VKFFT_P2(float, false, 4, 4, 4, 2, 1),
+	VKFFT_P2(float, false, 4, 4, 0, 0, 8), VKFFT_P2(float, false, 4, 4, 0, 0, 16), VKFFT_P2(float, false, 3, 3, 2, 0, 8), VKFFT_P2(float, false, 3, 3, 2, 0, 4),
+	VKFFT_P2(float, false, 5, 4, 0, 0, 8), VKFFT_P2(float, false, 4, 3, 2, 0, 8), VKFFT_P2(float, false, 3, 3, 3, 0, 4), VKFFT_P2(float, false, 4, 3, 2, 0, 4), VKFFT_P2(float, false, 5, 4, 0, 0, 4),
+	VKFFT_P2(float, false, 5, 5, 0, 0, 8), VKFFT_P2(float, false, 4, 3, 3, 0, 4), VKFFT_P2(float, false, 4, 3, 3, 0, 2), VKFFT_P2(float, false, 5, 5, 0, 0, 4), VKFFT_P2(float, false, 5, 5, 0, 0, 2),
+	VKFFT_P2(float, false, 5, 5, 1, 0, 2), VKFFT_P2(float, false, 4, 4, 3, 0, 1), VKFFT_P2(float, false, 4, 4, 3, 0, 2), VKFFT_P2(float, false, 5, 5, 1, 0, 4), VKFFT_P2(float, false, 4, 4, 3, 0, 4),
+	VKFFT_P2(float, false, 4, 4, 4, 0, 1), VKFFT_P2(float, false, 5, 5, 2, 0, 1), VKFFT_P2(float, false, 4, 4, 4, 0, 2), VKFFT_P2(float, false, 5, 5, 2, 0, 2),
+	VKFFT_P2(float, false, 5, 4, 4, 0, 1), VKFFT_P2(float, false, 4, 3, 3, 3, 1), VKFFT_P2(float, false, 5, 5, 3, 0, 1),
+	VKFFT_P2(float, false, 5, 5, 4, 0, 1), VKFFT_P2(float, false, 4, 4, 3, 3, 1), VKFFT_P2(float, false, 4, 4, 4, 2, 1),
 	// fp64
 	VKFFT_P2(double, true, 2, 0, 0, 0, 64),
 	VKFFT_P2(double, true, 3, 0, 0, 0, 64),
@@ -328,9 +328,9 @@ static const Pow2Variant kPow2ColVariants[] = {
 	VKFFT_P2C(float, false, 3, 2, 0, 0, 32), VKFFT_P2C(float, false, 3, 2, 0, 0, 16),
 	VKFFT_P2C(float, false, 3, 3, 0, 0, 32), VKFFT_P2C(float, false, 3, 3, 0, 0, 16),
 	VKFFT_P2C(float, false, 4, 3, 0, 0, 32), VKFFT_P2C(float, false, 4, 3, 0, 0, 16), VKFFT_P2C(float, false, 3, 2, 2, 0, 32),
-	VKFFT_P2C(float, false, 4, 4, 0, 0, 32), VKFFT_P2C(float, false, 4, 4, 0, 0, 16), VKFFT_P2C(float, false, 3, 3, 2, 0, 32), VKFFT_P2C(float, false, 3, 3, 2, 0, 16),
-	VKFFT_P2C(float, false, 4, 3, 2, 0, 16), VKFFT_P2C(float, false, 4, 3, 2, 0, 32), VKFFT_P2C(float, false, 3, 3, 3, 0, 16),
-	VKFFT_P2C(float, false, 4, 3, 3, 0, 16), VKFFT_P2C(float, false, 4, 3, 3, 0, 8),
+	VKFFT_P2C(float, false, 4, 4, 0, 0, 32), VKFFT_P2C(float, false, 4, 4, 0, 0, 16), VKFFT_P2C(float, false, 3, 3, 2, 0, 32), VKFFT_P2C(float, false, 3, 3, 2, 0, 16), VKFFT_P2C(float, false, 5, 3, 0, 0, 32),
+	VKFFT_P2C(float, false, 5, 4, 0, 0, 32), VKFFT_P2C(float, false, 4, 3, 2, 0, 16), VKFFT_P2C(float, false, 4, 3, 2, 0, 32), VKFFT_P2C(float, false, 3, 3, 3, 0, 16), VKFFT_P2C(float, false, 5, 4, 0, 0, 16),
+	VKFFT_P2C(float, false, 5, 5, 0, 0, 16), VKFFT_P2C(float, false, 4, 3, 3, 0, 16), VKFFT_P2C(float, false, 4, 3, 3, 0, 8),
 	VKFFT_P2C(double, true, 2, 2, 0, 0, 16),
 	VKFFT_P2C(double, true, 3, 2, 0, 0, 16),
 	VKFFT_P2C(double, true, 3, 3, 0, 0, 16),

@@ -178,8 +178,8 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	uint32_t raderP = 0;
 	for (uint32_t R : rad) {
 		if (S > 1) lutElems += (uint64_t)(R - 1) * S;
-		if (R > 16 && R <= b.raderDirectMax) lutElems += R;
-		if (R > 16 && R > b.raderDirectMax) raderP = R;
+		if (R > 16 && R != 32 && R <= b.raderDirectMax) lutElems += R;
+		if (R > 16 && R != 32 && R > b.raderDirectMax) raderP = R;
 		S *= R;
 	}
 	std::vector<uint32_t> subRad;
@@ -198,7 +198,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		uint32_t R = rad[si];
 		StageDesc& sd = p.st[si];
 		sd.radix = R; sd.S = (uint32_t)S; sd.lutOff = (uint32_t)cur;
-		sd.kind = R <= 16 ? 0 : (R <= b.raderDirectMax ? 1 : 2);
+		sd.kind = (R <= 16 || R == 32) ? 0 : (R <= b.raderDirectMax ? 1 : 2);
 		if (S > 1) {
 			for (uint32_t i = 1; i < R; i++)
 				for (uint64_t s = 0; s < S; s++) ar.putc(lutOff, cur + (uint64_t)(i - 1) * S + s, unit_root((uint64_t)i * s, (uint64_t)R * S), dp);
