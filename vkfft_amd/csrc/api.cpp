@@ -11,6 +11,7 @@
 #include <cstring>
 #include <cstdio>
 #include <new>
+#include <algorithm>
 
 using namespace vkfft_mi355x;
 
@@ -21,6 +22,7 @@ struct AppState {
 	uint64_t tempOwnedBytes = 0;
 	hipEvent_t* events = nullptr;
 	uint32_t numEvents = 0;
+	ExecStreams xs;                // helper streams for chunk-pipelined multi-pass plans
 };
 
 VkFFTResult hip_to_result(hipError_t e, VkFFTResult code) { return e == hipSuccess ? VKFFT_SUCCESS : code; }
@@ -83,6 +85,8 @@ VKFFT_API void deleteVkFFT(VkFFTApplication* app) {
 			for (uint32_t i = 0; i < st->numEvents; i++) if (st->events[i]) (void)hipEventDestroy(st->events[i]);
 			free(st->events);
 		}
+		for (int i = 0; i < st->xs.nAux; i++) { if (st->xs.aux[i]) (void)hipStreamDestroy(st->xs.aux[i]); if (st->xs.join[i]) (void)hipEventDestroy(st->xs.join[i]); }
+		if (st->xs.fork) (void)hipEventDestroy(st->xs.fork);
 		delete st;
 	}
 	free_direction(app->localFFTPlan);
@@ -200,6 +204,7 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 	if (c.fixMaxRaderPrimeMult) d.raderMultMax = c.fixMaxRaderPrimeMult;
 	if (c.userTempBuffer && c.tempBufferSize) d.userTempBytes = c.tempBufferSize[0];
 	if (const char* e = getenv("VKFFT_MI355X_CHUNK_MIB")) d.chunkTargetBytes = (uint64_t)atoll(e) << 20;
+	if (const char* e = getenv("VKFFT_MI355X_CHUNK_STREAMS")) d.chunkStreams = (uint32_t)atoi(e);
 	if (const char* e = getenv("VKFFT_MI355X_GENERIC_ONLY")) d.disableFastKernels = atoi(e) != 0;
 
 	AppState* st = new (std::nothrow) AppState();
@@ -223,6 +228,20 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 		if (hipMalloc(&st->tempOwned, need) != hipSuccess) { deleteVkFFT(app); return VKFFT_ERROR_FAILED_TO_ALLOCATE; }
 		st->tempOwnedBytes = need;
 		c.allocateTempBuffer = 1;
+	}
+	// ---- helper streams of chunk-pipelined plans ---------------------------------------------------------------
+	{
+		uint32_t want = 1;
+		if (app->localFFTPlan) want = std::max(want, ((DirectionPlan*)app->localFFTPlan->impl)->chunkBatch ? ((DirectionPlan*)app->localFFTPlan->impl)->chunkStreams : 1u);
+		if (app->localFFTPlan_inverse) want = std::max(want, ((DirectionPlan*)app->localFFTPlan_inverse->impl)->chunkBatch ? ((DirectionPlan*)app->localFFTPlan_inverse->impl)->chunkStreams : 1u);
+		if (want > 1) {
+			if (hipEventCreateWithFlags(&st->xs.fork, hipEventDisableTiming) != hipSuccess) { deleteVkFFT(app); return VKFFT_ERROR_FAILED_TO_CREATE_EVENT; }
+			for (uint32_t i = 0; i + 1 < want && i < 3; i++) {
+				if (hipStreamCreateWithFlags(&st->xs.aux[i], hipStreamNonBlocking) != hipSuccess) { deleteVkFFT(app); return VKFFT_ERROR_FAILED_TO_CREATE_COMMAND_QUEUE; }
+				st->xs.nAux = (int)i + 1;
+				if (hipEventCreateWithFlags(&st->xs.join[i], hipEventDisableTiming) != hipSuccess) { deleteVkFFT(app); return VKFFT_ERROR_FAILED_TO_CREATE_EVENT; }
+			}
+		}
 	}
 	// ---- multi-stream events ------------------------------------------------------------------------------
 	if (c.num_streams > 1 && c.stream) {
@@ -276,7 +295,7 @@ VKFFT_API VkFFTResult VkFFTAppend(VkFFTApplication* app, int inverse, VkFFTLaunc
 	}
 	hipStream_t stream = 0;
 	if (c.stream && c.num_streams >= 1) stream = c.stream[0];
-	int r = execute_direction(*dp, lb, stream);
+	int r = execute_direction(*dp, lb, stream, &st->xs);
 	if (r) { fprintf(stderr, "vkfft_mi355x: kernel launch failed\n"); return (VkFFTResult)r; }
 	return VKFFT_SUCCESS;
 }

@@ -46,7 +46,8 @@ struct DirectionPlan {
 	// intermediate stays resident in the 256 MiB Infinity Cache between passes
 	int chunkFirst = -1, chunkLast = -1;
 	uint64_t chunkBatch = 0, totalBatch = 0;
-	uint64_t chunkTempStrideBytes = 0;
+	uint64_t chunkTempStrideBytes = 0; // scratch slice per concurrently running chunk
+	uint32_t chunkStreams = 1;         // chunks in flight (stream-level pipelining)
 	uint32_t uploadsPerAxis[4] = {0, 0, 0, 0};
 	uint32_t bigSequenceEvenR2C = 0;
 	uint64_t axisSplit[4][4] = {};
@@ -76,6 +77,7 @@ struct TransformDesc {
 	uint64_t userTempBytes = 0;  // >0: temp supplied by the caller with this size
 	uint64_t chunkTargetBytes = 0; // working-set target of the Infinity-Cache chunking (0 = off: measured slower on MI355X)
 	bool disableFastKernels = false;
+	uint32_t chunkStreams = 2;
 };
 
 // returns 0 or a VkFFTResult code
@@ -86,7 +88,13 @@ struct LaunchBuffers {
 	void* base[4] = {nullptr, nullptr, nullptr, nullptr}; // by BufRole
 };
 int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
-int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream);
+// optional helper streams for chunk-pipelined execution (created by the API layer, owned by the application)
+struct ExecStreams {
+	int nAux = 0;
+	hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+	hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+};
+int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream, const ExecStreams* xs = nullptr);
 
 // fast-kernel registry queries used by the planner
 bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads);

@@ -1041,7 +1041,10 @@ int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
 		if (cb < d.batch) {
 			out.chunkFirst = 0; out.chunkLast = (int)out.passes.size() - 1;
 			out.chunkBatch = cb; out.totalBatch = d.batch;
-			if (!d.userTempBytes) out.tempBytes = cb * perFFT;
+			out.chunkStreams = std::max<uint32_t>(1, std::min<uint32_t>(d.chunkStreams, 4));
+			out.chunkTempStrideBytes = cb * perFFT;
+			if (!d.userTempBytes) out.tempBytes = out.chunkStreams * cb * perFFT;
+			else if (d.userTempBytes < out.chunkStreams * cb * perFFT) out.chunkStreams = 1;
 		}
 	}
 	if (d.userTempBytes && out.tempBytes > d.userTempBytes) return 2016;
