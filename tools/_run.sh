@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-VKFFT_MI355X_CHUNK_MIB=128 timeout 300 python tools/gpu_check.py > gpurun_out/check8.log 2>&1; tail -1 gpurun_out/check8.log; grep -E "BAD|EXC" gpurun_out/check8.log | head -5
-for k in 16 18 20 22; do
-python tools/tune.py $k "VKFFT_MI355X_CHUNK_MIB=0" "VKFFT_MI355X_CHUNK_MIB=64 VKFFT_MI355X_CHUNK_STREAMS=1" "VKFFT_MI355X_CHUNK_MIB=64 VKFFT_MI355X_CHUNK_STREAMS=2" "VKFFT_MI355X_CHUNK_MIB=128 VKFFT_MI355X_CHUNK_STREAMS=2" "VKFFT_MI355X_CHUNK_MIB=64 VKFFT_MI355X_CHUNK_STREAMS=3" "VKFFT_MI355X_CHUNK_MIB=32 VKFFT_MI355X_CHUNK_STREAMS=4" "VKFFT_MI355X_CHUNK_MIB=96 VKFFT_MI355X_CHUNK_STREAMS=2"
-done
+timeout 300 python tools/gpu_check.py > gpurun_out/check9.log 2>&1; tail -1 gpurun_out/check9.log; grep -E "BAD|EXC" gpurun_out/check9.log | head -5
+timeout 300 python tools/gpu_check.py real > gpurun_out/check9r.log 2>&1; tail -1 gpurun_out/check9r.log; grep -E "BAD|EXC" gpurun_out/check9r.log | head -5
+NO_REF=1 timeout 600 python tools/perf_configs.py 2>&1 | grep "^{"

@@ -22,6 +22,14 @@ template <typename T> inline void gb_store(GBuf b, uint32_t voff, uint32_t soff,
 	if (voff >= kGbRange) return;
 	*(cx<T>*)(b.base + (uint64_t)voff + soff) = v;
 }
+template <typename T> inline T gb_load_real(GBuf b, uint32_t voff, uint32_t soff) {
+	if (voff >= kGbRange) return (T)0;
+	return *(const T*)(b.base + (uint64_t)voff + soff);
+}
+template <typename T> inline void gb_store_real(GBuf b, uint32_t voff, uint32_t soff, T v) {
+	if (voff >= kGbRange) return;
+	*(T*)(b.base + (uint64_t)voff + soff) = v;
+}
 #else
 typedef unsigned int vk_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int vk_u32x4 __attribute__((ext_vector_type(4)));
@@ -47,6 +55,22 @@ template <> __device__ inline cx<double> gb_load<double>(GBuf b, uint32_t voff, 
 template <typename T> __device__ inline void gb_store(GBuf b, uint32_t voff, uint32_t soff, cx<T> v);
 template <> __device__ inline void gb_store<float>(GBuf b, uint32_t voff, uint32_t soff, cx<float> v) {
 	vk_u32x2 t; t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
+	__builtin_amdgcn_raw_buffer_store_b64(t, b.r, voff, soff, 0);
+}
+template <typename T> __device__ inline T gb_load_real(GBuf b, uint32_t voff, uint32_t soff);
+template <> __device__ inline float gb_load_real<float>(GBuf b, uint32_t voff, uint32_t soff) {
+	return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0));
+}
+template <> __device__ inline double gb_load_real<double>(GBuf b, uint32_t voff, uint32_t soff) {
+	vk_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 0);
+	return __hiloint2double((int)t.y, (int)t.x);
+}
+template <typename T> __device__ inline void gb_store_real(GBuf b, uint32_t voff, uint32_t soff, T v);
+template <> __device__ inline void gb_store_real<float>(GBuf b, uint32_t voff, uint32_t soff, float v) {
+	__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b.r, voff, soff, 0);
+}
+template <> __device__ inline void gb_store_real<double>(GBuf b, uint32_t voff, uint32_t soff, double v) {
+	vk_u32x2 t; t.x = (unsigned)__double2loint(v); t.y = (unsigned)__double2hiint(v);
 	__builtin_amdgcn_raw_buffer_store_b64(t, b.r, voff, soff, 0);
 }
 template <> __device__ inline void gb_store<double>(GBuf b, uint32_t voff, uint32_t soff, cx<double> v) {

@@ -274,9 +274,32 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	// workgroup tile
 	const bool anyCol = b.colIn || b.colOut;
 	uint32_t T;
-	const uint64_t ldsPerSub = 2 * (b.L + b.L / 16 + 2) * es; // both ping-pong buffers
+	// generic2 (register-direct, single LDS buffer, buffer addressing): every pass without Rader stages whose tile spans < 2 GiB
+	bool useG2 = false; // (a register-direct single-buffer interpreter was tried and dropped: the monolithic kernel spills)
+	for (size_t si = 0; si < rad.size(); si++) if (p.st[si].kind != 0 || rad[si] > 16) useG2 = false;
+	{
+		const uint64_t ib = (b.realIn ? 1 : 2) * (dp ? 8 : 4), ob = (b.realOut ? 1 : 2) * (dp ? 8 : 4);
+		const uint64_t maxPos = std::max<uint64_t>(std::max<uint64_t>(b.L, b.inLen), std::max<uint64_t>(b.outLen, b.opN)) * 2 + 4;
+		const uint64_t spanIn = (maxPos * (uint64_t)std::llabs(b.inStrideJ) + 64 * (uint64_t)std::llabs(dims[0].inStride)) * ib;
+		const uint64_t spanOut = (maxPos * (uint64_t)std::llabs(b.outStrideJ) + 64 * (uint64_t)std::llabs(dims[0].outStride)) * ob;
+		if (spanIn >= 0x7FFFFF00ull || spanOut >= 0x7FFFFF00ull) useG2 = false;
+	}
+	auto g2threads = [&](uint32_t TT) { // threads generic2 needs: every stage's butterflies fit P = 16/R per thread
+		uint64_t need = 64;
+		for (uint32_t R : rad) { const uint64_t P = std::min<uint64_t>(4, std::max<uint64_t>(1, 16 / R)); need = std::max<uint64_t>(need, ((b.L / R) * TT + P - 1) / P); }
+		return need;
+	};
+	uint64_t ldsPerSub = 0;
+	for (int attempt = 0; attempt < 2; attempt++) {
+	ldsPerSub = (useG2 ? 1 : 2) * (b.L + b.L / 16 + 2) * es; // one buffer (generic2) or both ping-pong buffers
 	if (b.forceT) T = b.forceT;
-	else if (anyCol) {
+	else if (anyCol && useG2) {
+		// strided tiles: 256-byte segments on the global side (real data: 64 columns of 4 bytes)
+		const bool realSide = b.realIn || b.realOut;
+		T = realSide ? (dp ? 32 : 64) : (dp ? 16 : 32);
+		while (T > 16 && (uint64_t)(T + 1) * ldsPerSub > b.maxLds / 2) T >>= 1; // two workgroups per CU when that keeps >= 16 columns
+		while (T > 1 && (uint64_t)(T + 1) * ldsPerSub > b.maxLds) T >>= 1;
+	} else if (anyCol) {
 		T = dp ? 16 : 32; // 256-byte segments
 		while (T > 1 && (uint64_t)(T + 1) * ldsPerSub > (b.maxLds * 7) / 10) T >>= 1; // leave room for two workgroups per CU when possible
 		while (T > 1 && (uint64_t)(T + 1) * ldsPerSub > b.maxLds) T >>= 1;
@@ -284,6 +307,12 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		// unit-stride rows: enough sub-FFTs for >= ~2048 points per workgroup
 		T = 1;
 		while (T < 64 && (uint64_t)T * b.L < 2048 && (uint64_t)(2 * T + 1) * ldsPerSub <= 64 * 1024) T <<= 1;
+	}
+	if (!useG2) break;
+	while (T > 1 && T / 2 >= dims[0].count) T >>= 1;
+	while (T > 1 && g2threads(T) > 1024) T >>= 1;
+	if (g2threads(T) <= 1024) break;
+	useG2 = false; // does not fit the register-direct kernel: plan for the ping-pong kernel instead
 	}
 	if (b.fastKernel == KERNEL_GENERIC) {
 		while (T > 1 && T / 2 >= dims[0].count) T >>= 1;
@@ -312,16 +341,19 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.ldsElems = (uint32_t)((padded + 1) * p.Tp);
 	p.tilesPerG0 = (uint32_t)((dims[0].count + T - 1) / T);
 	if (p.rd.P) { p.rd.tailElems = (uint32_t)((b.L / p.rd.P) * T + 1); p.rd.divU = make_fastdiv((uint32_t)((b.L / p.rd.P) * T)); }
-	pp.ldsBytes = (2 * (size_t)p.ldsElems + p.rd.tailElems) * es;
+	pp.ldsBytes = ((useG2 ? 1 : 2) * (size_t)p.ldsElems + p.rd.tailElems) * es;
 	if (pp.ldsBytes > b.maxLds && b.fastKernel == KERNEL_GENERIC) return 3002;
+	p.inElemBytes = (uint32_t)((b.realIn ? 1 : 2) * (dp ? 8 : 4));
+	p.outElemBytes = (uint32_t)((b.realOut ? 1 : 2) * (dp ? 8 : 4));
 	// threads: about one radix-8 butterfly per thread per stage
 	uint64_t work = (uint64_t)T * b.L / 8;
 	uint32_t thr = 64;
 	while (thr < work && thr < 1024) thr <<= 1;
 	if (pp.ldsBytes > 48 * 1024 && thr < 256) thr = 256;
+	if (useG2) { thr = (uint32_t)((g2threads(T) + 63) / 64 * 64); if (thr < 64) thr = 64; }
 	pp.threads = thr;
 	pp.dp = dp;
-	pp.kernel = KERNEL_GENERIC;
+	pp.kernel = useG2 ? KERNEL_GENERIC2 : KERNEL_GENERIC;
 	pp.inRole = b.inRole; pp.outRole = b.outRole;
 	pp.inOffset = b.inOffset; pp.outOffset = b.outOffset;
 	pp.inElemBytes = (int)((b.realIn ? 1 : 2) * (dp ? 8 : 4));
