@@ -27,6 +27,25 @@ def test_mixed_radix(run, oracle, N, dp):
     parity.check_c2c(run, oracle, (N,), 2, dp)
 
 
+def _mixed_table_sizes():
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "vkfft_amd", "csrc", "mixed_table.inc")).read()
+    return sorted(set(int(m) for m in re.findall(r"// N=(\d+)", txt)))
+
+
+def test_every_mixed_radix_table_entry(run, oracle):
+    """each ahead-of-time mixed-radix kernel instance (fp32 and fp64) against the double-precision truth"""
+    for N in _mixed_table_sizes():
+        for dp in (False, True):
+            if dp and N > 4096:
+                continue
+            x = parity.seeded_complex(N * 2, dp, N)
+            y, _ = run.transform(x, (N,), 2)
+            e = rel_l2(y, oracle.truth_c2c(x, (N,), 2, longdouble=dp))
+            assert e < (3e-15 if dp else 1e-6), (N, dp, e)
+
+
 @pytest.mark.parametrize("N", [17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 17 * 16, 31 * 9])
 def test_rader_direct_primes(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 2, False)

@@ -102,6 +102,32 @@ def test_radix_3_5_7_11_13(run, oracle, N, dp):
     parity.check_c2c(run, oracle, (N,), 4, dp)
 
 
+def test_every_mixed_radix_table_entry(run, oracle):
+    """Every ahead-of-time mixed-radix instance against the oracle on 7 sequences, then again with the chip full (many
+    workgroups per CU, memory back-pressure): the big batch is the 7 oracle-checked sequences repeated, so its output
+    must be the small-batch output repeated.  The second half is the test that exposes the gfx950 128-bit
+    buffer-store data hazard (memops.h)."""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "vkfft_amd", "csrc", "mixed_table.inc")).read()
+    for N in sorted(set(int(m) for m in re.findall(r"// N=(\d+)", txt))):
+        for dp in (False, True):
+            if dp and N > 4096:
+                continue
+            x7 = parity.seeded_complex(N * 7, dp, N)
+            want7 = oracle.truth_c2c(x7, (N,), 7, longdouble=dp)
+            y7, _ = run.transform(x7, (N,), 7)
+            e = rel_l2(y7, want7)
+            assert e < (3e-15 if dp else 1e-6), (N, dp, e)
+            reps = max(1, (1 << 21) // (7 * N))
+            x = np.tile(x7, reps)
+            want = np.tile(y7, reps)
+            for _ in range(2 if dp else 1):
+                y, _ = run.transform(x, (N,), 7 * reps)
+                bad = np.flatnonzero(y != want)
+                assert bad.size == 0, (N, dp, bad[:8], y[bad[:4]], want[bad[:4]])
+
+
 @pytest.mark.parametrize("N", [3 ** 10, 3 ** 13, 5 ** 8, 7 ** 7, 11 ** 5, 13 ** 5, 4000 * 4096 // 16])
 def test_radix_multi_pass(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 2, False, use_c_oracle=False)

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python tools/gpu_check.py > gpurun_out/check9.log 2>&1; tail -1 gpurun_out/check9.log; grep -E "BAD|EXC" gpurun_out/check9.log | head -5
-timeout 300 python tools/gpu_check.py real > gpurun_out/check9r.log 2>&1; tail -1 gpurun_out/check9r.log; grep -E "BAD|EXC" gpurun_out/check9r.log | head -5
-NO_REF=1 timeout 600 python tools/perf_configs.py 2>&1 | grep "^{"
+mkdir -p gpurun_out
+( time timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 ) 2>&1 | tee gpurun_out/gpu_tests.log
+timeout 600 python bench.py 2>&1 | tail -1 | tee gpurun_out/bench.json
+NO_REF=1 timeout 600 python tools/perf_configs.py 0 24 2>&1 | grep "^{" | tee gpurun_out/perf_configs.jsonl

@@ -38,6 +38,26 @@ __host__ __device__ constexpr double pow2_sin32(int k) {
 	return k == 0 ? 0.00000000000000000000e+00 : k == 1 ? 1.95090322016128248084e-01 : k == 2 ? 3.82683432365089781779e-01 : k == 3 ? 5.55570233019602177649e-01 : k == 4 ? 7.07106781186547461715e-01 : k == 5 ? 8.31469612302545235671e-01 : k == 6 ? 9.23879532511286738483e-01 : k == 7 ? 9.80785280403230430579e-01 : k == 8 ? 1.00000000000000000000e+00 : k == 9 ? 9.80785280403230430579e-01 : k == 10 ? 9.23879532511286738483e-01 : k == 11 ? 8.31469612302545457716e-01 : k == 12 ? 7.07106781186547572737e-01 : k == 13 ? 5.55570233019602177649e-01 : k == 14 ? 3.82683432365089892802e-01 : 1.95090322016128608906e-01;
 }
 
+// cos/sin(2*pi*m/R) for the composite radices (generated; exact to double rounding)
+__host__ __device__ constexpr double root_cos(int R, int m) {
+	if (R == 6) return m == 0 ? 1.00000000000000000000e+00 : m == 1 ? 5.00000000000000111022e-01 : m == 2 ? -4.99999999999999777955e-01 : m == 3 ? -1.00000000000000000000e+00 : m == 4 ? -5.00000000000000444089e-01 : 5.00000000000000111022e-01;
+	if (R == 9) return m == 0 ? 1.00000000000000000000e+00 : m == 1 ? 7.66044443118978013452e-01 : m == 2 ? 1.73648177666930414453e-01 : m == 3 ? -4.99999999999999777955e-01 : m == 4 ? -9.39692620785908316883e-01 : m == 5 ? -9.39692620785908427905e-01 : m == 6 ? -5.00000000000000444089e-01 : m == 7 ? 1.73648177666929970364e-01 : 7.66044443118977791407e-01;
+	if (R == 10) return m == 0 ? 1.00000000000000000000e+00 : m == 1 ? 8.09016994374947451263e-01 : m == 2 ? 3.09016994374947451263e-01 : m == 3 ? -3.09016994374947340241e-01 : m == 4 ? -8.09016994374947340241e-01 : m == 5 ? -1.00000000000000000000e+00 : m == 6 ? -8.09016994374947562285e-01 : m == 7 ? -3.09016994374947562285e-01 : m == 8 ? 3.09016994374947229218e-01 : 8.09016994374947340241e-01;
+	if (R == 12) return m == 0 ? 1.00000000000000000000e+00 : m == 1 ? 8.66025403784438707611e-01 : m == 2 ? 5.00000000000000111022e-01 : m == 3 ? 6.12323399573676603587e-17 : m == 4 ? -4.99999999999999777955e-01 : m == 5 ? -8.66025403784438707611e-01 : m == 6 ? -1.00000000000000000000e+00 : m == 7 ? -8.66025403784438818633e-01 : m == 8 ? -5.00000000000000444089e-01 : m == 9 ? -1.83697019872102968750e-16 : m == 10 ? 5.00000000000000111022e-01 : 8.66025403784438374544e-01;
+	if (R == 14) return m == 0 ? 1.00000000000000000000e+00 : m == 1 ? 9.00968867902419145999e-01 : m == 2 ? 6.23489801858733594386e-01 : m == 3 ? 2.22520933956314448388e-01 : m == 4 ? -2.22520933956314337365e-01 : m == 5 ? -6.23489801858733483364e-01 : m == 6 ? -9.00968867902419034976e-01 : m == 7 ? -1.00000000000000000000e+00 : m == 8 ? -9.00968867902419145999e-01 : m == 9 ? -6.23489801858733705409e-01 : m == 10 ? -2.22520933956314587165e-01 : m == 11 ? 2.22520933956313338165e-01 : m == 12 ? 6.23489801858733372342e-01 : 9.00968867902419368043e-01;
+	if (R == 15) return m == 0 ? 1.00000000000000000000e+00 : m == 1 ? 9.13545457642600866599e-01 : m == 2 ? 6.69130606358858237570e-01 : m == 3 ? 3.09016994374947451263e-01 : m == 4 ? -1.04528463267653332069e-01 : m == 5 ? -4.99999999999999777955e-01 : m == 6 ? -8.09016994374947340241e-01 : m == 7 ? -9.78147600733805688833e-01 : m == 8 ? -9.78147600733805688833e-01 : m == 9 ? -8.09016994374947562285e-01 : m == 10 ? -5.00000000000000444089e-01 : m == 11 ? -1.04528463267654234126e-01 : m == 12 ? 3.09016994374947229218e-01 : m == 13 ? 6.69130606358858459615e-01 : 9.13545457642600977621e-01;
+	return 1.0;
+}
+__host__ __device__ constexpr double root_sin(int R, int m) {
+	if (R == 6) return m == 0 ? 0.00000000000000000000e+00 : m == 1 ? 8.66025403784438596588e-01 : m == 2 ? 8.66025403784438707611e-01 : m == 3 ? 1.22464679914735320717e-16 : m == 4 ? -8.66025403784438374544e-01 : -8.66025403784438596588e-01;
+	if (R == 9) return m == 0 ? 0.00000000000000000000e+00 : m == 1 ? 6.42787609686539251896e-01 : m == 2 ? 9.84807753012208020316e-01 : m == 3 ? 8.66025403784438707611e-01 : m == 4 ? 3.42020143325668879442e-01 : m == 5 ? -3.42020143325668657397e-01 : m == 6 ? -8.66025403784438374544e-01 : m == 7 ? -9.84807753012208131338e-01 : -6.42787609686539584963e-01;
+	if (R == 10) return m == 0 ? 0.00000000000000000000e+00 : m == 1 ? 5.87785252292473137103e-01 : m == 2 ? 9.51056516295153531182e-01 : m == 3 ? 9.51056516295153642204e-01 : m == 4 ? 5.87785252292473248126e-01 : m == 5 ? 1.22464679914735320717e-16 : m == 6 ? -5.87785252292473026081e-01 : m == 7 ? -9.51056516295153531182e-01 : m == 8 ? -9.51056516295153642204e-01 : -5.87785252292473359148e-01;
+	if (R == 12) return m == 0 ? 0.00000000000000000000e+00 : m == 1 ? 4.99999999999999944489e-01 : m == 2 ? 8.66025403784438596588e-01 : m == 3 ? 1.00000000000000000000e+00 : m == 4 ? 8.66025403784438707611e-01 : m == 5 ? 4.99999999999999944489e-01 : m == 6 ? 1.22464679914735320717e-16 : m == 7 ? -4.99999999999999722444e-01 : m == 8 ? -8.66025403784438374544e-01 : m == 9 ? -1.00000000000000000000e+00 : m == 10 ? -8.66025403784438596588e-01 : -5.00000000000000444089e-01;
+	if (R == 14) return m == 0 ? 0.00000000000000000000e+00 : m == 1 ? 4.33883739117558120402e-01 : m == 2 ? 7.81831482468029803634e-01 : m == 3 ? 9.74927912181823619342e-01 : m == 4 ? 9.74927912181823619342e-01 : m == 5 ? 7.81831482468029914656e-01 : m == 6 ? 4.33883739117558231424e-01 : m == 7 ? 1.22464679914735320717e-16 : m == 8 ? -4.33883739117558009379e-01 : m == 9 ? -7.81831482468029692612e-01 : m == 10 ? -9.74927912181823619342e-01 : m == 11 ? -9.74927912181823841387e-01 : m == 12 ? -7.81831482468029914656e-01 : -4.33883739117557509779e-01;
+	if (R == 15) return m == 0 ? 0.00000000000000000000e+00 : m == 1 ? 4.06736643075800152758e-01 : m == 2 ? 7.43144825477394133095e-01 : m == 3 ? 9.51056516295153531182e-01 : m == 4 ? 9.94521895368273400884e-01 : m == 5 ? 8.66025403784438707611e-01 : m == 6 ? 5.87785252292473248126e-01 : m == 7 ? 2.07911690817759314820e-01 : m == 8 ? -2.07911690817759065020e-01 : m == 9 ? -5.87785252292473026081e-01 : m == 10 ? -8.66025403784438374544e-01 : m == 11 ? -9.94521895368273289861e-01 : m == 12 ? -9.51056516295153642204e-01 : m == 13 ? -7.43144825477394022073e-01 : -4.06736643075800152758e-01;
+	return 0.0;
+}
+
 // ---- power-of-two radices -----------------------------------------------------------------------------
 template <int R, typename T> struct DftPow2 {
 	// v[0..R) with element stride `str` in a register array; result in natural order, same slots.
@@ -114,9 +134,48 @@ template <int P, typename T> struct DftPrime {
 	}
 };
 
+template <int R, typename T> __host__ __device__ inline void dft(cx<T>* v);
+
+// ---- composite radices 6, 9, 10, 12, 14, 15: one Cooley-Tukey step in registers (n = B*n1 + n2, k = k1 + A*k2) ----------
+// (the reference's radix-6/9/10/12/14/15 butterflies, vkFFT_RadixKernels.h:499-2126, are built the same way)
+template <int A, int B, typename T> struct DftComposite {
+	__host__ __device__ static inline void run(cx<T>* v) {
+		constexpr int R = A * B;
+		cx<T> y[R];
+#pragma unroll
+		for (int n2 = 0; n2 < B; n2++) {
+			cx<T> tmp[A];
+#pragma unroll
+			for (int n1 = 0; n1 < A; n1++) tmp[n1] = v[B * n1 + n2];
+			dft<A, T>(tmp);
+#pragma unroll
+			for (int k1 = 0; k1 < A; k1++) {
+				const int m = (n2 * k1) % R;
+				if (m == 0) y[n2 * A + k1] = tmp[k1];
+				else y[n2 * A + k1] = cmul(tmp[k1], cx<T>{(T)root_cos(R, m), (T)(-root_sin(R, m))});
+			}
+		}
+#pragma unroll
+		for (int k1 = 0; k1 < A; k1++) {
+			cx<T> tmp[B];
+#pragma unroll
+			for (int n2 = 0; n2 < B; n2++) tmp[n2] = y[n2 * A + k1];
+			dft<B, T>(tmp);
+#pragma unroll
+			for (int k2 = 0; k2 < B; k2++) v[k1 + A * k2] = tmp[k2];
+		}
+	}
+};
+
 template <int R, typename T> __host__ __device__ inline void dft(cx<T>* v) {
 	if constexpr (R == 1) { }
 	else if constexpr (R == 2 || R == 4 || R == 8 || R == 16 || R == 32) DftPow2<R, T>::run(v);
+	else if constexpr (R == 6) DftComposite<2, 3, T>::run(v);
+	else if constexpr (R == 9) DftComposite<3, 3, T>::run(v);
+	else if constexpr (R == 10) DftComposite<2, 5, T>::run(v);
+	else if constexpr (R == 12) DftComposite<4, 3, T>::run(v);
+	else if constexpr (R == 14) DftComposite<2, 7, T>::run(v);
+	else if constexpr (R == 15) DftComposite<3, 5, T>::run(v);
 	else DftPrime<R, T>::run(v);
 }
 

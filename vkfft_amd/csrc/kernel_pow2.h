@@ -25,16 +25,7 @@
 
 namespace vkfft_mi355x {
 
-#if defined(VKFFT_HOSTEMU)
-#define VKFFT_WAVE_SYNC() hostemu::wave_sync()
-#define VKFFT_OPAQUE_ZERO(z) uint32_t z = 0
-#else
-// hides a (wave-uniform) pointer's provenance from the optimiser: stops loop-invariant twiddle loads from being
-// hoisted out of the persistent tile loop and pinned in dozens of VGPRs
-#define VKFFT_OPAQUE_ZERO(z) uint32_t z = 0; asm volatile("" : "+s"(z))
-// orders this wave's LDS writes before its later LDS reads without an s_barrier
-#define VKFFT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
-#endif
+
 
 template <int B0, int B1, int B2, int B3> struct Pow2Sched {
 	static constexpr int bits[4] = {B0, B1, B2, B3};

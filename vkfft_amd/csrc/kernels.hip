@@ -22,6 +22,8 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	case KERNEL_POW2_ROW:
 	case KERNEL_POW2_COL:
 		return launch_pow2(pp, prm, stream);
+	case KERNEL_MIXED_ROW:
+		return launch_mixed(pp, prm, stream);
 	case KERNEL_R2C_PAIR: {
 		const uint32_t npair = (prm.opN >> 2) + 1;
 		const uint64_t rows = (uint64_t)prm.dim[0].count * prm.dim[1].count * prm.dim[2].count;

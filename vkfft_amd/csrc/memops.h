@@ -6,6 +6,17 @@
 #pragma once
 #include "common.h"
 
+#if defined(VKFFT_HOSTEMU)
+#define VKFFT_WAVE_SYNC() hostemu::wave_sync()
+#define VKFFT_OPAQUE_ZERO(z) uint32_t z = 0
+#else
+// hides a (wave-uniform) pointer's provenance from the optimiser: stops loop-invariant twiddle loads from being
+// hoisted out of the persistent tile loop and pinned in dozens of VGPRs
+#define VKFFT_OPAQUE_ZERO(z) uint32_t z = 0; asm volatile("" : "+s"(z))
+// orders this wave's LDS writes before its later LDS reads without an s_barrier
+#define VKFFT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+#endif
+
 namespace vkfft_mi355x {
 
 constexpr uint32_t kGbRange = 0x7FFFFFF0u;  // bytes addressable through one resource
@@ -77,7 +88,11 @@ template <> __device__ inline void gb_store<double>(GBuf b, uint32_t voff, uint3
 	vk_u32x4 t;
 	t.x = (unsigned)__double2loint(v.x); t.y = (unsigned)__double2hiint(v.x);
 	t.z = (unsigned)__double2loint(v.y); t.w = (unsigned)__double2hiint(v.y);
-	__builtin_amdgcn_raw_buffer_store_b128(t, b.r, voff, soff, 0);
+	// gfx950 erratum-like behaviour (measured): a 128-bit buffer store whose soffset is an SGPR still
+	// reads its upper 64 data bits a cycle late, but the compiler's hazard recogniser only pads the soffset-less form —
+	// the next VALU write to those VGPRs then corrupts the imaginary half under memory back-pressure.  Folding the
+	// scalar offset into the per-lane offset keeps the store in the form the compiler protects with s_nop.
+	__builtin_amdgcn_raw_buffer_store_b128(t, b.r, voff + soff, 0, 0);
 }
 #endif
 

@@ -353,7 +353,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	if (useG2) { thr = (uint32_t)((g2threads(T) + 63) / 64 * 64); if (thr < 64) thr = 64; }
 	pp.threads = thr;
 	pp.dp = dp;
-	pp.kernel = useG2 ? KERNEL_GENERIC2 : KERNEL_GENERIC;
+	pp.kernel = KERNEL_GENERIC;
 	pp.inRole = b.inRole; pp.outRole = b.outRole;
 	pp.inOffset = b.inOffset; pp.outOffset = b.outOffset;
 	pp.inElemBytes = (int)((b.realIn ? 1 : 2) * (dp ? 8 : 4));
@@ -734,6 +734,14 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	const uint64_t singleCap = unit ? rowCap : max_col_len(dp, d.maxLds, 1);
 	if (j.N <= singleCap || (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N <= (dp ? 8192u : 16384u))) {
 		b.L = j.N;
+		if (unit && !d.disableFastKernels && (j.N & (j.N - 1)) != 0) { // curated non-power-of-two lengths: hand-specialised mixed-radix kernel
+			int variant, rad5[5], fpw, thr;
+			uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
+			if ((rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && mixed_row_lookup(j.N, dp, &variant, rad5, &fpw, &thr)) {
+				b.fastKernel = KERNEL_MIXED_ROW; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
+				for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
+			}
+		}
 		if (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N >= 4) {
 			int variant, bits[4], fpw, thr;
 			uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
