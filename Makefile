@@ -4,7 +4,8 @@ ARCH ?= gfx950
 CSRC := vkfft_amd/csrc
 LIBDIR := vkfft_amd/lib
 CXXFLAGS := -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I$(CSRC) -Wno-unused-result
-OBJS := build/obj/api.o build/obj/planner.o build/obj/plan_real.o build/obj/kernels.o build/obj/kernels_mixed.o
+OBJS := build/obj/api.o build/obj/planner.o build/obj/plan_real.o build/obj/kernels.o build/obj/kernels_mixed.o \
+        build/obj/kernels_opfft_f32_row.o build/obj/kernels_opfft_f32_col.o build/obj/kernels_opfft_f64_row.o build/obj/kernels_opfft_f64_col.o
 HDRS := $(wildcard $(CSRC)/*.h) include/vkFFT.h
 
 all: $(LIBDIR)/libvkfft_mi355x.so
@@ -13,11 +14,7 @@ build/obj/%.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p build/obj
 	$(HIPCC) $(CXXFLAGS) --offload-arch=$(ARCH) -c $< -o $@
 
-build/obj/kernels_mixed.o: $(CSRC)/kernels_mixed.hip $(HDRS) $(CSRC)/mixed_table.inc
-	@mkdir -p build/obj
-	$(HIPCC) $(CXXFLAGS) --offload-arch=$(ARCH) -c $< -o $@
-
-build/obj/kernels.o: $(CSRC)/kernels.hip $(HDRS)
+build/obj/%.o: $(CSRC)/%.hip $(HDRS) $(wildcard $(CSRC)/*.inc)
 	@mkdir -p build/obj
 	$(HIPCC) $(CXXFLAGS) --offload-arch=$(ARCH) -c $< -o $@
 

@@ -63,3 +63,59 @@ def check_r2r(runner, oracle, shape, batch, dp, type, dst, seed=3):
     assert rel_l2(z, x.astype(np.float64) * norm) < 2 * tol, f"inverse {'dst' if dst else 'dct'}{type} {shape}"
     o = oracle.r2r(x, shape, batch, type=type, dst=dst)
     assert rel_l2(y, o) < 2 * tol
+
+
+# ---- op-FFT kernel family (kernel_opfft.h): one case per generated table entry -----------------------------------
+def opfft_cases():
+    """[(family, L, col, dp)] parsed from the generated tables vkfft_amd/csrc/opfft_table_*.inc."""
+    import os, re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vkfft_amd", "csrc")
+    cases = []
+    for dp, tag in ((False, "f32"), (True, "f64")):
+        for col in (False, True):
+            txt = open(os.path.join(root, "opfft_table_%s_%s.inc" % (tag, "col" if col else "row"))).read()
+            for fam, L in re.findall(r"// (\w+) L=(\d+)", txt):
+                if fam == "dst1" and int(L) == 4:
+                    continue  # DST-I of length 1: size-1 axes are omitted (reference InitializeApp.h:1378-1381), nothing to run
+                cases.append((fam, int(L), col, dp))
+    return cases
+
+
+def opfft_transform_of(fam, L, col):
+    """(shape, kwargs of Runner.transform, real data?) of the smallest transform whose plan uses this table entry."""
+    n = {"r2c": 2 * L, "c2r": 2 * L, "dct2": L, "dct3": L, "dct4": 2 * L, "dct1": L // 2 + 1, "dst1": L // 2 - 1, "c2c": L}[fam]
+    kw = {"r2c": dict(r2c=True), "c2r": dict(r2c=True), "dct2": dict(dct=2), "dct3": dict(dct=3), "dct4": dict(dct=4), "dct1": dict(dct=1),
+          "dst1": dict(dst=1), "c2c": {}}[fam]
+    shape = (24, n) if col else (n,)
+    return shape, kw, fam != "c2c"
+
+
+def check_opfft_case(runner, oracle, fam, L, col, dp, load_elems=0):
+    """Parity of one table entry against the oracle; with load_elems > 0 also a chip-filling batch of the same sequences
+    whose output must repeat the small-batch output bit for bit."""
+    shape, kw, real = opfft_transform_of(fam, L, col)
+    batch = 3
+    if fam == "c2c":
+        check_c2c(runner, oracle, shape, batch, dp, use_c_oracle=False)
+    elif fam in ("r2c", "c2r"):
+        check_r2c(runner, oracle, shape, batch, dp)
+    else:
+        check_r2r(runner, oracle, shape, batch, dp, int(fam[3]), fam.startswith("dst"))
+    if load_elems:
+        n = int(np.prod(shape))
+        rng = np.random.default_rng(L)
+        if fam == "c2c":
+            x = seeded_complex(n * batch, dp, L)
+        elif fam in ("r2c", "c2r"):
+            W = shape[0]
+            x = np.zeros((batch * n // W, 2 * (W // 2 + 1)), dtype=np.float64 if dp else np.float32)
+            x[:, :W] = rng.uniform(-1, 1, (batch * n // W, W))
+            x = x.reshape(-1)
+        else:
+            x = rng.uniform(-1, 1, n * batch).astype(np.float64 if dp else np.float32)
+        small = runner.transform(x, shape, batch, both=True, **kw)
+        reps = max(2, load_elems // (n * batch))
+        big = runner.transform(np.tile(x, reps), shape, batch * reps, both=True, **kw)
+        for s, b in zip(small[:2], big[:2]):
+            bad = np.flatnonzero(np.tile(s, reps).view(np.uint8) != b.view(np.uint8))
+            assert bad.size == 0, (fam, L, col, dp, bad[:8])

@@ -46,6 +46,19 @@ def test_every_mixed_radix_table_entry(run, oracle):
             assert e < (3e-15 if dp else 1e-6), (N, dp, e)
 
 
+def _opfft_emu_cases():
+    cases = parity.opfft_cases()
+    return [c for i, c in enumerate(cases) if c[1] <= 128 or i % 7 == 0]
+
+
+@pytest.mark.parametrize("chunk", range(8))
+def test_opfft_table_entries(run, oracle, chunk):
+    """Fused pre/post map kernels (R2C/C2R, DCT/DST, strided C2C): every entry up to L=128 and every 7th of the rest."""
+    cases = _opfft_emu_cases()
+    for fam, L, col, dp in cases[chunk::8]:
+        parity.check_opfft_case(run, oracle, fam, L, col, dp)
+
+
 @pytest.mark.parametrize("N", [17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 17 * 16, 31 * 9])
 def test_rader_direct_primes(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 2, False)

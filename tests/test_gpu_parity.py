@@ -128,6 +128,15 @@ def test_every_mixed_radix_table_entry(run, oracle):
                 assert bad.size == 0, (N, dp, bad[:8], y[bad[:4]], want[bad[:4]])
 
 
+@pytest.mark.parametrize("chunk", range(4))
+def test_every_opfft_table_entry(run, oracle, chunk):
+    """Fused pre/post map kernels (kernel_opfft.h: R2C/C2R, DCT/DST I-IV, strided C2C): every generated instance against
+    the oracle, and with the chip full against its own small-batch output."""
+    cases = parity.opfft_cases()
+    for fam, L, col, dp in cases[chunk::4]:
+        parity.check_opfft_case(run, oracle, fam, L, col, dp, load_elems=1 << 20)
+
+
 @pytest.mark.parametrize("N", [3 ** 10, 3 ** 13, 5 ** 8, 7 ** 7, 11 ** 5, 13 ** 5, 4000 * 4096 // 16])
 def test_radix_multi_pass(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 2, False, use_c_oracle=False)

@@ -47,9 +47,9 @@ template <typename T> __device__ inline cx<T> twiddle4(const PassParams& p, uint
 
 // value that goes to LDS position `pos` of sub-FFT f (before the optional inverse swap)
 template <typename T, typename IO>
-__device__ inline cx<T> pre_gather(const PassParams& p, const IO& io, uint32_t pos, uint32_t natBase) {
+__device__ inline cx<T> pre_gather(const PassParams& p, const IO& io, uint32_t pos, uint32_t natBase, const uint32_t op) {
 	const cx<T> zero = {(T)0, (T)0};
-	switch (p.preOp) {
+	switch (op) {
 	default:
 	case OP_NONE:
 		return pos < p.inLen ? io.ldc(pos) : zero;
@@ -73,13 +73,13 @@ __device__ inline cx<T> pre_gather(const PassParams& p, const IO& io, uint32_t p
 		const uint32_t N = p.opN;
 		const uint32_t src = pos < (N + 1) / 2 ? 2 * pos : 2 * (N - 1 - pos) + 1;
 		T v = io.ldr(src);
-		if (p.preOp == OP_DST2_PRE && (src & 1)) v = -v;
+		if (op == OP_DST2_PRE && (src & 1)) v = -v;
 		return {v, (T)0};
 	}
 	case OP_DCT3_PRE: case OP_DST3_PRE: { // V_k = e^{+i pi k/2N} (x_k - i x_{N-k}), x_N = 0
 		const uint32_t N = p.opN;
 		T a, b;
-		if (p.preOp == OP_DCT3_PRE) {
+		if (op == OP_DCT3_PRE) {
 			a = io.ldr(pos);
 			b = pos == 0 ? (T)0 : io.ldr(N - pos);
 		} else { // DST-III = (-1)^n DCT-III(reversed input)
@@ -102,7 +102,7 @@ __device__ inline cx<T> pre_gather(const PassParams& p, const IO& io, uint32_t p
 	}
 	case OP_DCT4_PRE: case OP_DST4_PRE: {
 		const uint32_t N = p.opN;
-		const bool dst = p.preOp == OP_DST4_PRE;
+		const bool dst = op == OP_DST4_PRE;
 		if (p.L * 2 == N) { // even N: half-length complex FFT
 			uint32_t i0 = 2 * pos, i1 = N - 1 - 2 * pos;
 			if (dst) { i0 = N - 1 - i0; i1 = N - 1 - i1; }
@@ -125,9 +125,9 @@ __device__ inline cx<T> pre_gather(const PassParams& p, const IO& io, uint32_t p
 
 // output element k of sub-FFT f, gathered from LDS buffer `buf` (values already un-swapped by `rd`)
 template <typename T, typename IO, typename RD>
-__device__ inline void post_store(const PassParams& p, const IO& io, uint32_t k, uint32_t colIdx, uint32_t natBase, RD rd) {
+__device__ inline void post_store(const PassParams& p, const IO& io, uint32_t k, uint32_t colIdx, uint32_t natBase, RD rd, const uint32_t op) {
 	const T sc = (T)p.scale;
-	switch (p.postOp) {
+	switch (op) {
 	default:
 	case OP_NONE: {
 		cx<T> v = rd(k);
@@ -163,7 +163,7 @@ __device__ inline void post_store(const PassParams& p, const IO& io, uint32_t k,
 	}
 	case OP_DCT2_POST: case OP_DST2_POST: {
 		const uint32_t N = p.opN;
-		const uint32_t kk = p.postOp == OP_DST2_POST ? N - 1 - k : k;
+		const uint32_t kk = op == OP_DST2_POST ? N - 1 - k : k;
 		cx<T> v = cmul(((const cx<T>*)p.aux)[kk], rd(kk));
 		io.str(k, (T)2 * sc * v.x);
 		return;
@@ -172,7 +172,7 @@ __device__ inline void post_store(const PassParams& p, const IO& io, uint32_t k,
 		const uint32_t N = p.opN;
 		const uint32_t m = (k & 1) ? N - 1 - (k >> 1) : (k >> 1);
 		T v = rd(m).x * sc;
-		if (p.postOp == OP_DST3_POST && (k & 1)) v = -v;
+		if (op == OP_DST3_POST && (k & 1)) v = -v;
 		io.str(k, v);
 		return;
 	}
@@ -193,7 +193,7 @@ __device__ inline void post_store(const PassParams& p, const IO& io, uint32_t k,
 			cx<T> c = cmul(rd(k), ((const cx<T>*)p.aux2)[k]);
 			v = (T)2 * c.x;
 		}
-		if (p.postOp == OP_DST4_POST && (k & 1)) v = -v;
+		if (op == OP_DST4_POST && (k & 1)) v = -v;
 		io.str(k, v * sc);
 		return;
 	}
@@ -415,7 +415,7 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 			cx<T> v = {(T)0, (T)0};
 			if (f < nvalid) {
 				const Io64<T> io{p.in, p.out, inBase + (int64_t)f * p.dim[0].inStride, 0, p.inStrideJ, p.outStrideJ};
-				v = pre_gather<T>(p, io, pos, (g0base + f) * p.opStride0 + g1 * p.opStride1);
+				v = pre_gather<T>(p, io, pos, (g0base + f) * p.opStride0 + g1 * p.opStride1, p.preOp);
 			}
 			if (p.swapIn) v = cswap(v);
 			bufA[(pos + (pos >> ps)) * Tp + f] = v;
@@ -483,160 +483,7 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 			uint32_t colIdx = 0;
 			if (p.postOp == OP_TWIDDLE_4STEP) { if (p.fsColFromDim1) colIdx = g1; else { uint32_t qq, rr; p.fsColDiv.divmod(g0base + f, qq, rr); colIdx = qq; } }
 			const Io64<T> io{p.in, p.out, 0, outBase + (int64_t)f * p.dim[0].outStride, p.inStrideJ, p.outStrideJ};
-			post_store<T>(p, io, k, colIdx, (g0base + f) * p.opStride0 + g1 * p.opStride1, rd);
-		}
-	}
-}
-
-// =============================================================================================================
-// generic2: register-direct variant of the generic pass (no Rader stages).  Same Stockham index maps, but
-//   * the first stage gathers its inputs straight from global memory (every pre-op is a gather) and the last
-//     stage scatters straight to global memory whenever the post-op is element-wise,
-//   * between stages the data makes ONE trip through a single LDS buffer (read all inputs -> barrier ->
-//     butterflies -> write -> barrier) instead of ping-ponging between two buffers,
-//   * each thread keeps up to EMAX points (P = EMAX/R butterflies of radix R) in registers per stage,
-//   * global accesses use buffer addressing (Io32).
-// Run-time radix list, compile-time butterfly bodies: stage2<R, P, FIRST, LAST> is instantiated for the 9 radices.
-template <typename T, int R, int P, bool FIRST, bool LAST, typename MKIO>
-__device__ inline void stage2(const PassParams& p, const StageDesc& sd, int si, cx<T>* buf, uint32_t tid, uint32_t nthr,
-                              const MKIO& mkio, uint32_t g0base, uint32_t g1, uint32_t nvalid, bool swapIn, bool swapOut) {
-	const uint32_t nb = p.L / R;
-	const uint32_t total = nb << p.logT;
-	const uint32_t S = sd.S;
-	const uint32_t Tp = p.Tp, ps = p.padShift;
-	const cx<T>* lut = (const cx<T>*)p.lut + sd.lutOff;
-	const bool alongF = p.T >= 16;
-	cx<T> x[P][R];
-	uint32_t ft[P], tt[P];
-	bool act[P];
-#pragma unroll
-	for (int b = 0; b < P; b++) {
-		const uint32_t u = tid + b * nthr;
-		act[b] = u < total;
-		uint32_t f = 0, t = 0;
-		if (act[b]) { if (alongF) { f = u & (p.T - 1); t = u >> p.logT; } else p.divNb[si].divmod(u, f, t); }
-		ft[b] = f; tt[b] = t;
-		if (FIRST) {
-			const auto io = mkio(f, act[b] && f < nvalid);
-			const uint32_t nat = (g0base + f) * p.opStride0 + g1 * p.opStride1;
-#pragma unroll
-			for (int i = 0; i < R; i++) {
-				cx<T> v = pre_gather<T>(p, io, t + i * nb, nat);
-				x[b][i] = swapIn ? cswap(v) : v;
-			}
-		} else if (act[b]) {
-#pragma unroll
-			for (int i = 0; i < R; i++) { const uint32_t a = t + i * nb; x[b][i] = buf[(a + (a >> ps)) * Tp + f]; }
-		}
-	}
-	if (!FIRST) __syncthreads(); // every input is in registers before anyone overwrites the buffer
-#pragma unroll
-	for (int b = 0; b < P; b++) {
-		if (!act[b]) continue;
-		const uint32_t f = ft[b], t = tt[b];
-		uint32_t q, s;
-		if (S == 1) { q = t; s = 0; }
-		else p.divS[si].divmod(t, q, s);
-		if (S > 1) {
-#pragma unroll
-			for (int i = 1; i < R; i++) x[b][i] = cmul(x[b][i], lut[(i - 1) * S + s]);
-		}
-		dft<R, T>(x[b]);
-		const uint32_t ob = q * S * R + s;
-		if (LAST) {
-			const auto io = mkio(f, f < nvalid);
-			const uint32_t nat = (g0base + f) * p.opStride0 + g1 * p.opStride1;
-			uint32_t colIdx = 0;
-			if (p.postOp == OP_TWIDDLE_4STEP) { if (p.fsColFromDim1) colIdx = g1; else { uint32_t rr; p.fsColDiv.divmod(g0base + f, colIdx, rr); } }
-#pragma unroll
-			for (int k = 0; k < R; k++) {
-				const uint32_t a = ob + k * S;
-				const cx<T> val = swapOut ? cswap(x[b][k]) : x[b][k];
-				uint32_t ko = a;
-				if (p.postOp == OP_DST1_POST) { if (a == 0) continue; ko = a - 1; }
-				if (ko >= p.outLen) continue;
-				post_store<T>(p, io, ko, colIdx, nat, [&](uint32_t) { return val; });
-			}
-		} else {
-#pragma unroll
-			for (int k = 0; k < R; k++) { const uint32_t a = ob + k * S; buf[(a + (a >> ps)) * Tp + f] = x[b][k]; }
-		}
-	}
-	if (!LAST) __syncthreads();
-}
-
-template <typename T, int EMAX, bool FIRST, bool LAST, typename MKIO>
-__device__ inline void stage2_dispatch(const PassParams& p, const StageDesc& sd, int si, cx<T>* buf, uint32_t tid, uint32_t nthr, const MKIO& mkio,
-                                       uint32_t g0base, uint32_t g1, uint32_t nvalid, bool swapIn, bool swapOut) {
-	switch (sd.radix) {
-#define VK_S2(R) case R: stage2<T, R, (EMAX / R > 0 ? EMAX / R : 1), FIRST, LAST>(p, sd, si, buf, tid, nthr, mkio, g0base, g1, nvalid, swapIn, swapOut); break;
-		VK_S2(2) VK_S2(3) VK_S2(4) VK_S2(5) VK_S2(7) VK_S2(8) VK_S2(11) VK_S2(13) VK_S2(16)
-#undef VK_S2
-		default: break;
-	}
-}
-
-// post-ops whose output element k depends only on FFT output k (or a 1:1 function of it): the last stage may store directly
-__host__ __device__ inline bool post_is_elementwise(uint32_t op) {
-	return op == OP_NONE || op == OP_TWIDDLE_4STEP || op == OP_MUL_LUT || op == OP_BLUESTEIN_POST || op == OP_R2C_FULL || op == OP_C2R_FULL ||
-	       op == OP_DCT2_POST || op == OP_DCT1_POST || op == OP_DST1_POST;
-}
-
-template <typename T, int EMAX> __global__ void __launch_bounds__(1024) generic2_pass_kernel(const PassParams p) {
-	VKFFT_DYN_SMEM(smem_raw)
-	cx<T>* buf = (cx<T>*)smem_raw;
-	const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-	uint32_t wg = blockIdx.x;
-	const uint32_t tile = wg % p.tilesPerG0;
-	wg /= p.tilesPerG0;
-	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
-	const uint32_t g0base = tile << p.logT;
-	const uint32_t remain = p.dim[0].count - g0base;
-	const uint32_t nvalid = remain < p.T ? remain : p.T;
-	const int64_t inBase = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)g0base * p.dim[0].inStride;
-	const int64_t outBase = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)g0base * p.dim[0].outStride;
-	const GBuf gin = make_gbuf((const char*)p.in + inBase * (int64_t)p.inElemBytes);
-	const GBuf gout = make_gbuf((char*)p.out + outBase * (int64_t)p.outElemBytes);
-	const uint32_t inSj = (uint32_t)p.inStrideJ * p.inElemBytes, outSj = (uint32_t)p.outStrideJ * p.outElemBytes;
-	const uint32_t inS0 = (uint32_t)p.dim[0].inStride * p.inElemBytes, outS0 = (uint32_t)p.dim[0].outStride * p.outElemBytes;
-	auto mkio = [&](uint32_t f, bool ok) { return Io32<T>{gin, gout, ok ? f * inS0 : kGbInvalid, ok ? f * outS0 : kGbInvalid, inSj, outSj}; };
-	const uint32_t Tp = p.Tp, ps = p.padShift;
-	const int reps = p.midOp == OP_BLUESTEIN_MID ? 2 : 1;
-	const bool direct = post_is_elementwise(p.postOp);
-	const bool swapO = p.swapOut || reps == 2;
-	for (int rep = 0; rep < reps; rep++) {
-		for (uint32_t si = 0; si < p.nStages; si++) {
-			const StageDesc& sd = p.st[si];
-			const bool first = rep == 0 && si == 0;
-			const bool last = direct && rep == reps - 1 && si == p.nStages - 1;
-			if (first && last) stage2_dispatch<T, EMAX, true, true>(p, sd, si, buf, tid, nthr, mkio, g0base, g1, nvalid, p.swapIn != 0, swapO);
-			else if (first) stage2_dispatch<T, EMAX, true, false>(p, sd, si, buf, tid, nthr, mkio, g0base, g1, nvalid, p.swapIn != 0, swapO);
-			else if (last) stage2_dispatch<T, EMAX, false, true>(p, sd, si, buf, tid, nthr, mkio, g0base, g1, nvalid, p.swapIn != 0, swapO);
-			else stage2_dispatch<T, EMAX, false, false>(p, sd, si, buf, tid, nthr, mkio, g0base, g1, nvalid, p.swapIn != 0, swapO);
-		}
-		if (rep == 0 && reps == 2) { // Bluestein: spectrum x FFT(chirp), swapped for the inverse pass through the same stages
-			const uint32_t total = p.L << p.logT;
-			const cx<T>* bh = (const cx<T>*)p.aux2;
-			for (uint32_t idx = tid; idx < total; idx += nthr) {
-				uint32_t f, pos;
-				if (p.T >= 16) { f = idx & (p.T - 1); pos = idx >> p.logT; }
-				else p.divL.divmod(idx, f, pos);
-				const uint32_t li = (pos + (pos >> ps)) * Tp + f;
-				buf[li] = cswap(cmul(buf[li], bh[pos]));
-			}
-			__syncthreads();
-		}
-	}
-	if (!direct) { // post-ops that combine several FFT outputs: gather from LDS
-		const uint32_t total = p.outLen << p.logT;
-		for (uint32_t idx = tid; idx < total; idx += nthr) {
-			uint32_t f, k;
-			if (p.colModeOut) { f = idx & (p.T - 1); k = idx >> p.logT; }
-			else p.divOutLen.divmod(idx, f, k);
-			if (f >= nvalid) continue;
-			auto rd = [&](uint32_t a) -> cx<T> { cx<T> v = buf[(a + (a >> ps)) * Tp + f]; return swapO ? cswap(v) : v; };
-			const auto io = mkio(f, true);
-			post_store<T>(p, io, k, 0, (g0base + f) * p.opStride0 + g1 * p.opStride1, rd);
+			post_store<T>(p, io, k, colIdx, (g0base + f) * p.opStride0 + g1 * p.opStride1, rd, p.postOp);
 		}
 	}
 }

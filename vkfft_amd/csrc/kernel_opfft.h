@@ -1,0 +1,171 @@
+// Hand-specialised single-pass kernels WITH a fused pre/post map: the real transforms (R2C / C2R through the even
+// decomposition, DCT/DST I-IV; reference vkFFT_R2C.h:178,450, vkFFT_R2R.h:28-861) on unit-stride rows and on strided
+// columns, and strided C2C of non-power-of-two length.  Same register/LDS structure as kernel_mixed.h (compile-time
+// radix schedule, one LDS buffer, first stage fed from global memory, last stage stored to global memory); what is added:
+//   * the first stage's inputs come from pre_gather<PRE> (every pre-map is a gather: kernel_generic.h), the last stage's
+//     outputs go through post_scatter<POST> (every post-map except the R2C even split is 1:1 or 1:2 in scatter form) —
+//     the R2C even split needs Z[k] and Z[H-k] together and makes one more trip through LDS;
+//   * COL = true lays the workgroup across FPW neighbouring columns (lanes along the unit-stride direction) so that a
+//     strided axis is read and written in FPW-element segments without a transposition.
+// PRE/POST are compile-time: the DST members of a family share the DCT instance (op read from the pass descriptor, the
+// switch folds to the one family body).
+#pragma once
+#include "engine.h"
+#include "kernel_generic.h"
+#include "mix_sched.h"
+
+namespace vkfft_mi355x {
+
+// scatter form of the post-maps: FFT output `a` of this sub-FFT with value v -> its output element(s)
+template <typename T, typename IO>
+__device__ inline void post_scatter(const PassParams& p, const IO& io, const uint32_t a, const cx<T> v, const uint32_t colIdx, const uint32_t nat, const uint32_t op) {
+	auto rd = [&](uint32_t) { return v; };
+	const uint32_t N = p.opN;
+	switch (op) {
+	default: // OP_NONE, OP_TWIDDLE_4STEP, OP_MUL_LUT, OP_BLUESTEIN_POST, OP_R2C_FULL, OP_C2R_FULL, OP_DCT1_POST: output a <- FFT output a
+		if (a < p.outLen) post_store<T>(p, io, a, colIdx, nat, rd, op);
+		return;
+	case OP_DST1_POST:
+		if (a >= 1 && a <= N) post_store<T>(p, io, a - 1, colIdx, nat, rd, op);
+		return;
+	case OP_DCT2_POST:
+		post_store<T>(p, io, a, colIdx, nat, rd, op);
+		return;
+	case OP_DST2_POST:
+		post_store<T>(p, io, N - 1 - a, colIdx, nat, rd, op);
+		return;
+	case OP_DCT3_POST: case OP_DST3_POST:
+		post_store<T>(p, io, a < (N + 1) / 2 ? 2 * a : 2 * (N - 1 - a) + 1, colIdx, nat, rd, op);
+		return;
+	case OP_DCT4_POST: case OP_DST4_POST:
+		if (p.L * 2 == N) { // half-length form: FFT output m feeds outputs 2m and N-1-2m
+			post_store<T>(p, io, 2 * a, colIdx, nat, rd, op);
+			post_store<T>(p, io, N - 1 - 2 * a, colIdx, nat, rd, op);
+		} else if (a < N) post_store<T>(p, io, a, colIdx, nat, rd, op);
+		return;
+	}
+}
+
+// the DST member of a DCT family at run time, everything else at compile time
+template <int OP> __device__ inline uint32_t op_resolve(const uint32_t runtimeOp) {
+	if constexpr (OP == OP_DCT2_PRE) return runtimeOp == OP_DST2_PRE ? OP_DST2_PRE : OP_DCT2_PRE;
+	else if constexpr (OP == OP_DCT3_PRE) return runtimeOp == OP_DST3_PRE ? OP_DST3_PRE : OP_DCT3_PRE;
+	else if constexpr (OP == OP_DCT4_PRE) return runtimeOp == OP_DST4_PRE ? OP_DST4_PRE : OP_DCT4_PRE;
+	else if constexpr (OP == OP_DCT2_POST) return runtimeOp == OP_DST2_POST ? OP_DST2_POST : OP_DCT2_POST;
+	else if constexpr (OP == OP_DCT3_POST) return runtimeOp == OP_DST3_POST ? OP_DST3_POST : OP_DCT3_POST;
+	else if constexpr (OP == OP_DCT4_POST) return runtimeOp == OP_DST4_POST ? OP_DST4_POST : OP_DCT4_POST;
+	else return (uint32_t)OP;
+}
+
+template <typename T, typename SCH, int SI, int TPF, int PRE, int POST>
+__device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut, const uint32_t tau, const bool waveOnly, const PassParams& p,
+                                const uint32_t colIdx, const uint32_t nat) {
+	constexpr int N = SCH::N, R = SCH::rad[SI], NB = N / R, P = (NB + TPF - 1) / TPF, S = SCH::S(SI);
+	constexpr bool first = SI == 0, last = SI == SCH::NS - 1;
+	constexpr bool staged = POST == OP_R2C_EVEN_POST; // the post-map gathers from LDS
+	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
+	cx<T> x[P][R];
+#pragma unroll
+	for (int b = 0; b < P; b++) {
+		const uint32_t t = tau + b * TPF;
+		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
+#pragma unroll
+			for (int i = 0; i < R; i++) {
+				if constexpr (first) {
+					const cx<T> v = pre_gather<T>(p, io, t + i * NB, nat, op_resolve<PRE>(p.preOp));
+					x[b][i] = p.swapIn ? cswap(v) : v;
+				} else x[b][i] = ldsf[mix_slot(t + i * NB)];
+			}
+		}
+	}
+	if constexpr (!first && (!last || staged)) { // all inputs are in registers before the buffer is overwritten
+		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+	}
+#pragma unroll
+	for (int b = 0; b < P; b++) {
+		const uint32_t t = tau + b * TPF;
+		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
+			const uint32_t s = t % (uint32_t)S;
+			if constexpr (!first) {
+				constexpr int LO = SCH::lutOff(SI);
+#pragma unroll
+				for (int i = 1; i < R; i++) x[b][i] = cmul(x[b][i], gb_load<T>(glut, s * ES, (uint32_t)(LO + (i - 1) * S) * ES));
+			}
+			dft<R, T>(x[b]);
+			const uint32_t ob = (t - s) * (uint32_t)R + s;
+#pragma unroll
+			for (int k = 0; k < R; k++) {
+				if constexpr (last) {
+					const cx<T> v = p.swapOut ? cswap(x[b][k]) : x[b][k];
+					if constexpr (staged) ldsf[mix_slot(ob + k * S)] = v;
+					else post_scatter<T>(p, io, ob + k * S, v, colIdx, nat, op_resolve<POST>(p.postOp));
+				} else ldsf[mix_slot(ob + k * S)] = x[b][k];
+			}
+		}
+	}
+	if constexpr (!last) {
+		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		op_stage<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, PRE, POST>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
+	} else if constexpr (staged) {
+		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		constexpr int PO = (N + 1 + TPF - 1) / TPF; // R2C even split: N + 1 outputs from the length-N complex FFT
+		auto rd = [&](uint32_t a) { return ldsf[mix_slot(a)]; };
+#pragma unroll
+		for (int b = 0; b < PO; b++) {
+			const uint32_t k = tau + b * TPF;
+			if (k < p.outLen) post_store<T>(p, io, k, colIdx, nat, rd, (uint32_t)POST);
+		}
+	}
+}
+
+template <int N, int FPW, bool COL, bool NEEDS_LDS> __host__ __device__ constexpr int opfft_pitch() {
+	if (!NEEDS_LDS) return 1;
+	int pitch = N + (N >> 4) + 1;
+	if (COL) { // lanes run along the FPW columns: column pitch = (32/FPW) * odd spreads a half-wave over all banks
+		const int q = FPW >= 32 ? 1 : 32 / FPW;
+		while (pitch % (2 * q) != q) pitch++;
+	}
+	return pitch;
+}
+
+template <typename T, typename SCH, int TPF, int FPW, bool COL, int PRE, int POST>
+__global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
+	constexpr int N = SCH::N;
+	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || POST == OP_R2C_EVEN_POST)>();
+	constexpr bool waveOnly = !COL && (TPF <= 64) && (64 % TPF == 0); // a row FFT that never straddles wavefronts
+	__shared__ cx<T> lds[FPW * LDSPF];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t f = COL ? tid % FPW : tid / TPF, tau = COL ? tid / FPW : tid % TPF;
+	uint32_t wg = blockIdx.x;
+	const uint32_t tile = wg % p.tilesPerG0;
+	wg /= p.tilesPerG0;
+	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
+	const uint32_t f0 = tile * FPW, g0 = f0 + f;
+	const bool valid = g0 < p.dim[0].count;
+	const int64_t inBase = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride;
+	const int64_t outBase = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride;
+	Io32<T> io;
+	io.gin = make_gbuf((const char*)p.in + inBase * (int64_t)p.inElemBytes);
+	io.gout = make_gbuf((char*)p.out + outBase * (int64_t)p.outElemBytes);
+	io.inOff = valid ? f * (uint32_t)p.dim[0].inStride * p.inElemBytes : kGbInvalid;
+	io.outOff = valid ? f * (uint32_t)p.dim[0].outStride * p.outElemBytes : kGbInvalid;
+	io.inSj = (uint32_t)p.inStrideJ * p.inElemBytes;
+	io.outSj = (uint32_t)p.outStrideJ * p.outElemBytes;
+	const GBuf glut = make_gbuf(p.lut);
+	uint32_t colIdx = 0;
+	if constexpr (POST == OP_TWIDDLE_4STEP) { if (p.fsColFromDim1) colIdx = g1; else { uint32_t rr; p.fsColDiv.divmod(g0, colIdx, rr); } }
+	op_stage<T, SCH, 0, TPF, PRE, POST>(lds + f * LDSPF, io, glut, tau, waveOnly, p, colIdx, g0 * p.opStride0 + g1 * p.opStride1);
+}
+
+// ---- registry ---------------------------------------------------------------------------------------------------
+struct OpfftVariant {
+	int n; bool dp; bool col; int pre, post; int rad[5]; int tpf; int fpw;
+	void (*launch)(const PassParams&, dim3, hipStream_t);
+};
+template <typename T, typename SCH, int TPF, int FPW, bool COL, int PRE, int POST> void opfft_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
+	hipLaunchKernelGGL((opfft_kernel<T, SCH, TPF, FPW, COL, PRE, POST>), grid, dim3(TPF * FPW), 0, s, prm);
+}
+#define VKFFT_OPX(T, dp, col, pre, post, r0, r1, r2, r3, r4, tpf, fpw) \
+	{ (r0) * (r1) * (r2) * (r3) * (r4), dp, col, pre, post, {r0, r1, r2, r3, r4}, tpf, fpw, &opfft_launch<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, col, pre, post> },
+
+} // namespace vkfft_mi355x

@@ -3,6 +3,7 @@
 #include "engine.h"
 #include "kernel_generic.h"
 #include "kernel_pow2.h"
+#include "kernel_opfft.h"
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -24,6 +25,8 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 		return launch_pow2(pp, prm, stream);
 	case KERNEL_MIXED_ROW:
 		return launch_mixed(pp, prm, stream);
+	case KERNEL_OPFFT:
+		return launch_opfft(pp, prm, stream);
 	case KERNEL_R2C_PAIR: {
 		const uint32_t npair = (prm.opN >> 2) + 1;
 		const uint64_t rows = (uint64_t)prm.dim[0].count * prm.dim[1].count * prm.dim[2].count;
@@ -46,6 +49,52 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	default:
 		return 4039;
 	}
+	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
+
+// ---- op-FFT registry: four table parts, one translation unit each (kernels_opfft_*.hip) ---------------------------
+const OpfftVariant* opfft_table_f32_row(int*);
+const OpfftVariant* opfft_table_f32_col(int*);
+const OpfftVariant* opfft_table_f64_row(int*);
+const OpfftVariant* opfft_table_f64_col(int*);
+static const OpfftVariant* opfft_part(int part, int* count) {
+	switch (part) {
+	case 0: return opfft_table_f32_row(count);
+	case 1: return opfft_table_f32_col(count);
+	case 2: return opfft_table_f64_row(count);
+	default: return opfft_table_f64_col(count);
+	}
+}
+static uint32_t opfft_family(uint32_t op) { // DST members run on the DCT instance of their family
+	switch (op) {
+	case OP_DST2_PRE: return OP_DCT2_PRE; case OP_DST2_POST: return OP_DCT2_POST;
+	case OP_DST3_PRE: return OP_DCT3_PRE; case OP_DST3_POST: return OP_DCT3_POST;
+	case OP_DST4_PRE: return OP_DCT4_PRE; case OP_DST4_POST: return OP_DCT4_POST;
+	default: return op;
+	}
+}
+bool opfft_lookup(uint64_t n, bool dp, bool col, uint32_t pre, uint32_t post, int* variant, int rad[5], int* fpw, int* threads) {
+	const int part = (dp ? 2 : 0) + (col ? 1 : 0);
+	int cnt = 0;
+	const OpfftVariant* tab = opfft_part(part, &cnt);
+	pre = opfft_family(pre); post = opfft_family(post);
+	for (int i = 0; i < cnt; i++) {
+		if ((uint64_t)tab[i].n != n || (uint32_t)tab[i].pre != pre || (uint32_t)tab[i].post != post) continue;
+		*variant = (part << 16) | i;
+		for (int k = 0; k < 5; k++) rad[k] = tab[i].rad[k];
+		*fpw = tab[i].fpw; *threads = tab[i].tpf * tab[i].fpw;
+		return true;
+	}
+	return false;
+}
+int launch_opfft(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
+	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
+	if (grid64 == 0) return 0;
+	int cnt = 0;
+	const OpfftVariant* tab = opfft_part(pp.variant >> 16, &cnt);
+	const int idx = pp.variant & 0xffff;
+	if (grid64 > 0x7fffffffull || pp.variant < 0 || idx >= cnt) return 4039;
+	tab[idx].launch(prm, dim3((uint32_t)grid64), stream);
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
 }
 

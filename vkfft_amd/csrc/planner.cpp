@@ -123,6 +123,7 @@ struct PassBuild {
 	std::vector<uint32_t> radices; // explicit stage radices (fast kernels fix their own schedule)
 	int fastKernel = KERNEL_GENERIC, fastVariant = -1, fastThreads = 0;
 	bool allowFast = true;
+	bool allowOp = false;   // op-FFT family (kernel_opfft.h): fused pre/post map kernels
 	bool noCollapse = false;
 	int chunkDim = -1;
 	uint64_t maxLds = 160 * 1024;
@@ -162,6 +163,20 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 			b.fastKernel = KERNEL_POW2_COL; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)tc;
 			b.radices.clear();
 			for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
+		}
+	}
+	// real transforms (fused pre/post map) and strided C2C of curated lengths: op-FFT family
+	if (b.allowOp && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && b.colIn == b.colOut && b.radices.empty()
+	    && !(b.preOp == OP_NONE && b.postOp == OP_NONE && !b.colIn)) {
+		const uint64_t ib = (b.realIn ? 1 : 2) * (b.dp ? 8 : 4), ob = (b.realOut ? 1 : 2) * (b.dp ? 8 : 4);
+		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
+		const uint64_t maxPos = std::max<uint64_t>(std::max<uint64_t>(b.L, b.inLen), std::max<uint64_t>(b.outLen, b.opN)) * 2 + 4;
+		const uint64_t spanIn = (maxPos * (uint64_t)std::llabs(b.inStrideJ) + 64 * (uint64_t)std::llabs(d0.inStride)) * ib;
+		const uint64_t spanOut = (maxPos * (uint64_t)std::llabs(b.outStrideJ) + 64 * (uint64_t)std::llabs(d0.outStride)) * ob;
+		int variant, rad5[5], fpw, thr;
+		if (spanIn < 0x7FFFFF00ull && spanOut < 0x7FFFFF00ull && opfft_lookup(b.L, b.dp, b.colIn, b.preOp, b.postOp, &variant, rad5, &fpw, &thr)) {
+			b.fastKernel = KERNEL_OPFFT; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
+			for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
 		}
 	}
 	PassParams& p = pp.prm;
@@ -274,32 +289,10 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	// workgroup tile
 	const bool anyCol = b.colIn || b.colOut;
 	uint32_t T;
-	// generic2 (register-direct, single LDS buffer, buffer addressing): every pass without Rader stages whose tile spans < 2 GiB
-	bool useG2 = false; // (a register-direct single-buffer interpreter was tried and dropped: the monolithic kernel spills)
-	for (size_t si = 0; si < rad.size(); si++) if (p.st[si].kind != 0 || rad[si] > 16) useG2 = false;
-	{
-		const uint64_t ib = (b.realIn ? 1 : 2) * (dp ? 8 : 4), ob = (b.realOut ? 1 : 2) * (dp ? 8 : 4);
-		const uint64_t maxPos = std::max<uint64_t>(std::max<uint64_t>(b.L, b.inLen), std::max<uint64_t>(b.outLen, b.opN)) * 2 + 4;
-		const uint64_t spanIn = (maxPos * (uint64_t)std::llabs(b.inStrideJ) + 64 * (uint64_t)std::llabs(dims[0].inStride)) * ib;
-		const uint64_t spanOut = (maxPos * (uint64_t)std::llabs(b.outStrideJ) + 64 * (uint64_t)std::llabs(dims[0].outStride)) * ob;
-		if (spanIn >= 0x7FFFFF00ull || spanOut >= 0x7FFFFF00ull) useG2 = false;
-	}
-	auto g2threads = [&](uint32_t TT) { // threads generic2 needs: every stage's butterflies fit P = 16/R per thread
-		uint64_t need = 64;
-		for (uint32_t R : rad) { const uint64_t P = std::min<uint64_t>(4, std::max<uint64_t>(1, 16 / R)); need = std::max<uint64_t>(need, ((b.L / R) * TT + P - 1) / P); }
-		return need;
-	};
-	uint64_t ldsPerSub = 0;
-	for (int attempt = 0; attempt < 2; attempt++) {
-	ldsPerSub = (useG2 ? 1 : 2) * (b.L + b.L / 16 + 2) * es; // one buffer (generic2) or both ping-pong buffers
+	// (a register-direct single-buffer interpreter was tried and dropped: the monolithic kernel spills)
+	const uint64_t ldsPerSub = 2 * (b.L + b.L / 16 + 2) * es; // both ping-pong buffers
 	if (b.forceT) T = b.forceT;
-	else if (anyCol && useG2) {
-		// strided tiles: 256-byte segments on the global side (real data: 64 columns of 4 bytes)
-		const bool realSide = b.realIn || b.realOut;
-		T = realSide ? (dp ? 32 : 64) : (dp ? 16 : 32);
-		while (T > 16 && (uint64_t)(T + 1) * ldsPerSub > b.maxLds / 2) T >>= 1; // two workgroups per CU when that keeps >= 16 columns
-		while (T > 1 && (uint64_t)(T + 1) * ldsPerSub > b.maxLds) T >>= 1;
-	} else if (anyCol) {
+	else if (anyCol) {
 		T = dp ? 16 : 32; // 256-byte segments
 		while (T > 1 && (uint64_t)(T + 1) * ldsPerSub > (b.maxLds * 7) / 10) T >>= 1; // leave room for two workgroups per CU when possible
 		while (T > 1 && (uint64_t)(T + 1) * ldsPerSub > b.maxLds) T >>= 1;
@@ -307,12 +300,6 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		// unit-stride rows: enough sub-FFTs for >= ~2048 points per workgroup
 		T = 1;
 		while (T < 64 && (uint64_t)T * b.L < 2048 && (uint64_t)(2 * T + 1) * ldsPerSub <= 64 * 1024) T <<= 1;
-	}
-	if (!useG2) break;
-	while (T > 1 && T / 2 >= dims[0].count) T >>= 1;
-	while (T > 1 && g2threads(T) > 1024) T >>= 1;
-	if (g2threads(T) <= 1024) break;
-	useG2 = false; // does not fit the register-direct kernel: plan for the ping-pong kernel instead
 	}
 	if (b.fastKernel == KERNEL_GENERIC) {
 		while (T > 1 && T / 2 >= dims[0].count) T >>= 1;
@@ -341,7 +328,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.ldsElems = (uint32_t)((padded + 1) * p.Tp);
 	p.tilesPerG0 = (uint32_t)((dims[0].count + T - 1) / T);
 	if (p.rd.P) { p.rd.tailElems = (uint32_t)((b.L / p.rd.P) * T + 1); p.rd.divU = make_fastdiv((uint32_t)((b.L / p.rd.P) * T)); }
-	pp.ldsBytes = ((useG2 ? 1 : 2) * (size_t)p.ldsElems + p.rd.tailElems) * es;
+	pp.ldsBytes = (2 * (size_t)p.ldsElems + p.rd.tailElems) * es;
 	if (pp.ldsBytes > b.maxLds && b.fastKernel == KERNEL_GENERIC) return 3002;
 	p.inElemBytes = (uint32_t)((b.realIn ? 1 : 2) * (dp ? 8 : 4));
 	p.outElemBytes = (uint32_t)((b.realOut ? 1 : 2) * (dp ? 8 : 4));
@@ -350,7 +337,6 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	uint32_t thr = 64;
 	while (thr < work && thr < 1024) thr <<= 1;
 	if (pp.ldsBytes > 48 * 1024 && thr < 256) thr = 256;
-	if (useG2) { thr = (uint32_t)((g2threads(T) + 63) / 64 * 64); if (thr < 64) thr = 64; }
 	pp.threads = thr;
 	pp.dp = dp;
 	pp.kernel = KERNEL_GENERIC;
@@ -644,7 +630,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	bool smoothOK = is_supported_len(j.N, dmax);
 	const uint64_t rowCap = max_row_len(dp, d.maxLds);
 	PassBuild b;
-	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax; b.allowFast = !d.disableFastKernels;
+	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax; b.allowFast = !d.disableFastKernels; b.allowOp = !d.disableFastKernels;
 	b.inRole = j.inRole; b.outRole = j.outRole;
 	out.axisSplit[j.axisIndex][0] = j.N;
 
@@ -808,7 +794,7 @@ static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vecto
 	const size_t es = dp ? 16 : 8;
 	const uint32_t dmax = direct_max(d);
 	PassBuild b;
-	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax; b.allowFast = false;
+	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax; b.allowFast = false; b.allowOp = !d.disableFastKernels;
 	b.opN = (uint32_t)N; b.scale = scale;
 	const bool even = (N % 2 == 0);
 	b.L = even ? N / 2 : N;
@@ -892,7 +878,7 @@ static int plan_r2r_axis(const TransformDesc& d, int type, bool dst, uint64_t N,
 	const size_t es = dp ? 16 : 8;
 	const uint32_t dmax = direct_max(d);
 	PassBuild b;
-	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax; b.allowFast = false;
+	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax; b.allowFast = false; b.allowOp = !d.disableFastKernels;
 	b.opN = (uint32_t)N; b.scale = scale;
 	b.realIn = b.realOut = true;
 	b.inLen = b.outLen = (uint32_t)N;
