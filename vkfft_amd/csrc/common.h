@@ -75,6 +75,12 @@ enum : uint32_t {
 	OP_BLUESTEIN_MID = 23,  // mid : pointwise * FFT(chirp), then the stage list runs again as inverse (vkFFT_Bluestein.h:201)
 	OP_BLUESTEIN_POST = 24, // post: x[k] *= conj(chirp[k]) for k < N
 	OP_MUL_LUT = 25,        // post: pointwise multiply by aux[j] (multi-pass Bluestein)
+	// DCT/DST-II and -III of even length N through ONE complex FFT of length N/2 (Makhoul permutation + the even R2C /
+	// C2R split fused with the quarter-wave twiddle): half the LDS footprint and arithmetic of the full-length form
+	OP_DCT2H_PRE = 26, OP_DCT2H_POST = 27,
+	OP_DCT3H_PRE = 28, OP_DCT3H_POST = 29,
+	OP_DST2H_PRE = 30, OP_DST2H_POST = 31,
+	OP_DST3H_PRE = 32, OP_DST3H_POST = 33,
 };
 
 struct StageDesc {

@@ -104,6 +104,7 @@ int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 // op-FFT family (kernel_opfft.h): pre/post are the DCT member of their family (DST variants share the instance)
 bool opfft_lookup(uint64_t n, bool dp, bool col, uint32_t pre, uint32_t post, int* variant, int rad[5], int* fpw, int* threads);
 int launch_opfft(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
+uint64_t opfft_next_len(uint64_t minLen, bool dp, bool col, uint32_t pre, uint32_t post); // smallest table length >= minLen of a family, 0: none
 
 // misc
 std::vector<uint32_t> factorize_radices(uint64_t n, bool* smooth);

@@ -31,8 +31,9 @@ template <typename T> struct Io64 {
 };
 template <typename T> struct Io32 {
 	GBuf gin, gout; uint32_t inOff, outOff, inSj, outSj; // byte offsets / byte strides; offsets = kGbInvalid for lanes of a partial tile
-	__device__ inline uint32_t ia(uint32_t j) const { return inOff >= kGbRange ? kGbInvalid : inOff + j * inSj; }
-	__device__ inline uint32_t oa(uint32_t j) const { return outOff >= kGbRange ? kGbInvalid : outOff + j * outSj; }
+	// lanes of a partial tile carry inOff = kGbInvalid: adding j * stride (< 2 GiB, planner span guard) keeps them out of range
+	__device__ inline uint32_t ia(uint32_t j) const { return inOff + j * inSj; }
+	__device__ inline uint32_t oa(uint32_t j) const { return outOff + j * outSj; }
 	__device__ inline cx<T> ldc(uint32_t j) const { return gb_load<T>(gin, ia(j), 0); }
 	__device__ inline T ldr(uint32_t j) const { return gb_load_real<T>(gin, ia(j), 0); }
 	__device__ inline void stc(uint32_t j, cx<T> v) const { gb_store<T>(gout, oa(j), 0, v); }
@@ -88,6 +89,25 @@ __device__ inline cx<T> pre_gather(const PassParams& p, const IO& io, uint32_t p
 		}
 		cx<T> w = cconj(((const cx<T>*)p.aux)[pos]);
 		return cmul(w, cx<T>{a, -b});
+	}
+	case OP_DCT2H_PRE: case OP_DST2H_PRE: { // L = N/2: z[n] = v[2n] + i v[2n+1], v = Makhoul permutation of x
+		const uint32_t N = p.opN, H = N >> 1;
+		const uint32_t j0 = 2 * pos, j1 = 2 * pos + 1;
+		const uint32_t s0 = j0 < H ? 2 * j0 : 2 * (N - 1 - j0) + 1, s1 = j1 < H ? 2 * j1 : 2 * (N - 1 - j1) + 1;
+		T a = io.ldr(s0), b = io.ldr(s1);
+		if (op == OP_DST2H_PRE) { if (s0 & 1) a = -a; if (s1 & 1) b = -b; }
+		return {a, b};
+	}
+	case OP_DCT3H_PRE: case OP_DST3H_PRE: { // L = N/2: Hermitian V_k = e^{+i pi k/2N}(x_k - i x_{N-k}) folded by the even C2R split
+		const uint32_t N = p.opN, H = N >> 1, m = H - pos;
+		const bool dst = op == OP_DST3H_PRE;
+		auto X = [&](uint32_t k) -> T { return k >= N ? (T)0 : io.ldr(dst ? N - 1 - k : k); }; // x_N = 0; DST-III reads the reversed input
+		const cx<T>* c = (const cx<T>*)p.aux;
+		const cx<T> a = cmul(cconj(c[pos]), cx<T>{X(pos), -X(N - pos)});
+		const cx<T> b = cconj(cmul(cconj(c[m]), cx<T>{X(m), -X(N - m)}));
+		const cx<T> w = cconj(((const cx<T>*)p.aux2)[pos]);
+		const cx<T> d = cmul(w, csub(a, b)), s2 = cadd(a, b);
+		return {s2.x - d.y, s2.y + d.x};
 	}
 	case OP_DCT1_PRE: { // even extension, L = 2N-2
 		const uint32_t N = p.opN, M = 2 * N - 2;
@@ -173,6 +193,26 @@ __device__ inline void post_store(const PassParams& p, const IO& io, uint32_t k,
 		const uint32_t m = (k & 1) ? N - 1 - (k >> 1) : (k >> 1);
 		T v = rd(m).x * sc;
 		if (op == OP_DST3_POST && (k & 1)) v = -v;
+		io.str(k, v);
+		return;
+	}
+	case OP_DCT2H_POST: case OP_DST2H_POST: { // k in [0, N/2]: y[k] = 2 Re(c^k V_k), y[N-k] = -2 Im(c^k V_k), V = even R2C split of Z
+		const uint32_t N = p.opN, H = N >> 1;
+		const bool dst = op == OP_DST2H_POST;
+		const cx<T> zk = rd(k == H ? 0 : k), zm = cconj(rd(k == 0 ? 0 : H - k));
+		const cx<T> w = ((const cx<T>*)p.aux2)[k];
+		const cx<T> s2 = cadd(zk, zm), d = cmul(w, csub(zk, zm));
+		const cx<T> t = cmul(((const cx<T>*)p.aux)[k], cx<T>{s2.x + d.y, s2.y - d.x}); // c^k * 2 V_k
+		io.str(dst ? N - 1 - k : k, sc * t.x);
+		if (k >= 1 && k < H) io.str(dst ? k - 1 : N - k, -sc * t.y);
+		return;
+	}
+	case OP_DCT3H_POST: case OP_DST3H_POST: { // gather form: output k <- v[m], v[2n] + i v[2n+1] = FFT output n
+		const uint32_t N = p.opN;
+		const uint32_t m = (k & 1) ? N - 1 - (k >> 1) : (k >> 1);
+		const cx<T> z = rd(m >> 1);
+		T v = ((m & 1) ? z.y : z.x) * sc;
+		if (op == OP_DST3H_POST && (k & 1)) v = -v;
 		io.str(k, v);
 		return;
 	}

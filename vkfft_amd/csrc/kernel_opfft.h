@@ -37,6 +37,12 @@ __device__ inline void post_scatter(const PassParams& p, const IO& io, const uin
 	case OP_DCT3_POST: case OP_DST3_POST:
 		post_store<T>(p, io, a < (N + 1) / 2 ? 2 * a : 2 * (N - 1 - a) + 1, colIdx, nat, rd, op);
 		return;
+	case OP_DCT3H_POST: case OP_DST3H_POST: { // FFT output a = v[2a] + i v[2a+1]; v[m] is output m < N/2 ? 2m : 2(N-1-m)+1
+		const uint32_t m0 = 2 * a, m1 = 2 * a + 1, H = N >> 1;
+		post_store<T>(p, io, m0 < H ? 2 * m0 : 2 * (N - 1 - m0) + 1, colIdx, nat, rd, op);
+		post_store<T>(p, io, m1 < H ? 2 * m1 : 2 * (N - 1 - m1) + 1, colIdx, nat, rd, op);
+		return;
+	}
 	case OP_DCT4_POST: case OP_DST4_POST:
 		if (p.L * 2 == N) { // half-length form: FFT output m feeds outputs 2m and N-1-2m
 			post_store<T>(p, io, 2 * a, colIdx, nat, rd, op);
@@ -51,6 +57,10 @@ template <int OP> __device__ inline uint32_t op_resolve(const uint32_t runtimeOp
 	if constexpr (OP == OP_DCT2_PRE) return runtimeOp == OP_DST2_PRE ? OP_DST2_PRE : OP_DCT2_PRE;
 	else if constexpr (OP == OP_DCT3_PRE) return runtimeOp == OP_DST3_PRE ? OP_DST3_PRE : OP_DCT3_PRE;
 	else if constexpr (OP == OP_DCT4_PRE) return runtimeOp == OP_DST4_PRE ? OP_DST4_PRE : OP_DCT4_PRE;
+	else if constexpr (OP == OP_DCT2H_PRE) return runtimeOp == OP_DST2H_PRE ? OP_DST2H_PRE : OP_DCT2H_PRE;
+	else if constexpr (OP == OP_DCT3H_PRE) return runtimeOp == OP_DST3H_PRE ? OP_DST3H_PRE : OP_DCT3H_PRE;
+	else if constexpr (OP == OP_DCT2H_POST) return runtimeOp == OP_DST2H_POST ? OP_DST2H_POST : OP_DCT2H_POST;
+	else if constexpr (OP == OP_DCT3H_POST) return runtimeOp == OP_DST3H_POST ? OP_DST3H_POST : OP_DCT3H_POST;
 	else if constexpr (OP == OP_DCT2_POST) return runtimeOp == OP_DST2_POST ? OP_DST2_POST : OP_DCT2_POST;
 	else if constexpr (OP == OP_DCT3_POST) return runtimeOp == OP_DST3_POST ? OP_DST3_POST : OP_DCT3_POST;
 	else if constexpr (OP == OP_DCT4_POST) return runtimeOp == OP_DST4_POST ? OP_DST4_POST : OP_DCT4_POST;
@@ -62,7 +72,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
                                 const uint32_t colIdx, const uint32_t nat) {
 	constexpr int N = SCH::N, R = SCH::rad[SI], NB = N / R, P = (NB + TPF - 1) / TPF, S = SCH::S(SI);
 	constexpr bool first = SI == 0, last = SI == SCH::NS - 1;
-	constexpr bool staged = POST == OP_R2C_EVEN_POST; // the post-map gathers from LDS
+	constexpr bool staged = POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST; // the post-map gathers from LDS
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	cx<T> x[P][R];
 #pragma unroll
@@ -113,8 +123,64 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 #pragma unroll
 		for (int b = 0; b < PO; b++) {
 			const uint32_t k = tau + b * TPF;
-			if (k < p.outLen) post_store<T>(p, io, k, colIdx, nat, rd, (uint32_t)POST);
+			if (k < p.outLen) post_store<T>(p, io, k, colIdx, nat, rd, op_resolve<POST>(p.postOp));
 		}
+	}
+}
+
+// Fused Bluestein (chirp-z) row: x[n] conj(chirp[n]) zero-padded to M -> FFT_M -> * FFT(chirp)/M -> inverse FFT_M through
+// the swap identity -> * conj(chirp[k]), k < N  — the single-pass form of the reference's vkFFT_Bluestein.h:32,201 on a
+// compile-time schedule of the padded length M.  REP = 0: forward half, REP = 1: inverse half.
+template <typename T, typename SCH, int SI, int TPF, int REP>
+__device__ inline void blue_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut, const GBuf gbhat, const uint32_t tau, const bool waveOnly, const PassParams& p, const uint32_t nat) {
+	constexpr int N = SCH::N, R = SCH::rad[SI], NB = N / R, P = (NB + TPF - 1) / TPF, S = SCH::S(SI);
+	constexpr bool first = SI == 0, last = SI == SCH::NS - 1;
+	constexpr bool fromGlobal = first && REP == 0, toGlobal = last && REP == 1;
+	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
+	cx<T> x[P][R];
+#pragma unroll
+	for (int b = 0; b < P; b++) {
+		const uint32_t t = tau + b * TPF;
+		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
+#pragma unroll
+			for (int i = 0; i < R; i++) {
+				if constexpr (fromGlobal) {
+					const cx<T> v = pre_gather<T>(p, io, t + i * NB, nat, (uint32_t)OP_BLUESTEIN_PRE);
+					x[b][i] = p.swapIn ? cswap(v) : v;
+				} else x[b][i] = ldsf[mix_slot(t + i * NB)];
+			}
+		}
+	}
+	if constexpr (!fromGlobal) { // all inputs are in registers before the buffer is overwritten
+		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+	}
+#pragma unroll
+	for (int b = 0; b < P; b++) {
+		const uint32_t t = tau + b * TPF;
+		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
+			const uint32_t s = t % (uint32_t)S;
+			if constexpr (!first) {
+				constexpr int LO = SCH::lutOff(SI);
+#pragma unroll
+				for (int i = 1; i < R; i++) x[b][i] = cmul(x[b][i], gb_load<T>(glut, s * ES, (uint32_t)(LO + (i - 1) * S) * ES));
+			}
+			dft<R, T>(x[b]);
+			const uint32_t ob = (t - s) * (uint32_t)R + s;
+#pragma unroll
+			for (int k = 0; k < R; k++) {
+				const uint32_t a = ob + k * S;
+				if constexpr (toGlobal) post_scatter<T>(p, io, a, cswap(x[b][k]), 0, nat, (uint32_t)OP_BLUESTEIN_POST);
+				else if constexpr (last) ldsf[mix_slot(a)] = cswap(cmul(x[b][k], gb_load<T>(gbhat, a * ES, 0))); // spectrum x FFT(chirp)/M, swapped for the inverse half
+				else ldsf[mix_slot(a)] = x[b][k];
+			}
+		}
+	}
+	if constexpr (!last) {
+		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		blue_stage<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, REP>(ldsf, io, glut, gbhat, tau, waveOnly, p, nat);
+	} else if constexpr (REP == 0) {
+		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		blue_stage<T, SCH, 0, TPF, 1>(ldsf, io, glut, gbhat, tau, waveOnly, p, nat);
 	}
 }
 
@@ -131,7 +197,7 @@ template <int N, int FPW, bool COL, bool NEEDS_LDS> __host__ __device__ constexp
 template <typename T, typename SCH, int TPF, int FPW, bool COL, int PRE, int POST>
 __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	constexpr int N = SCH::N;
-	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || POST == OP_R2C_EVEN_POST)>();
+	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST || PRE == OP_BLUESTEIN_PRE)>();
 	constexpr bool waveOnly = !COL && (TPF <= 64) && (64 % TPF == 0); // a row FFT that never straddles wavefronts
 	__shared__ cx<T> lds[FPW * LDSPF];
 	const uint32_t tid = threadIdx.x;
@@ -154,7 +220,13 @@ __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	const GBuf glut = make_gbuf(p.lut);
 	uint32_t colIdx = 0;
 	if constexpr (POST == OP_TWIDDLE_4STEP) { if (p.fsColFromDim1) colIdx = g1; else { uint32_t rr; p.fsColDiv.divmod(g0, colIdx, rr); } }
-	op_stage<T, SCH, 0, TPF, PRE, POST>(lds + f * LDSPF, io, glut, tau, waveOnly, p, colIdx, g0 * p.opStride0 + g1 * p.opStride1);
+	const uint32_t nat = g0 * p.opStride0 + g1 * p.opStride1;
+	cx<T>* ldsf = lds + f * LDSPF;
+	if constexpr (PRE == OP_BLUESTEIN_PRE) {
+		blue_stage<T, SCH, 0, TPF, 0>(ldsf, io, glut, make_gbuf(p.aux2), tau, waveOnly, p, nat);
+	} else {
+		op_stage<T, SCH, 0, TPF, PRE, POST>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
+	}
 }
 
 // ---- registry ---------------------------------------------------------------------------------------------------

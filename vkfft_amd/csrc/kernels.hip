@@ -70,6 +70,8 @@ static uint32_t opfft_family(uint32_t op) { // DST members run on the DCT instan
 	case OP_DST2_PRE: return OP_DCT2_PRE; case OP_DST2_POST: return OP_DCT2_POST;
 	case OP_DST3_PRE: return OP_DCT3_PRE; case OP_DST3_POST: return OP_DCT3_POST;
 	case OP_DST4_PRE: return OP_DCT4_PRE; case OP_DST4_POST: return OP_DCT4_POST;
+	case OP_DST2H_PRE: return OP_DCT2H_PRE; case OP_DST2H_POST: return OP_DCT2H_POST;
+	case OP_DST3H_PRE: return OP_DCT3H_PRE; case OP_DST3H_POST: return OP_DCT3H_POST;
 	default: return op;
 	}
 }
@@ -78,14 +80,22 @@ bool opfft_lookup(uint64_t n, bool dp, bool col, uint32_t pre, uint32_t post, in
 	int cnt = 0;
 	const OpfftVariant* tab = opfft_part(part, &cnt);
 	pre = opfft_family(pre); post = opfft_family(post);
-	for (int i = 0; i < cnt; i++) {
-		if ((uint64_t)tab[i].n != n || (uint32_t)tab[i].pre != pre || (uint32_t)tab[i].post != post) continue;
-		*variant = (part << 16) | i;
-		for (int k = 0; k < 5; k++) rad[k] = tab[i].rad[k];
-		*fpw = tab[i].fpw; *threads = tab[i].tpf * tab[i].fpw;
-		return true;
-	}
-	return false;
+	int first = -1;
+	for (int i = 0; i < cnt && first < 0; i++)
+		if ((uint64_t)tab[i].n == n && (uint32_t)tab[i].pre == pre && (uint32_t)tab[i].post == post) first = i;
+	if (first < 0) return false;
+	*variant = (part << 16) | first;
+	for (int k = 0; k < 5; k++) rad[k] = tab[first].rad[k];
+	*fpw = tab[first].fpw; *threads = tab[first].tpf * tab[first].fpw;
+	return true;
+}
+uint64_t opfft_next_len(uint64_t minLen, bool dp, bool col, uint32_t pre, uint32_t post) {
+	int cnt = 0;
+	const OpfftVariant* tab = opfft_part((dp ? 2 : 0) + (col ? 1 : 0), &cnt);
+	uint64_t best = 0;
+	for (int i = 0; i < cnt; i++)
+		if ((uint32_t)tab[i].pre == pre && (uint32_t)tab[i].post == post && (uint64_t)tab[i].n >= minLen && (!best || (uint64_t)tab[i].n < best)) best = (uint64_t)tab[i].n;
+	return best;
 }
 int launch_opfft(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;

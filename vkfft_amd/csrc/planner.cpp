@@ -166,7 +166,8 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		}
 	}
 	// real transforms (fused pre/post map) and strided C2C of curated lengths: op-FFT family
-	if (b.allowOp && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && b.colIn == b.colOut && b.radices.empty()
+	const bool fusedBluestein = b.preOp == OP_BLUESTEIN_PRE && b.midOp == OP_BLUESTEIN_MID && b.postOp == OP_BLUESTEIN_POST && !b.colIn && b.auxOff2ForPre == (size_t)-1;
+	if (b.allowOp && b.fastKernel == KERNEL_GENERIC && !b.forceT && (b.midOp == OP_NONE || fusedBluestein) && b.colIn == b.colOut && b.radices.empty()
 	    && !(b.preOp == OP_NONE && b.postOp == OP_NONE && !b.colIn)) {
 		const uint64_t ib = (b.realIn ? 1 : 2) * (b.dp ? 8 : 4), ob = (b.realOut ? 1 : 2) * (b.dp ? 8 : 4);
 		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
@@ -640,10 +641,17 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		std::vector<uint64_t> probe;
 		if (smoothOK && j.N > cap1 && !fastRow && !choose_split(j.N, dp, d.maxLds, dmax, !d.disableFastKernels, probe)) smoothOK = false;
 	}
-	if (!smoothOK) {
+	// lengths with a prime factor above 13 on unit-stride rows: the fused Bluestein kernel on a compile-time schedule of the
+	// padded length beats the interpreter's Rader stages (measured), so it also takes the Rader-capable lengths
+	uint64_t fusedM = 0;
+	if (unit && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N)) {
+		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
+		if ((rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull) fusedM = opfft_next_len(2 * j.N - 1, dp, false, OP_BLUESTEIN_PRE, OP_BLUESTEIN_POST);
+	}
+	if (!smoothOK || fusedM) {
 		// Bluestein (chirp-z) through a padded smooth length M >= 2N-1
 		const uint64_t N = j.N;
-		uint64_t M = d.forceBluesteinSize ? d.forceBluesteinSize : next_smooth(2 * N - 1, d.fixMaxRadixBluestein ? d.fixMaxRadixBluestein : 7);
+		uint64_t M = fusedM ? fusedM : d.forceBluesteinSize ? d.forceBluesteinSize : next_smooth(2 * N - 1, d.fixMaxRadixBluestein ? d.fixMaxRadixBluestein : 7);
 		uint64_t cap = unit ? rowCap : max_col_len(dp, d.maxLds, 1);
 		std::vector<uint64_t> spM;
 		if (M > cap) {
@@ -892,14 +900,27 @@ static int plan_r2r_axis(const TransformDesc& d, int type, bool dst, uint64_t N,
 		if (!dst) { if (N < 2) return 3004; b.L = 2 * N - 2; b.preOp = OP_DCT1_PRE; b.postOp = OP_DCT1_POST; }
 		else { b.L = 2 * N + 2; b.preOp = OP_DST1_PRE; b.postOp = OP_DST1_POST; }
 		break;
-	case 2: {
+	case 2: case 3: if (N % 2 == 0 && N >= 4) {
+		// even length: one complex FFT of length N/2 (Makhoul permutation + even R2C/C2R split + quarter-wave twiddle)
+		const uint64_t H = N / 2;
+		b.L = H;
+		if (type == 2) { b.preOp = dst ? OP_DST2H_PRE : OP_DCT2H_PRE; b.postOp = dst ? OP_DST2H_POST : OP_DCT2H_POST; b.outLen = (uint32_t)(H + 1); }
+		else { b.preOp = dst ? OP_DST3H_PRE : OP_DCT3H_PRE; b.postOp = dst ? OP_DST3H_POST : OP_DCT3H_POST; b.swapIn = b.swapOut = true; }
+		size_t aux = ar.alloc(N * es), aux2 = ar.alloc((H + 1) * es);
+		for (uint64_t k = 0; k < N; k++) ar.putc(aux, k, unit_root(k, 4 * N), dp);
+		for (uint64_t k = 0; k <= H; k++) ar.putc(aux2, k, unit_root(k, N), dp);
+		b.auxOff = aux; b.aux2Off = aux2;
+		break;
+	}
+	if (type == 3) goto full3;
+	{
 		b.L = N; b.preOp = dst ? OP_DST2_PRE : OP_DCT2_PRE; b.postOp = dst ? OP_DST2_POST : OP_DCT2_POST;
 		size_t aux = ar.alloc(N * es);
 		for (uint64_t k = 0; k < N; k++) ar.putc(aux, k, unit_root(k, 4 * N), dp);
 		b.auxOff = aux;
 		break;
 	}
-	case 3: {
+	full3: {
 		b.L = N; b.preOp = dst ? OP_DST3_PRE : OP_DCT3_PRE; b.postOp = dst ? OP_DST3_POST : OP_DCT3_POST;
 		b.swapIn = b.swapOut = true;
 		size_t aux = ar.alloc(N * es);
