@@ -83,11 +83,6 @@ def opfft_cases():
 
 def opfft_transform_of(fam, L, col):
     """(shape, kwargs of Runner.transform, real data?) of the smallest transform whose plan uses this table entry."""
-    if fam == "blue":  # fused Bluestein on padded length L: the largest prime whose 2N-1 fits
-        n = (L + 1) // 2
-        while any(n % q == 0 for q in range(2, int(n ** 0.5) + 1)):
-            n -= 1
-        return (n,), {}, False
     n = {"r2c": 2 * L, "c2r": 2 * L, "dct2": L, "dct3": L, "dct2h": 2 * L, "dct3h": 2 * L, "dct4": 2 * L, "dct1": L // 2 + 1, "dst1": L // 2 - 1, "c2c": L}[fam]
     kw = {"r2c": dict(r2c=True), "c2r": dict(r2c=True), "dct2": dict(dct=2), "dct3": dict(dct=3), "dct2h": dict(dct=2), "dct3h": dict(dct=3), "dct4": dict(dct=4), "dct1": dict(dct=1),
           "dst1": dict(dst=1), "c2c": {}}[fam]
@@ -100,8 +95,8 @@ def check_opfft_case(runner, oracle, fam, L, col, dp, load_elems=0):
     whose output must repeat the small-batch output bit for bit."""
     shape, kw, real = opfft_transform_of(fam, L, col)
     batch = 3
-    if fam in ("c2c", "blue"):
-        check_c2c(runner, oracle, shape, batch, dp, use_c_oracle=False, kind="bluestein" if fam == "blue" else "c2c")
+    if fam == "c2c":
+        check_c2c(runner, oracle, shape, batch, dp, use_c_oracle=False)
     elif fam in ("r2c", "c2r"):
         check_r2c(runner, oracle, shape, batch, dp)
     else:
@@ -109,7 +104,7 @@ def check_opfft_case(runner, oracle, fam, L, col, dp, load_elems=0):
     if load_elems:
         n = int(np.prod(shape))
         rng = np.random.default_rng(L)
-        if fam in ("c2c", "blue"):
+        if fam == "c2c":
             x = seeded_complex(n * batch, dp, L)
         elif fam in ("r2c", "c2r"):
             W = shape[0]

@@ -128,62 +128,6 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 	}
 }
 
-// Fused Bluestein (chirp-z) row: x[n] conj(chirp[n]) zero-padded to M -> FFT_M -> * FFT(chirp)/M -> inverse FFT_M through
-// the swap identity -> * conj(chirp[k]), k < N  — the single-pass form of the reference's vkFFT_Bluestein.h:32,201 on a
-// compile-time schedule of the padded length M.  REP = 0: forward half, REP = 1: inverse half.
-template <typename T, typename SCH, int SI, int TPF, int REP>
-__device__ inline void blue_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut, const GBuf gbhat, const uint32_t tau, const bool waveOnly, const PassParams& p, const uint32_t nat) {
-	constexpr int N = SCH::N, R = SCH::rad[SI], NB = N / R, P = (NB + TPF - 1) / TPF, S = SCH::S(SI);
-	constexpr bool first = SI == 0, last = SI == SCH::NS - 1;
-	constexpr bool fromGlobal = first && REP == 0, toGlobal = last && REP == 1;
-	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
-	cx<T> x[P][R];
-#pragma unroll
-	for (int b = 0; b < P; b++) {
-		const uint32_t t = tau + b * TPF;
-		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
-#pragma unroll
-			for (int i = 0; i < R; i++) {
-				if constexpr (fromGlobal) {
-					const cx<T> v = pre_gather<T>(p, io, t + i * NB, nat, (uint32_t)OP_BLUESTEIN_PRE);
-					x[b][i] = p.swapIn ? cswap(v) : v;
-				} else x[b][i] = ldsf[mix_slot(t + i * NB)];
-			}
-		}
-	}
-	if constexpr (!fromGlobal) { // all inputs are in registers before the buffer is overwritten
-		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
-	}
-#pragma unroll
-	for (int b = 0; b < P; b++) {
-		const uint32_t t = tau + b * TPF;
-		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
-			const uint32_t s = t % (uint32_t)S;
-			if constexpr (!first) {
-				constexpr int LO = SCH::lutOff(SI);
-#pragma unroll
-				for (int i = 1; i < R; i++) x[b][i] = cmul(x[b][i], gb_load<T>(glut, s * ES, (uint32_t)(LO + (i - 1) * S) * ES));
-			}
-			dft<R, T>(x[b]);
-			const uint32_t ob = (t - s) * (uint32_t)R + s;
-#pragma unroll
-			for (int k = 0; k < R; k++) {
-				const uint32_t a = ob + k * S;
-				if constexpr (toGlobal) post_scatter<T>(p, io, a, cswap(x[b][k]), 0, nat, (uint32_t)OP_BLUESTEIN_POST);
-				else if constexpr (last) ldsf[mix_slot(a)] = cswap(cmul(x[b][k], gb_load<T>(gbhat, a * ES, 0))); // spectrum x FFT(chirp)/M, swapped for the inverse half
-				else ldsf[mix_slot(a)] = x[b][k];
-			}
-		}
-	}
-	if constexpr (!last) {
-		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
-		blue_stage<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, REP>(ldsf, io, glut, gbhat, tau, waveOnly, p, nat);
-	} else if constexpr (REP == 0) {
-		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
-		blue_stage<T, SCH, 0, TPF, 1>(ldsf, io, glut, gbhat, tau, waveOnly, p, nat);
-	}
-}
-
 template <int N, int FPW, bool COL, bool NEEDS_LDS> __host__ __device__ constexpr int opfft_pitch() {
 	if (!NEEDS_LDS) return 1;
 	int pitch = N + (N >> 4) + 1;
@@ -197,7 +141,7 @@ template <int N, int FPW, bool COL, bool NEEDS_LDS> __host__ __device__ constexp
 template <typename T, typename SCH, int TPF, int FPW, bool COL, int PRE, int POST>
 __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	constexpr int N = SCH::N;
-	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST || PRE == OP_BLUESTEIN_PRE)>();
+	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST)>();
 	constexpr bool waveOnly = !COL && (TPF <= 64) && (64 % TPF == 0); // a row FFT that never straddles wavefronts
 	__shared__ cx<T> lds[FPW * LDSPF];
 	const uint32_t tid = threadIdx.x;
@@ -222,11 +166,7 @@ __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	if constexpr (POST == OP_TWIDDLE_4STEP) { if (p.fsColFromDim1) colIdx = g1; else { uint32_t rr; p.fsColDiv.divmod(g0, colIdx, rr); } }
 	const uint32_t nat = g0 * p.opStride0 + g1 * p.opStride1;
 	cx<T>* ldsf = lds + f * LDSPF;
-	if constexpr (PRE == OP_BLUESTEIN_PRE) {
-		blue_stage<T, SCH, 0, TPF, 0>(ldsf, io, glut, make_gbuf(p.aux2), tau, waveOnly, p, nat);
-	} else {
-		op_stage<T, SCH, 0, TPF, PRE, POST>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
-	}
+	op_stage<T, SCH, 0, TPF, PRE, POST>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
 }
 
 // ---- registry ---------------------------------------------------------------------------------------------------

@@ -164,6 +164,66 @@ inline unsigned pow2_persist_mult() { // tuning knob: resident-grid multiplier (
 	return (unsigned)m;
 }
 
+// ---- fused Bluestein (chirp-z) rows of length n <= M/2 on a power-of-two padded length M ---------------------------
+// x[j] conj(chirp[j]) zero-padded to M -> FFT_M -> * FFT(chirp)/M -> inverse FFT_M (swap identity) -> * conj(chirp[k]), k < n:
+// the single-kernel form of the reference's vkFFT_Bluestein.h:32,201.  Built on the register-resident Stockham core above: the
+// data never leaves registers between the two transforms, and because register m of a thread holds point tau + m*TPF on the
+// way in, at the spectrum and on the way out, the chirp and FFT(chirp) values a thread needs are the same for every row —
+// the workgroup is persistent (grid-stride over the row tiles) and keeps them in registers.
+template <typename T, typename SCH, int FPW>
+__global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_blue_kernel(const PassParams p) {
+	constexpr int LOGN = SCH::LOGN, M = 1 << LOGN, LOGE = SCH::LOGE, E = 1 << LOGE, TPF = M / E, EH = E / 2;
+	constexpr int LDSPF = SCH::NS > 1 ? M + (M >> LOGE) : 1;
+	constexpr bool waveOnly = TPF <= 64;
+	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
+	__shared__ cx<T> lds[FPW * LDSPF];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t f = tid / TPF, tau = tid % TPF;
+	const uint32_t n = p.opN;
+	const GBuf glut = make_gbuf(p.lut), gch = make_gbuf(p.aux), gbh = make_gbuf(p.aux2);
+	cx<T> ch[EH], bh[E];
+#pragma unroll
+	for (int m = 0; m < EH; m++) { const uint32_t pos = tau + m * TPF; ch[m] = gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0); }
+#pragma unroll
+	for (int m = 0; m < E; m++) bh[m] = gb_load<T>(gbh, (tau + m * TPF) * ES, 0);
+	const uint32_t tiles = p.tilesPerG0 * p.dim[1].count * p.dim[2].count;
+	const T sc = (T)p.scale;
+	for (uint32_t wgi = blockIdx.x; wgi < tiles; wgi += gridDim.x) {
+		uint32_t wg = wgi;
+		const uint32_t tile = wg % p.tilesPerG0;
+		wg /= p.tilesPerG0;
+		const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
+		const uint32_t f0 = tile * FPW;
+		const bool valid = f0 + f < p.dim[0].count;
+		const GBuf gin = make_gbuf((const cx<T>*)p.in + ((int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride));
+		const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride));
+		const uint32_t laneIn = valid ? (f * (uint32_t)p.dim[0].inStride + tau) * ES : kGbInvalid;
+		const uint32_t laneOut = valid ? (f * (uint32_t)p.dim[0].outStride + tau) * ES : kGbInvalid;
+		cx<T> v[E];
+#pragma unroll
+		for (int m = 0; m < EH; m++) { // points >= n are the zero padding (n <= M/2: they include every m >= E/2)
+			cx<T> x = gb_load<T>(gin, tau + m * TPF < n ? laneIn : kGbInvalid, (uint32_t)(m * TPF) * ES);
+			if (p.bluesteinSwapIn) x = cswap(x);
+			v[m] = cmulc(x, ch[m]);
+		}
+#pragma unroll
+		for (int m = EH; m < E; m++) v[m] = cx<T>{(T)0, (T)0};
+		pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], bh[m]));
+		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); } // the exchange buffer is reused
+		pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
+#pragma unroll
+		for (int m = 0; m < EH; m++) {
+			cx<T> x = cmulc(cswap(v[m]), ch[m]);
+			if (p.bluesteinSwapOut) x = cswap(x);
+			if (sc != (T)1) x = cscale(x, sc);
+			gb_store<T>(gout, tau + m * TPF < n ? laneOut : kGbInvalid, (uint32_t)(m * TPF) * ES, x);
+		}
+		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); }
+	}
+}
+
 // ---- strided-tile ("column") kernel: Four-Step passes and the non-unit-stride axes of 2D/3D transforms ----
 // A workgroup transforms TC neighbouring columns; lanes run across the columns so that every global
 // access is a TC*sizeof(complex) contiguous segment (256 B for TC=32 fp32).  Same register-resident
@@ -331,6 +391,41 @@ static const Pow2Variant kPow2ColVariants[] = {
 	VKFFT_P2C(double, true, 4, 3, 3, 0, 8),
 };
 constexpr int kNumPow2ColVariants = (int)(sizeof(kPow2ColVariants) / sizeof(kPow2ColVariants[0]));
+
+// fused Bluestein on a power-of-two padded length: one entry per (log2 M, dp)
+template <typename T, typename SCH, int FPW> void pow2_blue_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
+	constexpr int threads = ((1 << SCH::LOGN) >> SCH::LOGE) * FPW;
+	const unsigned resident = pow2_num_cus() * 8u; // persistent: the workgroups stride over the row tiles
+	hipLaunchKernelGGL((pow2_blue_kernel<T, SCH, FPW>), dim3(grid.x < resident ? grid.x : resident), dim3(threads), 0, s, prm);
+}
+#define VKFFT_P2B(T, dp, b0, b1, b2, b3, fpw) \
+	{ (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, fpw, (((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (fpw)), &pow2_blue_launch<T, Pow2Sched<b0, b1, b2, b3>, fpw> }
+static const Pow2Variant kPow2BlueVariants[] = {
+	VKFFT_P2B(float, false, 3, 3, 0, 0, 32),
+	VKFFT_P2B(float, false, 4, 3, 0, 0, 16),
+	VKFFT_P2B(float, false, 4, 4, 0, 0, 16),
+	VKFFT_P2B(float, false, 4, 3, 2, 0, 8),
+	VKFFT_P2B(float, false, 4, 3, 3, 0, 4),
+	VKFFT_P2B(float, false, 4, 4, 3, 0, 2),
+	VKFFT_P2B(float, false, 4, 4, 4, 0, 1),
+	VKFFT_P2B(float, false, 4, 3, 3, 3, 1),
+	VKFFT_P2B(double, true, 3, 3, 0, 0, 32),
+	VKFFT_P2B(double, true, 3, 2, 2, 0, 16),
+	VKFFT_P2B(double, true, 3, 3, 2, 0, 8),
+	VKFFT_P2B(double, true, 3, 3, 3, 0, 4),
+	VKFFT_P2B(double, true, 3, 3, 2, 2, 2),
+	VKFFT_P2B(double, true, 3, 3, 3, 2, 1),
+	VKFFT_P2B(double, true, 3, 3, 3, 3, 1),
+};
+constexpr int kNumPow2BlueVariants = (int)(sizeof(kPow2BlueVariants) / sizeof(kPow2BlueVariants[0]));
+
+inline int launch_pow2_blue(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
+	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
+	if (grid64 == 0) return 0;
+	if (grid64 > 0x7fffffffull || pp.variant < 0 || pp.variant >= kNumPow2BlueVariants) return 4039;
+	kPow2BlueVariants[pp.variant].launch(prm, dim3((uint32_t)grid64), stream);
+	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
 
 inline int launch_pow2(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;

@@ -23,6 +23,8 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	case KERNEL_POW2_ROW:
 	case KERNEL_POW2_COL:
 		return launch_pow2(pp, prm, stream);
+	case KERNEL_POW2_BLUE:
+		return launch_pow2_blue(pp, prm, stream);
 	case KERNEL_MIXED_ROW:
 		return launch_mixed(pp, prm, stream);
 	case KERNEL_OPFFT:
@@ -89,14 +91,6 @@ bool opfft_lookup(uint64_t n, bool dp, bool col, uint32_t pre, uint32_t post, in
 	*fpw = tab[first].fpw; *threads = tab[first].tpf * tab[first].fpw;
 	return true;
 }
-uint64_t opfft_next_len(uint64_t minLen, bool dp, bool col, uint32_t pre, uint32_t post) {
-	int cnt = 0;
-	const OpfftVariant* tab = opfft_part((dp ? 2 : 0) + (col ? 1 : 0), &cnt);
-	uint64_t best = 0;
-	for (int i = 0; i < cnt; i++)
-		if ((uint32_t)tab[i].pre == pre && (uint32_t)tab[i].post == post && (uint64_t)tab[i].n >= minLen && (!best || (uint64_t)tab[i].n < best)) best = (uint64_t)tab[i].n;
-	return best;
-}
 int launch_opfft(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
 	if (grid64 == 0) return 0;
@@ -131,6 +125,10 @@ bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fp
 }
 bool pow2_col_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* tc, int* threads) {
 	return pow2_lookup(kPow2ColVariants, kNumPow2ColVariants, "VKFFT_MI355X_P2C", log2n, dp, variant, bits, tc, threads);
+}
+
+bool pow2_blue_lookup(uint32_t log2m, bool dp, int* variant, int bits[4], int* fpw, int* threads) {
+	return pow2_lookup(kPow2BlueVariants, kNumPow2BlueVariants, "VKFFT_MI355X_P2B", log2m, dp, variant, bits, fpw, threads);
 }
 
 static int launch_with_hostloop(const PassPlan& pp, PassParams prm, hipStream_t stream, size_t level) {

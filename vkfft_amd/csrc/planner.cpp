@@ -167,7 +167,17 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	}
 	// real transforms (fused pre/post map) and strided C2C of curated lengths: op-FFT family
 	const bool fusedBluestein = b.preOp == OP_BLUESTEIN_PRE && b.midOp == OP_BLUESTEIN_MID && b.postOp == OP_BLUESTEIN_POST && !b.colIn && b.auxOff2ForPre == (size_t)-1;
-	if (b.allowOp && b.fastKernel == KERNEL_GENERIC && !b.forceT && (b.midOp == OP_NONE || fusedBluestein) && b.colIn == b.colOut && b.radices.empty()
+	if (fusedBluestein && b.allowOp && b.fastKernel == KERNEL_GENERIC && (b.L & (b.L - 1)) == 0 && !b.forceT && b.radices.empty()) { // power-of-two padded length: register-resident persistent kernel
+		int variant, bits[4], fpw, thr;
+		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
+		const uint64_t span = (b.L + 64 * (uint64_t)std::max<int64_t>(std::llabs(d0.inStride), std::llabs(d0.outStride))) * (b.dp ? 16 : 8);
+		if (span < 0x7FFFFF00ull && b.opN * 2 <= b.L && pow2_blue_lookup(ilog2(b.L), b.dp, &variant, bits, &fpw, &thr)) {
+			b.fastKernel = KERNEL_POW2_BLUE; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
+			b.radices.clear();
+			for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
+		}
+	}
+	if (b.allowOp && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && b.colIn == b.colOut && b.radices.empty()
 	    && !(b.preOp == OP_NONE && b.postOp == OP_NONE && !b.colIn)) {
 		const uint64_t ib = (b.realIn ? 1 : 2) * (b.dp ? 8 : 4), ob = (b.realOut ? 1 : 2) * (b.dp ? 8 : 4);
 		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
@@ -646,7 +656,9 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	uint64_t fusedM = 0;
 	if (unit && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N)) {
 		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
-		if ((rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull) fusedM = opfft_next_len(2 * j.N - 1, dp, false, OP_BLUESTEIN_PRE, OP_BLUESTEIN_POST);
+		uint64_t Mp = 64; while (Mp < 2 * j.N - 1) Mp *= 2; // measured: the power-of-two padded length wins even at 1.6x the {1,3,5}*2^k one
+		int v, bits[4], fpw, thr;
+		if ((rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && pow2_blue_lookup(ilog2(Mp), dp, &v, bits, &fpw, &thr)) fusedM = Mp;
 	}
 	if (!smoothOK || fusedM) {
 		// Bluestein (chirp-z) through a padded smooth length M >= 2N-1
