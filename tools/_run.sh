@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -x -q -m gpu -k "rader or bluestein or opfft" 2>&1 | tail -3
-for b in 1.4 0.5 10; do echo "BIAS=$b"; VKFFT_MI355X_BLUE_BIAS=$b NO_REF=1 timeout 600 python tools/perf_configs.py 10 14 2>&1 | grep "^{"; done | tee gpurun_out/perf_blue_ab.log
+( time timeout 1200 python -m pytest tests -x -q -m gpu -k "opfft or dct or dst" 2>&1 | tail -4 ) 2>&1 | tee gpurun_out/gpu_tests_opfft.log
+NO_REF=1 timeout 600 python tools/perf_configs.py 19 20 2>&1 | grep "^{" | tee gpurun_out/perf_configs_real.jsonl
+NO_REF=1 timeout 600 python tools/perf_configs.py 22 28 2>&1 | grep "^{" | tee -a gpurun_out/perf_configs_real.jsonl

@@ -67,24 +67,61 @@ template <int OP> __device__ inline uint32_t op_resolve(const uint32_t runtimeOp
 	else return (uint32_t)OP;
 }
 
-template <typename T, typename SCH, int SI, int TPF, int PRE, int POST>
+// Mirrored-pair wide access of the half-length DCT/DST-II/III on unit-stride rows.  With z[n] = v[2n] + i v[2n+1] and v the
+// Makhoul permutation of the real row, the four consecutive reals x[4n .. 4n+3] (n < H/2) are exactly
+//   (Re z[n], Im z[H-1-n], Im z[n], Re z[H-1-n]),
+// and H-1-n is input (output) R-1-i of butterfly NB-1-t when n is input (output) i of butterfly t.  A thread that owns the
+// butterfly pair (t, NB-1-t) of the first (last) stage therefore moves its 2R points with R 16-byte accesses and no index
+// arithmetic, instead of 2R strided 4-byte accesses.  Needs an even radix and an even number of butterflies per thread.
+template <typename SCH, int SI, int TPF> __host__ __device__ constexpr bool opfft_can_pair() {
+	constexpr int R = SCH::rad[SI], NB = SCH::N / R;
+	return (R % 2 == 0) && (NB % (2 * TPF) == 0);
+}
+// butterfly owned by slot b of thread tau: the plain map, or pairs (t, NB-1-t) in slots (b, b + P/2)
+template <int NB, int TPF, int P, bool PAIR> __device__ inline uint32_t opfft_bfly(const uint32_t tau, const int b) {
+	if constexpr (!PAIR) return tau + b * TPF;
+	else return b < P / 2 ? tau + b * TPF : (uint32_t)(NB - 1) - (tau + (b - P / 2) * TPF);
+}
+
+template <typename T, typename SCH, int SI, int TPF, int PRE, int POST, bool ROW>
 __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut, const uint32_t tau, const bool waveOnly, const PassParams& p,
                                 const uint32_t colIdx, const uint32_t nat) {
 	constexpr int N = SCH::N, R = SCH::rad[SI], NB = N / R, P = (NB + TPF - 1) / TPF, S = SCH::S(SI);
 	constexpr bool first = SI == 0, last = SI == SCH::NS - 1;
 	constexpr bool staged = POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST; // the post-map gathers from LDS
+	constexpr bool pairIn = ROW && first && PRE == OP_DCT2H_PRE && opfft_can_pair<SCH, SI, TPF>();
+	constexpr bool pairOut = ROW && last && POST == OP_DCT3H_POST && opfft_can_pair<SCH, SI, TPF>();
+	constexpr bool PAIR = pairIn || pairOut;
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	cx<T> x[P][R];
+	if constexpr (pairIn) {
+		const bool dst = p.preOp == OP_DST2H_PRE; // DST-II = DCT-II of (-1)^j x_j: the odd reals change sign
 #pragma unroll
-	for (int b = 0; b < P; b++) {
-		const uint32_t t = tau + b * TPF;
-		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
+		for (int b = 0; b < P; b++) {
+			const uint32_t t = opfft_bfly<NB, TPF, P, true>(tau, b);
+			constexpr int mirror = P / 2;
+			const int bm = b < mirror ? b + mirror : b - mirror; // slot of butterfly NB-1-t
 #pragma unroll
-			for (int i = 0; i < R; i++) {
-				if constexpr (first) {
-					const cx<T> v = pre_gather<T>(p, io, t + i * NB, nat, op_resolve<PRE>(p.preOp));
-					x[b][i] = p.swapIn ? cswap(v) : v;
-				} else x[b][i] = ldsf[mix_slot(t + i * NB)];
+			for (int i = 0; i < R / 2; i++) {
+				Real4<T> q = gb_load_real4<T>(io.gin, io.inOff + t * (2 * ES), (uint32_t)(i * NB) * (2 * ES));
+				if (dst) { q.y = -q.y; q.w = -q.w; }
+				const cx<T> a = {q.x, q.z}, m = {q.w, q.y};
+				x[b][i] = p.swapIn ? cswap(a) : a;
+				x[bm][R - 1 - i] = p.swapIn ? cswap(m) : m;
+			}
+		}
+	} else {
+#pragma unroll
+		for (int b = 0; b < P; b++) {
+			const uint32_t t = opfft_bfly<NB, TPF, P, PAIR>(tau, b);
+			if (PAIR || (b + 1) * TPF <= NB || t < (uint32_t)NB) {
+#pragma unroll
+				for (int i = 0; i < R; i++) {
+					if constexpr (first) {
+						const cx<T> v = pre_gather<T>(p, io, t + i * NB, nat, op_resolve<PRE>(p.preOp));
+						x[b][i] = p.swapIn ? cswap(v) : v;
+					} else x[b][i] = ldsf[mix_slot(t + i * NB)];
+				}
 			}
 		}
 	}
@@ -93,8 +130,8 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 	}
 #pragma unroll
 	for (int b = 0; b < P; b++) {
-		const uint32_t t = tau + b * TPF;
-		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
+		const uint32_t t = opfft_bfly<NB, TPF, P, PAIR>(tau, b);
+		if (PAIR || (b + 1) * TPF <= NB || t < (uint32_t)NB) {
 			const uint32_t s = t % (uint32_t)S;
 			if constexpr (!first) {
 				constexpr int LO = SCH::lutOff(SI);
@@ -102,20 +139,37 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 				for (int i = 1; i < R; i++) x[b][i] = cmul(x[b][i], gb_load<T>(glut, s * ES, (uint32_t)(LO + (i - 1) * S) * ES));
 			}
 			dft<R, T>(x[b]);
-			const uint32_t ob = (t - s) * (uint32_t)R + s;
+			if constexpr (!pairOut) {
+				const uint32_t ob = (t - s) * (uint32_t)R + s;
 #pragma unroll
-			for (int k = 0; k < R; k++) {
-				if constexpr (last) {
-					const cx<T> v = p.swapOut ? cswap(x[b][k]) : x[b][k];
-					if constexpr (staged) ldsf[mix_slot(ob + k * S)] = v;
-					else post_scatter<T>(p, io, ob + k * S, v, colIdx, nat, op_resolve<POST>(p.postOp));
-				} else ldsf[mix_slot(ob + k * S)] = x[b][k];
+				for (int k = 0; k < R; k++) {
+					if constexpr (last) {
+						const cx<T> v = p.swapOut ? cswap(x[b][k]) : x[b][k];
+						if constexpr (staged) ldsf[mix_slot(ob + k * S)] = v;
+						else post_scatter<T>(p, io, ob + k * S, v, colIdx, nat, op_resolve<POST>(p.postOp));
+					} else ldsf[mix_slot(ob + k * S)] = x[b][k];
+				}
+			}
+		}
+	}
+	if constexpr (pairOut) { // last stage: output k of butterfly t is point t + k*NB; four reals per 16-byte store
+		const bool dst = p.postOp == OP_DST3H_POST; // DST-III: odd outputs change sign
+		const T sc = (T)p.scale, so = dst ? -sc : sc;
+#pragma unroll
+		for (int b = 0; b < P; b++) {
+			const uint32_t t = opfft_bfly<NB, TPF, P, true>(tau, b);
+			constexpr int mirror = P / 2;
+			const int bm = b < mirror ? b + mirror : b - mirror;
+#pragma unroll
+			for (int k = 0; k < R / 2; k++) {
+				const cx<T> a = p.swapOut ? cswap(x[b][k]) : x[b][k], m = p.swapOut ? cswap(x[bm][R - 1 - k]) : x[bm][R - 1 - k];
+				gb_store_real4<T>(io.gout, io.outOff + t * (2 * ES), (uint32_t)(k * NB) * (2 * ES), Real4<T>{a.x * sc, m.y * so, a.y * sc, m.x * so});
 			}
 		}
 	}
 	if constexpr (!last) {
 		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
-		op_stage<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, PRE, POST>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
+		op_stage<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, PRE, POST, ROW>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
 	} else if constexpr (staged) {
 		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
 		constexpr int PO = (N + 1 + TPF - 1) / TPF; // R2C even split: N + 1 outputs from the length-N complex FFT
@@ -166,7 +220,7 @@ __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	if constexpr (POST == OP_TWIDDLE_4STEP) { if (p.fsColFromDim1) colIdx = g1; else { uint32_t rr; p.fsColDiv.divmod(g0, colIdx, rr); } }
 	const uint32_t nat = g0 * p.opStride0 + g1 * p.opStride1;
 	cx<T>* ldsf = lds + f * LDSPF;
-	op_stage<T, SCH, 0, TPF, PRE, POST>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
+	op_stage<T, SCH, 0, TPF, PRE, POST, !COL>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
 }
 
 // ---- registry ---------------------------------------------------------------------------------------------------

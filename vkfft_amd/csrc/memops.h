@@ -41,6 +41,17 @@ template <typename T> inline void gb_store_real(GBuf b, uint32_t voff, uint32_t 
 	if (voff >= kGbRange) return;
 	*(T*)(b.base + (uint64_t)voff + soff) = v;
 }
+template <typename T> struct Real4 { T x, y, z, w; };
+template <typename T> inline Real4<T> gb_load_real4(GBuf b, uint32_t voff, uint32_t soff) {
+	if (voff >= kGbRange) return Real4<T>{(T)0, (T)0, (T)0, (T)0};
+	const T* q = (const T*)(b.base + (uint64_t)voff + soff);
+	return Real4<T>{q[0], q[1], q[2], q[3]};
+}
+template <typename T> inline void gb_store_real4(GBuf b, uint32_t voff, uint32_t soff, Real4<T> v) {
+	if (voff >= kGbRange) return;
+	T* q = (T*)(b.base + (uint64_t)voff + soff);
+	q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+}
 #else
 typedef unsigned int vk_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int vk_u32x4 __attribute__((ext_vector_type(4)));
@@ -93,6 +104,26 @@ template <> __device__ inline void gb_store<double>(GBuf b, uint32_t voff, uint3
 	// the next VALU write to those VGPRs then corrupts the imaginary half under memory back-pressure.  Folding the
 	// scalar offset into the per-lane offset keeps the store in the form the compiler protects with s_nop.
 	__builtin_amdgcn_raw_buffer_store_b128(t, b.r, voff + soff, 0, 0);
+}
+// four consecutive reals (one 128-bit access for fp32, two for fp64; dword alignment is enough for buffer accesses)
+template <typename T> struct Real4 { T x, y, z, w; };
+template <typename T> __device__ inline Real4<T> gb_load_real4(GBuf b, uint32_t voff, uint32_t soff);
+template <> __device__ inline Real4<float> gb_load_real4<float>(GBuf b, uint32_t voff, uint32_t soff) {
+	vk_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, soff, 0);
+	return Real4<float>{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+}
+template <> __device__ inline Real4<double> gb_load_real4<double>(GBuf b, uint32_t voff, uint32_t soff) {
+	const cx<double> a = gb_load<double>(b, voff, soff), c = gb_load<double>(b, voff + 16u, soff);
+	return Real4<double>{a.x, a.y, c.x, c.y};
+}
+template <typename T> __device__ inline void gb_store_real4(GBuf b, uint32_t voff, uint32_t soff, Real4<T> v);
+template <> __device__ inline void gb_store_real4<float>(GBuf b, uint32_t voff, uint32_t soff, Real4<float> v) {
+	vk_u32x4 t; t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y); t.z = __float_as_uint(v.z); t.w = __float_as_uint(v.w);
+	__builtin_amdgcn_raw_buffer_store_b128(t, b.r, voff + soff, 0, 0); // soffset folded: see gb_store<double>
+}
+template <> __device__ inline void gb_store_real4<double>(GBuf b, uint32_t voff, uint32_t soff, Real4<double> v) {
+	gb_store<double>(b, voff, soff, cx<double>{v.x, v.y});
+	gb_store<double>(b, voff + 16u, soff, cx<double>{v.z, v.w});
 }
 #endif
 
