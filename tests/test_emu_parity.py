@@ -56,7 +56,7 @@ def test_opfft_table_entries(run, oracle, chunk):
     """Fused pre/post map kernels (R2C/C2R, DCT/DST, strided C2C): every entry up to L=128 and every 7th of the rest."""
     cases = _opfft_emu_cases()
     for fam, L, col, dp in cases[chunk::8]:
-        parity.check_opfft_case(run, oracle, fam, L, col, dp)
+        parity.check_opfft_case(run, oracle, fam, L, col, dp, max_points=1 << 17)
 
 
 @pytest.mark.parametrize("N", [17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 17 * 16, 31 * 9])

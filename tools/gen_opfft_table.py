@@ -25,7 +25,11 @@ FAMILIES = {
     "dct1": ("OP_DCT1_PRE", "OP_DCT1_POST", True, True, True, True),
     "dst1": ("OP_DST1_PRE", "OP_DST1_POST", True, True, True, True),
     "c2c": ("OP_NONE", "OP_NONE", False, False, True, False),
+    "c2c4": ("OP_NONE", "OP_TWIDDLE_4STEP", False, False, True, False),   # middle Four-Step pass: column FFT + twiddle, in place
+    "c2cT": ("OP_NONE", "OP_TWIDDLE_4STEP", False, False, True, False),   # first Four-Step pass: column FFT + twiddle + transposed store
 }
+# factor lengths of multi-pass plans of prime-power sizes (3^k, 5^k, 7^k, 11^k, 13^k: BASELINE config 3)
+FOURSTEP_EXTRA = [9, 27, 81, 25, 49, 11, 121, 1331, 13, 169, 2197]
 
 
 def pitch(n, fpw, col):
@@ -99,18 +103,19 @@ def main():
             lines = ["// GENERATED by tools/gen_opfft_table.py — do not edit.  VKFFT_OPX(type, dp, col, pre, post, R0..R4, threads per FFT, FFTs per workgroup)"]
             for fam, (pre, post, real, row_ok, col_ok, pow2only) in FAMILIES.items():
                 if (col and not col_ok) or (not col and not row_ok): continue
-                for n in sorted(lens):
+                fourstep = fam in ("c2c", "c2c4", "c2cT")
+                for n in sorted(set(lens) | (set(FOURSTEP_EXTRA) if fourstep and not dp else set())):
                     ispow2 = n & (n - 1) == 0
                     if pow2only and not ispow2: continue
                     if dp and n > 2048: continue
-                    if fam == "c2c" and ispow2 and n <= 1024: continue  # pow2_col_kernel covers these
+                    if fourstep and ispow2 and n <= 1024: continue  # pow2_col_kernel covers these
                     if fam in ("dct2", "dct3") and n % 2 == 0: continue  # even lengths take the half-length form
                     r = plan_col(n, dp, real) if col else plan_row(n, dp, {"dct2h": "first", "dct3h": "last"}.get(fam))
                     if r is None: continue
                     rad, tpf, fpw = r
                     rr = rad + [1] * (5 - len(rad))
-                    lines.append("VKFFT_OPX(%s, %s, %s, %s, %s, %d, %d, %d, %d, %d, %d, %d) // %s L=%d" %
-                                 (tname, "true" if dp else "false", "true" if col else "false", pre, post, *rr, tpf, fpw, fam, n))
+                    lines.append("VKFFT_OPX(%s, %s, %s, %s, %s, %d, %d, %d, %d, %d, %d, %d, %s) // %s L=%d" %
+                                 (tname, "true" if dp else "false", "true" if col else "false", pre, post, *rr, tpf, fpw, "true" if fam == "c2cT" else "false", fam, n))
                     total += 1
             open(os.path.join(root, "opfft_table_%s_%s.inc" % (tag, "col" if col else "row")), "w").write("\n".join(lines) + "\n")
     print("wrote", total, "entries")

@@ -103,7 +103,7 @@ bool pow2_blue_lookup(uint32_t log2m, bool dp, int* variant, int bits[4], int* f
 bool mixed_row_lookup(uint64_t n, bool dp, int* variant, int rad[5], int* fpw, int* threads);
 int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 // op-FFT family (kernel_opfft.h): pre/post are the DCT member of their family (DST variants share the instance)
-bool opfft_lookup(uint64_t n, bool dp, bool col, uint32_t pre, uint32_t post, int* variant, int rad[5], int* fpw, int* threads);
+bool opfft_lookup(uint64_t n, bool dp, bool col, bool trans, uint32_t pre, uint32_t post, int* variant, int rad[5], int* fpw, int* threads); // trans: column tile in, transposed (per-column contiguous) store out
 int launch_opfft(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 
 // misc

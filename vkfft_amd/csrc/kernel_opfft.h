@@ -83,12 +83,12 @@ template <int NB, int TPF, int P, bool PAIR> __device__ inline uint32_t opfft_bf
 	else return b < P / 2 ? tau + b * TPF : (uint32_t)(NB - 1) - (tau + (b - P / 2) * TPF);
 }
 
-template <typename T, typename SCH, int SI, int TPF, int PRE, int POST, bool ROW>
+template <typename T, typename SCH, int SI, int TPF, int PRE, int POST, bool ROW, bool TRANS>
 __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut, const uint32_t tau, const bool waveOnly, const PassParams& p,
                                 const uint32_t colIdx, const uint32_t nat) {
 	constexpr int N = SCH::N, R = SCH::rad[SI], NB = N / R, P = (NB + TPF - 1) / TPF, S = SCH::S(SI);
 	constexpr bool first = SI == 0, last = SI == SCH::NS - 1;
-	constexpr bool staged = POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST; // the post-map gathers from LDS
+	constexpr bool staged = POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST || TRANS; // the post-map (or the transposed store) gathers from LDS
 	constexpr bool pairIn = ROW && first && PRE == OP_DCT2H_PRE && opfft_can_pair<SCH, SI, TPF>();
 	constexpr bool pairOut = ROW && last && POST == OP_DCT3H_POST && opfft_can_pair<SCH, SI, TPF>();
 	constexpr bool PAIR = pairIn || pairOut;
@@ -169,8 +169,8 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 	}
 	if constexpr (!last) {
 		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
-		op_stage<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, PRE, POST, ROW>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
-	} else if constexpr (staged) {
+		op_stage<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, PRE, POST, ROW, TRANS>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
+	} else if constexpr (staged && !TRANS) {
 		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
 		constexpr int PO = (N + 1 + TPF - 1) / TPF; // R2C even split: N + 1 outputs from the length-N complex FFT
 		auto rd = [&](uint32_t a) { return ldsf[mix_slot(a)]; };
@@ -192,10 +192,11 @@ template <int N, int FPW, bool COL, bool NEEDS_LDS> __host__ __device__ constexp
 	return pitch;
 }
 
-template <typename T, typename SCH, int TPF, int FPW, bool COL, int PRE, int POST>
+template <typename T, typename SCH, int TPF, int FPW, bool COL, int PRE, int POST, bool TRANS>
 __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	constexpr int N = SCH::N;
-	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST)>();
+	static_assert(!TRANS || (COL && (POST == OP_NONE || POST == OP_TWIDDLE_4STEP)), "transposed store: first Four-Step pass of a column tile");
+	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || TRANS || POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST)>();
 	constexpr bool waveOnly = !COL && (TPF <= 64) && (64 % TPF == 0); // a row FFT that never straddles wavefronts
 	__shared__ cx<T> lds[FPW * LDSPF];
 	const uint32_t tid = threadIdx.x;
@@ -217,21 +218,45 @@ __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	io.outSj = (uint32_t)p.outStrideJ * p.outElemBytes;
 	const GBuf glut = make_gbuf(p.lut);
 	uint32_t colIdx = 0;
-	if constexpr (POST == OP_TWIDDLE_4STEP) { if (p.fsColFromDim1) colIdx = g1; else { uint32_t rr; p.fsColDiv.divmod(g0, colIdx, rr); } }
+	if constexpr (POST == OP_TWIDDLE_4STEP && !TRANS) { if (p.fsColFromDim1) colIdx = g1; else { uint32_t rr; p.fsColDiv.divmod(g0, colIdx, rr); } }
 	const uint32_t nat = g0 * p.opStride0 + g1 * p.opStride1;
 	cx<T>* ldsf = lds + f * LDSPF;
-	op_stage<T, SCH, 0, TPF, PRE, POST, !COL>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
+	op_stage<T, SCH, 0, TPF, PRE, POST, !COL, TRANS>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
+	if constexpr (TRANS) {
+		// first Four-Step pass: every column leaves as ONE contiguous run (Y^T[m][k0], reference vkFFT_ReadWrite.h:1405-1424);
+		// the tile is read back from LDS with lanes along the column so that the stores are contiguous, twiddle applied on the way
+		__syncthreads();
+		constexpr int NT = TPF * FPW, TOT = FPW * N, PT = (TOT + NT - 1) / NT;
+		constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
+		const uint32_t remain = p.dim[0].count - f0, nvalid = remain < (uint32_t)FPW ? remain : (uint32_t)FPW;
+		const T sc = (T)p.scale;
+#pragma unroll
+		for (int b = 0; b < PT; b++) {
+			const uint32_t idx = tid + b * NT;
+			if (TOT % NT == 0 || idx < (uint32_t)TOT) {
+				const uint32_t c = idx / (uint32_t)N, k = idx % (uint32_t)N;
+				cx<T> v = lds[c * LDSPF + mix_slot(k)];
+				if constexpr (POST == OP_TWIDDLE_4STEP) {
+					uint32_t ci = g1;
+					if (!p.fsColFromDim1) { uint32_t rr; p.fsColDiv.divmod(f0 + c, ci, rr); }
+					v = cmul(v, twiddle4<T>(p, k * ci));
+				}
+				if (sc != (T)1) v = cscale(v, sc);
+				gb_store<T>(io.gout, c < nvalid ? (c * (uint32_t)p.dim[0].outStride + k * (uint32_t)p.outStrideJ) * ES : kGbInvalid, 0, v);
+			}
+		}
+	}
 }
 
 // ---- registry ---------------------------------------------------------------------------------------------------
 struct OpfftVariant {
-	int n; bool dp; bool col; int pre, post; int rad[5]; int tpf; int fpw;
+	int n; bool dp; bool col; int pre, post; int rad[5]; int tpf; int fpw; bool trans;
 	void (*launch)(const PassParams&, dim3, hipStream_t);
 };
-template <typename T, typename SCH, int TPF, int FPW, bool COL, int PRE, int POST> void opfft_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
-	hipLaunchKernelGGL((opfft_kernel<T, SCH, TPF, FPW, COL, PRE, POST>), grid, dim3(TPF * FPW), 0, s, prm);
+template <typename T, typename SCH, int TPF, int FPW, bool COL, int PRE, int POST, bool TRANS> void opfft_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
+	hipLaunchKernelGGL((opfft_kernel<T, SCH, TPF, FPW, COL, PRE, POST, TRANS>), grid, dim3(TPF * FPW), 0, s, prm);
 }
-#define VKFFT_OPX(T, dp, col, pre, post, r0, r1, r2, r3, r4, tpf, fpw) \
-	{ (r0) * (r1) * (r2) * (r3) * (r4), dp, col, pre, post, {r0, r1, r2, r3, r4}, tpf, fpw, &opfft_launch<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, col, pre, post> },
+#define VKFFT_OPX(T, dp, col, pre, post, r0, r1, r2, r3, r4, tpf, fpw, trans) \
+	{ (r0) * (r1) * (r2) * (r3) * (r4), dp, col, pre, post, {r0, r1, r2, r3, r4}, tpf, fpw, trans, &opfft_launch<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, col, pre, post, trans> },
 
 } // namespace vkfft_mi355x

@@ -77,14 +77,14 @@ static uint32_t opfft_family(uint32_t op) { // DST members run on the DCT instan
 	default: return op;
 	}
 }
-bool opfft_lookup(uint64_t n, bool dp, bool col, uint32_t pre, uint32_t post, int* variant, int rad[5], int* fpw, int* threads) {
+bool opfft_lookup(uint64_t n, bool dp, bool col, bool trans, uint32_t pre, uint32_t post, int* variant, int rad[5], int* fpw, int* threads) {
 	const int part = (dp ? 2 : 0) + (col ? 1 : 0);
 	int cnt = 0;
 	const OpfftVariant* tab = opfft_part(part, &cnt);
 	pre = opfft_family(pre); post = opfft_family(post);
 	int first = -1;
 	for (int i = 0; i < cnt && first < 0; i++)
-		if ((uint64_t)tab[i].n == n && (uint32_t)tab[i].pre == pre && (uint32_t)tab[i].post == post) first = i;
+		if ((uint64_t)tab[i].n == n && (uint32_t)tab[i].pre == pre && (uint32_t)tab[i].post == post && tab[i].trans == trans) first = i;
 	if (first < 0) return false;
 	*variant = (part << 16) | first;
 	for (int k = 0; k < 5; k++) rad[k] = tab[first].rad[k];

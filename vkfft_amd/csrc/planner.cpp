@@ -177,7 +177,9 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 			for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
 		}
 	}
-	if (b.allowOp && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && b.colIn == b.colOut && b.radices.empty()
+	// (column tile in, per-column contiguous run out = the first Four-Step pass: the transposed-store variant)
+	const bool transOut = b.colIn && !b.colOut && b.preOp == OP_NONE && (b.postOp == OP_NONE || b.postOp == OP_TWIDDLE_4STEP) && b.outStrideJ == 1 && !b.realIn && !b.realOut;
+	if (b.allowOp && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && (b.colIn == b.colOut || transOut) && b.radices.empty()
 	    && !(b.preOp == OP_NONE && b.postOp == OP_NONE && !b.colIn)) {
 		const uint64_t ib = (b.realIn ? 1 : 2) * (b.dp ? 8 : 4), ob = (b.realOut ? 1 : 2) * (b.dp ? 8 : 4);
 		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
@@ -185,7 +187,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		const uint64_t spanIn = (maxPos * (uint64_t)std::llabs(b.inStrideJ) + 64 * (uint64_t)std::llabs(d0.inStride)) * ib;
 		const uint64_t spanOut = (maxPos * (uint64_t)std::llabs(b.outStrideJ) + 64 * (uint64_t)std::llabs(d0.outStride)) * ob;
 		int variant, rad5[5], fpw, thr;
-		if (spanIn < 0x7FFFFF00ull && spanOut < 0x7FFFFF00ull && opfft_lookup(b.L, b.dp, b.colIn, b.preOp, b.postOp, &variant, rad5, &fpw, &thr)) {
+		if (spanIn < 0x7FFFFF00ull && spanOut < 0x7FFFFF00ull && opfft_lookup(b.L, b.dp, b.colIn, transOut, b.preOp, b.postOp, &variant, rad5, &fpw, &thr)) {
 			b.fastKernel = KERNEL_OPFFT; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
 			for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
 		}
@@ -399,8 +401,31 @@ static bool is_supported_len(uint64_t L, uint32_t directMax) {
 
 // choose N = n[0]*n[1](*n[2]); n[0] is the pass that runs over the largest stride (executed first).
 // Preference order: two passes with wide tiles and two workgroups per CU, ..., three passes last.
+// a factor length the hand-specialised column kernels serve in all three Four-Step roles (first pass with transposed store,
+// middle pass with twiddle, last pass)
+static bool fast_col_len(uint64_t L, bool dp) {
+	int v, r5[5], bits[4], f, t;
+	if ((L & (L - 1)) == 0 && L >= 16 && L <= 1024) return pow2_col_lookup(ilog2(L), dp, &v, bits, &f, &t);
+	return opfft_lookup(L, dp, true, true, OP_NONE, OP_TWIDDLE_4STEP, &v, r5, &f, &t) && opfft_lookup(L, dp, true, false, OP_NONE, OP_TWIDDLE_4STEP, &v, r5, &f, &t)
+	       && opfft_lookup(L, dp, true, false, OP_NONE, OP_NONE, &v, r5, &f, &t);
+}
+
 static bool choose_split(uint64_t N, bool dp, uint64_t maxLds, uint32_t directMax, bool fast, std::vector<uint64_t>& out) {
 	const bool fastP2 = fast && (N & (N - 1)) == 0; // fast column kernels: single LDS buffer, L <= 1024
+	if (fast && !fastP2) { // non-power-of-two: prefer a split whose factors all run on hand-specialised column kernels
+		std::vector<uint64_t> fd;
+		for (uint64_t d = 2; d * d <= N; d++) if (N % d == 0) { fd.push_back(d); if (d != N / d) fd.push_back(N / d); }
+		std::sort(fd.begin(), fd.end());
+		uint64_t best = 0;
+		for (uint64_t d : fd) if (d <= N / d && fast_col_len(d, dp) && fast_col_len(N / d, dp)) best = d; // most balanced pair
+		if (best) { out = {N / best, best}; return true; }
+		uint64_t ba = 0, bb = 0; double bestCost = 1e300;
+		for (uint64_t a : fd) if (fast_col_len(a, dp)) for (uint64_t b2 : fd) if ((N / a) % b2 == 0 && N / a / b2 > 1 && fast_col_len(b2, dp) && fast_col_len(N / a / b2, dp)) {
+			const double m = (double)std::max(a, std::max(b2, N / a / b2));
+			if (m < bestCost) { bestCost = m; ba = a; bb = b2; }
+		}
+		if (ba) { out = {ba, bb, N / ba / bb}; return true; }
+	}
 	auto capOf = [&](uint32_t T, uint64_t budget) { uint64_t c = max_col_len(dp, fastP2 ? 2 * budget : budget, T); return fastP2 ? std::min<uint64_t>(c, 1024) : c; };
 	struct Opt { uint32_t T; uint64_t budget; };
 	const uint32_t Tw = dp ? 16 : 32;
