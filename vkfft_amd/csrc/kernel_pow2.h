@@ -224,6 +224,37 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 	}
 }
 
+// Four-Step twiddle w^(k*col), k = tau + m*TPF, of a thread's E points (reference vkFFT_4step.h:31): exponent
+// e_m = e_0 + m*D with D = TPF*col.  Instead of one table look-up (2 gathers of the two-level LUT) per element,
+// 2*sqrt(E)-1 look-ups feed a two-factor product.
+template <typename T, int LOGE, int TPF>
+__device__ inline void pow2_col_twiddle(cx<T>* v, const PassParams& p, const uint32_t tau, const uint32_t colIdx) {
+	constexpr int E = 1 << LOGE;
+	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
+	const GBuf gtab = make_gbuf(p.aux);
+	const uint32_t loMask = (1u << p.fsLoBits) - 1u;
+	const uint32_t hiBase = (loMask + 1u) * ES;
+	auto tw = [&](uint32_t e) { return cmul(gb_load<T>(gtab, (e & loMask) * ES, 0), gb_load<T>(gtab, (e >> p.fsLoBits) * ES, hiBase)); };
+	if (p.debugFlags & 8) {
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = cmul(v[m], tw((tau + m * TPF) * colIdx));
+	} else {
+		// m = (j << LOB) + i:  w^(e_0 + m*D) = A[j] * B[i],  A[j] = w^((tau + (j<<LOB)*TPF)*col),  B[i] = w^(i*TPF*col)
+		constexpr int HIB = (LOGE + 1) / 2, LOB = LOGE - HIB;
+		cx<T> A[1 << HIB], B[1 << LOB];
+#pragma unroll
+		for (int j = 0; j < (1 << HIB); j++) A[j] = tw((tau + (uint32_t)((j << LOB) * TPF)) * colIdx);
+		B[0] = cx<T>{(T)1, (T)0};
+#pragma unroll
+		for (int i = 1; i < (1 << LOB); i++) B[i] = tw((uint32_t)(i * TPF) * colIdx);
+		cx<T> wm[E];
+#pragma unroll
+		for (int m = 0; m < E; m++) wm[m] = (m & ((1 << LOB) - 1)) ? cmul(A[m >> LOB], B[m & ((1 << LOB) - 1)]) : A[m >> LOB];
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = cmul(v[m], wm[m]);
+	}
+}
+
 // ---- strided-tile ("column") kernel: Four-Step passes and the non-unit-stride axes of 2D/3D transforms ----
 // A workgroup transforms TC neighbouring columns; lanes run across the columns so that every global
 // access is a TC*sizeof(complex) contiguous segment (256 B for TC=32 fp32).  Same register-resident
@@ -265,32 +296,9 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 		for (int m = 0; m < E; m++) v[m] = cswap(v[m]);
 	}
 	if (p.postOp == OP_TWIDDLE_4STEP && !(p.debugFlags & 1)) {
-		// Four-Step twiddle w^(k*col), k = tau + m*TPF: exponent e_m = e_0 + m*D with D = TPF*col.  Instead of one
-		// table look-up (2 gathers of the two-level LUT) per element, 2*sqrt(E)-1 look-ups feed a two-factor product.
 		uint32_t colIdx, rr;
 		if (p.fsColFromDim1) colIdx = g1; else p.fsColDiv.divmod(col0 + c, colIdx, rr);
-		const GBuf gtab = make_gbuf(p.aux);
-		const uint32_t loMask = (1u << p.fsLoBits) - 1u;
-		const uint32_t hiBase = (loMask + 1u) * ES;
-		auto tw = [&](uint32_t e) { return cmul(gb_load<T>(gtab, (e & loMask) * ES, 0), gb_load<T>(gtab, (e >> p.fsLoBits) * ES, hiBase)); };
-		if (p.debugFlags & 8) {
-#pragma unroll
-			for (int m = 0; m < E; m++) v[m] = cmul(v[m], tw((tau + m * TPF) * colIdx));
-		} else {
-			// m = (j << LOB) + i:  w^(e_0 + m*D) = A[j] * B[i],  A[j] = w^((tau + (j<<LOB)*TPF)*col),  B[i] = w^(i*TPF*col)
-			constexpr int HIB = (LOGE + 1) / 2, LOB = LOGE - HIB;
-			cx<T> A[1 << HIB], B[1 << LOB];
-#pragma unroll
-			for (int j = 0; j < (1 << HIB); j++) A[j] = tw((tau + (uint32_t)((j << LOB) * TPF)) * colIdx);
-			B[0] = cx<T>{(T)1, (T)0};
-#pragma unroll
-			for (int i = 1; i < (1 << LOB); i++) B[i] = tw((uint32_t)(i * TPF) * colIdx);
-			cx<T> wm[E];
-#pragma unroll
-			for (int m = 0; m < E; m++) wm[m] = (m & ((1 << LOB) - 1)) ? cmul(A[m >> LOB], B[m & ((1 << LOB) - 1)]) : A[m >> LOB];
-#pragma unroll
-			for (int m = 0; m < E; m++) v[m] = cmul(v[m], wm[m]);
-		}
+		pow2_col_twiddle<T, LOGE, TPF>(v, p, tau, colIdx);
 	}
 	const T sc = (T)p.scale;
 	if (sc != (T)1) {
@@ -315,6 +323,103 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 			const uint32_t k = idx % L, cc = idx / L;
 			const uint32_t off = cc < nvalid ? (cc * (uint32_t)p.dim[0].outStride + k * (uint32_t)p.outStrideJ) * ES : kGbInvalid;
 			gb_store<T>(gout, off, 0, lds[k * TCP + cc]);
+		}
+	}
+}
+
+// ---- multi-pass Bluestein on a power-of-two padded length M = n0*n1 (both factors column-kernel lengths) ---------------
+// Three passes instead of the five of "Four-Step FFT_M, multiply, Four-Step inverse FFT_M" (cf. the reference's merged
+// convolution kernel, vkFFT_Convolution.h:125): with the transposed scratch layout T[m][k0] of the first Four-Step pass, the
+// second pass of the forward transform and the first pass of the inverse act on the SAME columns, so
+//   MODE 1: x[n] conj(chirp[n]) (zero for n >= N) -> column FFT over j0 (n = m + j0*n1) -> twiddle -> T[m][k0]      (N in, M out)
+//   MODE 2: column FFT over m -> * FFT(chirp)[k0 + n0*k1]/M -> inverse column FFT (swap identity) -> T[m][k0] in place (M, M)
+//   MODE 3: rows T[m][.] -> conj twiddle -> inverse FFT over k0 -> * conj(chirp[n]), n = m + j0*n1 < N -> y[n]        (M in, N out)
+// Same register-resident column core as pow2_col_kernel; MODE 3 loads its tile transposed through LDS (rows are contiguous
+// in T, lanes must run along m for the output side).
+template <typename T, typename SCH, int TC, int MODE>
+__global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col_blue_kernel(const PassParams p) {
+	constexpr int LOGN = SCH::LOGN, L = 1 << LOGN, LOGE = SCH::LOGE, E = 1 << LOGE, TPF = L / E;
+	constexpr int TCP = TC + 1, NT = TPF * TC;
+	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
+	__shared__ cx<T> lds[L * TCP];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t c = tid % TC, tau = tid / TC;
+	uint32_t wg = blockIdx.x;
+	const uint32_t tile = wg % p.tilesPerG0;
+	wg /= p.tilesPerG0;
+	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
+	const uint32_t col0 = tile * TC;
+	const bool valid = col0 + c < p.dim[0].count;
+	const uint32_t nvalid = p.dim[0].count - col0 < (uint32_t)TC ? p.dim[0].count - col0 : (uint32_t)TC;
+	const int64_t inB = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)col0 * p.dim[0].inStride;
+	const int64_t outB = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)col0 * p.dim[0].outStride;
+	const GBuf gin = make_gbuf((const cx<T>*)p.in + inB);
+	const GBuf gout = make_gbuf((cx<T>*)p.out + outB);
+	const GBuf glut = make_gbuf(p.lut);
+	const T sc = (T)p.scale;
+	cx<T> v[E];
+	if constexpr (MODE == 1) {
+		// element j0 = tau + m*TPF of column (col0 + c) is point n = (col0 + c) + j0 * inStrideJ of the length-opN row
+		const GBuf gch = make_gbuf(p.aux3);
+		const uint32_t stride = (uint32_t)p.inStrideJ;
+#pragma unroll
+		for (int m = 0; m < E; m++) {
+			const uint32_t n = col0 + c + (tau + m * TPF) * stride;
+			const bool in = valid && n < p.opN;
+			cx<T> x = gb_load<T>(gin, in ? (c + (tau + m * TPF) * stride) * ES : kGbInvalid, 0);
+			if (p.bluesteinSwapIn) x = cswap(x);
+			v[m] = cmulc(x, gb_load<T>(gch, in ? n * ES : kGbInvalid, 0));
+		}
+		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
+		pow2_col_twiddle<T, LOGE, TPF>(v, p, tau, col0 + c);
+		// transposed store: column c becomes the contiguous run T[col0 + c][.]
+		if constexpr (SCH::NS > 1) __syncthreads();
+#pragma unroll
+		for (int m = 0; m < E; m++) lds[(tau + m * TPF) * TCP + c] = v[m];
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < E; i++) {
+			const uint32_t idx = tid + i * NT;
+			const uint32_t k = idx % L, cc = idx / L;
+			gb_store<T>(gout, cc < nvalid ? (cc * (uint32_t)p.dim[0].outStride + k) * ES : kGbInvalid, 0, lds[k * TCP + cc]);
+		}
+	} else if constexpr (MODE == 2) {
+		const uint32_t lane = valid ? (tau * (uint32_t)p.inStrideJ + c) * ES : kGbInvalid;
+		const uint32_t step = (uint32_t)(TPF * (uint32_t)p.inStrideJ) * ES;
+		const GBuf gbh = make_gbuf((const cx<T>*)p.aux2 + col0); // FFT(chirp)/M at spectrum index (col0 + c) + n0 * k1
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = gb_load<T>(gin, lane, m * step);
+		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], gb_load<T>(gbh, lane, m * step)));
+		if constexpr (SCH::NS > 1) __syncthreads(); // the exchange buffer is reused
+		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
+#pragma unroll
+		for (int m = 0; m < E; m++) gb_store<T>(gout, lane, m * step, cswap(v[m]));
+	} else {
+		// rows (col0 + cc) of T are contiguous runs of L points: load them with lanes along the run, turn the tile in LDS
+#pragma unroll
+		for (int i = 0; i < E; i++) {
+			const uint32_t idx = tid + i * NT;
+			const uint32_t k = idx % L, cc = idx / L;
+			lds[k * TCP + cc] = gb_load<T>(gin, cc < nvalid ? (cc * (uint32_t)p.dim[0].inStride + k) * ES : kGbInvalid, 0);
+		}
+		__syncthreads();
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = cswap(lds[(tau + m * TPF) * TCP + c]);
+		if constexpr (SCH::NS > 1) __syncthreads(); // the tile is in registers before the exchanges overwrite it
+		pow2_col_twiddle<T, LOGE, TPF>(v, p, tau, col0 + c); // swap(u conj(w)) = swap(u) w: the forward table serves the inverse
+		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
+		const GBuf gch = make_gbuf(p.aux3);
+		const uint32_t stride = (uint32_t)p.outStrideJ;
+#pragma unroll
+		for (int m = 0; m < E; m++) {
+			const uint32_t n = col0 + c + (tau + m * TPF) * stride;
+			const bool in = valid && n < p.opN;
+			cx<T> y = cmulc(cswap(v[m]), gb_load<T>(gch, in ? n * ES : kGbInvalid, 0));
+			if (p.bluesteinSwapOut) y = cswap(y);
+			if (sc != (T)1) y = cscale(y, sc);
+			gb_store<T>(gout, in ? (c + (tau + m * TPF) * stride) * ES : kGbInvalid, 0, y);
 		}
 	}
 }
@@ -418,6 +523,37 @@ static const Pow2Variant kPow2BlueVariants[] = {
 	VKFFT_P2B(double, true, 3, 3, 3, 3, 1),
 };
 constexpr int kNumPow2BlueVariants = (int)(sizeof(kPow2BlueVariants) / sizeof(kPow2BlueVariants[0]));
+
+// multi-pass Bluestein column kernels: one entry per (log2 L, dp, mode); Pow2Variant::fpw holds the tile width
+template <typename T, typename SCH, int TC, int MODE> void pow2_col_blue_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
+	constexpr int threads = ((1 << SCH::LOGN) >> SCH::LOGE) * TC;
+	hipLaunchKernelGGL((pow2_col_blue_kernel<T, SCH, TC, MODE>), grid, dim3(threads), 0, s, prm);
+}
+struct Pow2ColBlueVariant { Pow2Variant v; int mode; };
+#define VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, mode) \
+	{ { (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, tc, (((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (tc)), &pow2_col_blue_launch<T, Pow2Sched<b0, b1, b2, b3>, tc, mode> }, mode }
+#define VKFFT_P2CB(T, dp, b0, b1, b2, b3, tc) VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 1), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 2), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 3)
+static const Pow2ColBlueVariant kPow2ColBlueVariants[] = {
+	VKFFT_P2CB(float, false, 3, 3, 0, 0, 32),
+	VKFFT_P2CB(float, false, 4, 3, 0, 0, 32),
+	VKFFT_P2CB(float, false, 4, 4, 0, 0, 32),
+	VKFFT_P2CB(float, false, 4, 3, 2, 0, 16),
+	VKFFT_P2CB(float, false, 4, 3, 3, 0, 16),
+	VKFFT_P2CB(double, true, 3, 3, 0, 0, 16),
+	VKFFT_P2CB(double, true, 3, 2, 2, 0, 16),
+	VKFFT_P2CB(double, true, 3, 3, 2, 0, 16),
+	VKFFT_P2CB(double, true, 3, 3, 3, 0, 8),
+	VKFFT_P2CB(double, true, 4, 3, 3, 0, 8),
+};
+constexpr int kNumPow2ColBlueVariants = (int)(sizeof(kPow2ColBlueVariants) / sizeof(kPow2ColBlueVariants[0]));
+
+inline int launch_pow2_col_blue(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
+	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
+	if (grid64 == 0) return 0;
+	if (grid64 > 0x7fffffffull || pp.variant < 0 || pp.variant >= kNumPow2ColBlueVariants) return 4039;
+	kPow2ColBlueVariants[pp.variant].v.launch(prm, dim3((uint32_t)grid64), stream);
+	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
 
 inline int launch_pow2_blue(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;

@@ -25,6 +25,8 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 		return launch_pow2(pp, prm, stream);
 	case KERNEL_POW2_BLUE:
 		return launch_pow2_blue(pp, prm, stream);
+	case KERNEL_POW2_COL_BLUE:
+		return launch_pow2_col_blue(pp, prm, stream);
 	case KERNEL_MIXED_ROW:
 		return launch_mixed(pp, prm, stream);
 	case KERNEL_OPFFT:
@@ -127,6 +129,17 @@ bool pow2_col_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* tc
 	return pow2_lookup(kPow2ColVariants, kNumPow2ColVariants, "VKFFT_MI355X_P2C", log2n, dp, variant, bits, tc, threads);
 }
 
+bool pow2_col_blue_lookup(uint32_t log2l, bool dp, int mode, int* variant, int bits[4], int* tc, int* threads) {
+	for (int i = 0; i < kNumPow2ColBlueVariants; i++) {
+		const Pow2ColBlueVariant& e = kPow2ColBlueVariants[i];
+		if (e.v.log2n != (int)log2l || e.v.dp != dp || e.mode != mode) continue;
+		*variant = i;
+		for (int k = 0; k < 4; k++) bits[k] = e.v.bits[k];
+		*tc = e.v.fpw; *threads = e.v.threads;
+		return true;
+	}
+	return false;
+}
 bool pow2_blue_lookup(uint32_t log2m, bool dp, int* variant, int bits[4], int* fpw, int* threads) {
 	return pow2_lookup(kPow2BlueVariants, kNumPow2BlueVariants, "VKFFT_MI355X_P2B", log2m, dp, variant, bits, fpw, threads);
 }

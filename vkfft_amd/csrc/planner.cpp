@@ -364,7 +364,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	}
 
 	// Four-Step two-level table
-	if (b.postOp == OP_TWIDDLE_4STEP) {
+	if (b.postOp == OP_TWIDDLE_4STEP || b.preOp == OP_FOURSTEP_INV_PRE) {
 		uint32_t lo = (ceil_log2(b.fsN) + 1) / 2;
 		uint64_t nlo = 1ull << lo, nhi = (b.fsN + nlo - 1) / nlo;
 		size_t off = ar.alloc((nlo + nhi) * es);
@@ -690,6 +690,11 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		const uint64_t N = j.N;
 		uint64_t M = fusedM ? fusedM : d.forceBluesteinSize ? d.forceBluesteinSize : next_smooth(2 * N - 1, d.fixMaxRadixBluestein ? d.fixMaxRadixBluestein : 7);
 		uint64_t cap = unit ? rowCap : max_col_len(dp, d.maxLds, 1);
+		if (unit && !fusedM && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein) {
+			// multi-pass rows: a power-of-two padded length runs as three passes on the column kernels (below)
+			uint64_t Mp = 1; while (Mp < 2 * N - 1) Mp *= 2;
+			if (Mp > cap && Mp <= (1ull << 20)) M = Mp;
+		}
 		std::vector<uint64_t> spM;
 		if (M > cap) {
 			if (!unit) return 3002;
@@ -722,6 +727,55 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 			}
 			for (uint64_t n = 0; n < N; n++) ar.putc(chirpOff, n, cChirp[n], dp);
 			for (uint64_t k = 0; k < M; k++) ar.putc(bhatOff, k, cBhat[k] / (ld)M, dp);
+		}
+		if (spM.size() == 2 && (M & (M - 1)) == 0 && !d.disableFastKernels) {
+			// power-of-two padded length whose two factors are column-kernel lengths: three passes (kernel_pow2.h,
+			// pow2_col_blue_kernel) — the middle one is FFT over m, * FFT(chirp), inverse FFT over m in registers
+			const uint64_t n0 = spM[0], n1 = M / n0;
+			int v1, v2, v3, bits1[4], bits2[4], bits3[4], tc1, tc2, tc3, th1, th2, th3;
+			if (pow2_col_blue_lookup(ilog2(n0), dp, 1, &v1, bits1, &tc1, &th1) && pow2_col_blue_lookup(ilog2(n1), dp, 2, &v2, bits2, &tc2, &th2)
+			    && pow2_col_blue_lookup(ilog2(n0), dp, 3, &v3, bits3, &tc3, &th3)) {
+				uint64_t nsub = 1;
+				for (auto& o : j.others) nsub *= o.count;
+				std::vector<HostDim> dense = j.others;
+				{ int64_t run = (int64_t)M; for (auto& o : dense) { o.inStride = o.outStride = run; run *= (int64_t)o.count; } }
+				auto withOthers = [&](HostDim tiled, int inKind, int outKind) { // 0: caller's layout, 1: dense scratch rows of M
+					std::vector<HostDim> r; r.push_back(tiled);
+					for (size_t i = 0; i < j.others.size(); i++) r.push_back({j.others[i].count, inKind ? dense[i].inStride : j.others[i].inStride, outKind ? dense[i].outStride : j.others[i].outStride});
+					return r;
+				};
+				auto setFast = [&](PassBuild& q, int variant, const int bits[4], int tc, int thr) {
+					q.fastKernel = KERNEL_POW2_COL_BLUE; q.fastVariant = variant; q.fastThreads = thr; q.forceT = (uint32_t)tc;
+					q.radices.clear();
+					for (int k = 0; k < 4; k++) if (bits[k]) q.radices.push_back(1u << bits[k]);
+					q.noCollapse = true;
+				};
+				PassBuild a = b;
+				a.L = n0; a.inStrideJ = (int64_t)n1; a.outStrideJ = 1; a.colIn = true; a.colOut = false;
+				a.dims = withOthers({n1, 1, (int64_t)n0}, 0, 1);
+				a.preOp = OP_BLUESTEIN_PRE; a.auxOff2ForPre = chirpOff; a.bsSwapIn = j.inverse; a.opN = (uint32_t)N; a.opStrideJ = (uint32_t)n1; a.opStride0 = 1;
+				a.postOp = OP_TWIDDLE_4STEP; a.fsN = M; a.fsColDiv = 1;
+				a.inRole = j.inRole; a.outRole = ROLE_TEMP; a.label = "bluestein-1";
+				setFast(a, v1, bits1, tc1, th1);
+				PassBuild m2 = b;
+				m2.L = n1; m2.inStrideJ = m2.outStrideJ = (int64_t)n0; m2.colIn = m2.colOut = true;
+				m2.dims = withOthers({n0, 1, 1}, 1, 1);
+				m2.midOp = OP_BLUESTEIN_MID; m2.aux2Off = bhatOff;
+				m2.inRole = m2.outRole = ROLE_TEMP; m2.label = "bluestein-2";
+				setFast(m2, v2, bits2, tc2, th2);
+				PassBuild c3 = b;
+				c3.L = n0; c3.inStrideJ = 1; c3.outStrideJ = (int64_t)n1; c3.colIn = c3.colOut = true;
+				c3.dims = withOthers({n1, (int64_t)n0, 1}, 1, 0);
+				c3.preOp = OP_FOURSTEP_INV_PRE; c3.fsN = M; c3.fsColDiv = 1;
+				c3.postOp = OP_BLUESTEIN_POST; c3.auxOff2ForPre = chirpOff; c3.bsSwapOut = j.inverse; c3.opN = (uint32_t)N; c3.opStrideJ = (uint32_t)n1; c3.opStride0 = 1;
+				c3.scale = j.scale;
+				c3.inRole = ROLE_TEMP; c3.outRole = j.outRole; c3.label = "bluestein-3";
+				setFast(c3, v3, bits3, tc3, th3);
+				for (PassBuild* q : {&a, &m2, &c3}) { PassPlan pp; int r = finish_pass(*q, ar, pp); if (r) return r; passes.push_back(pp); }
+				out.uploadsPerAxis[j.axisIndex] = 3;
+				out.tempBytes = std::max<uint64_t>(out.tempBytes, nsub * M * es);
+				return 0;
+			}
 		}
 		if (!spM.empty()) {
 			// multi-pass Bluestein: FFT_M (Four-Step) with the chirp fused into its first load and FFT(chirp) into its last
