@@ -8,7 +8,12 @@ OBJS := build/obj/api.o build/obj/planner.o build/obj/plan_real.o build/obj/kern
         build/obj/kernels_opfft_f32_row.o build/obj/kernels_opfft_f32_col.o build/obj/kernels_opfft_f64_row.o build/obj/kernels_opfft_f64_col.o
 HDRS := $(wildcard $(CSRC)/*.h) include/vkFFT.h
 
-all: $(LIBDIR)/libvkfft_mi355x.so
+all: $(LIBDIR)/libvkfft_mi355x.so build/vkfft_mi355x_cli
+
+# caller-side benchmark driver (flag-compatible in spirit with the reference's VkFFT_TestSuite): links the C-ABI only
+build/vkfft_mi355x_cli: tools/vkfft_cli.cpp include/vkFFT.h $(LIBDIR)/libvkfft_mi355x.so
+	@mkdir -p build
+	$(HIPCC) -O2 -std=c++17 -Wno-unused-value -Wno-unused-result -Iinclude tools/vkfft_cli.cpp -L$(LIBDIR) -lvkfft_mi355x -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -o $@
 
 build/obj/%.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p build/obj

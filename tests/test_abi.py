@@ -69,3 +69,13 @@ def test_no_cpu_fallback_without_gpu(product_lib):
     else:
         assert rc in (4051, 1002)  # FAILED_TO_GET_ATTRIBUTE / INVALID_DEVICE
         assert bytes(app) == bytes(C.sizeof(api.VkFFTApplication))  # app left zeroed, as the reference does on failure
+
+
+def test_cli_driver_builds_and_prints_usage(product_lib):
+    """tools/vkfft_cli.cpp (the counterpart of the reference's VkFFT_TestSuite flags) links the C-ABI and runs without a GPU
+    as far as its usage text; every other mode needs a device and says so."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", root, "build/vkfft_mi355x_cli"])
+    out = subprocess.run([os.path.join(root, "build", "vkfft_mi355x_cli"), "-h"], capture_output=True, text=True)
+    assert out.returncode == 0 and "-benchmark_vkfft" in out.stdout and "-vkfft <id>" in out.stdout

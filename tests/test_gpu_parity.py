@@ -290,3 +290,17 @@ def test_out_of_place_and_offsets(product_lib):
     assert rel_l2(out, np.fft.fft(x.astype(np.complex128).reshape(B, N), axis=1)) < 1e-6
     assert np.array_equal(src.cpu().numpy().view(np.complex64), x)
     app.delete()
+
+
+def test_cli_driver_on_device(product_lib):
+    """The caller-side benchmark driver: device self-check and one user-defined system through the public API."""
+    import os, re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", root, "build/vkfft_mi355x_cli"])
+    exe = os.path.join(root, "build", "vkfft_mi355x_cli")
+    out = subprocess.run([exe, "-test"], capture_output=True, text=True)
+    assert out.returncode == 0 and "PASS" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([exe, "-benchmark_vkfft", "-X", "4096", "-B", "4096", "-N", "5"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"scaled_bandwidth: ([0-9.]+) GB/s", out.stdout)
+    assert m and float(m.group(1)) > 100.0, out.stdout
