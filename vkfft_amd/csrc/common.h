@@ -152,8 +152,6 @@ struct PassParams {
 	uint32_t ldsElems;   // elements per LDS buffer (two buffers are used)
 	uint32_t tilesPerG0; // ceil(dim[0].count / T)
 	uint32_t inElemBytes, outElemBytes; // bytes per global element on each side (real scalar or complex)
-	uint32_t debugFlags; // development switches (VKFFT_MI355X_DEBUG): 1 skip 4-step twiddle, 2 sincospi twiddle, 4 skip transposed store
-	float fsInv2;        // 2 / fsN when the fp32 sincospi twiddle path is exact (power-of-two fsN <= 2^24), else 0
 };
 
 } // namespace vkfft_mi355x

@@ -235,24 +235,19 @@ __device__ inline void pow2_col_twiddle(cx<T>* v, const PassParams& p, const uin
 	const uint32_t loMask = (1u << p.fsLoBits) - 1u;
 	const uint32_t hiBase = (loMask + 1u) * ES;
 	auto tw = [&](uint32_t e) { return cmul(gb_load<T>(gtab, (e & loMask) * ES, 0), gb_load<T>(gtab, (e >> p.fsLoBits) * ES, hiBase)); };
-	if (p.debugFlags & 8) {
+	// m = (j << LOB) + i:  w^(e_0 + m*D) = A[j] * B[i],  A[j] = w^((tau + (j<<LOB)*TPF)*col),  B[i] = w^(i*TPF*col)
+	constexpr int HIB = (LOGE + 1) / 2, LOB = LOGE - HIB;
+	cx<T> A[1 << HIB], B[1 << LOB];
 #pragma unroll
-		for (int m = 0; m < E; m++) v[m] = cmul(v[m], tw((tau + m * TPF) * colIdx));
-	} else {
-		// m = (j << LOB) + i:  w^(e_0 + m*D) = A[j] * B[i],  A[j] = w^((tau + (j<<LOB)*TPF)*col),  B[i] = w^(i*TPF*col)
-		constexpr int HIB = (LOGE + 1) / 2, LOB = LOGE - HIB;
-		cx<T> A[1 << HIB], B[1 << LOB];
+	for (int j = 0; j < (1 << HIB); j++) A[j] = tw((tau + (uint32_t)((j << LOB) * TPF)) * colIdx);
+	B[0] = cx<T>{(T)1, (T)0};
 #pragma unroll
-		for (int j = 0; j < (1 << HIB); j++) A[j] = tw((tau + (uint32_t)((j << LOB) * TPF)) * colIdx);
-		B[0] = cx<T>{(T)1, (T)0};
+	for (int i = 1; i < (1 << LOB); i++) B[i] = tw((uint32_t)(i * TPF) * colIdx);
+	cx<T> wm[E];
 #pragma unroll
-		for (int i = 1; i < (1 << LOB); i++) B[i] = tw((uint32_t)(i * TPF) * colIdx);
-		cx<T> wm[E];
+	for (int m = 0; m < E; m++) wm[m] = (m & ((1 << LOB) - 1)) ? cmul(A[m >> LOB], B[m & ((1 << LOB) - 1)]) : A[m >> LOB];
 #pragma unroll
-		for (int m = 0; m < E; m++) wm[m] = (m & ((1 << LOB) - 1)) ? cmul(A[m >> LOB], B[m & ((1 << LOB) - 1)]) : A[m >> LOB];
-#pragma unroll
-		for (int m = 0; m < E; m++) v[m] = cmul(v[m], wm[m]);
-	}
+	for (int m = 0; m < E; m++) v[m] = cmul(v[m], wm[m]);
 }
 
 // ---- strided-tile ("column") kernel: Four-Step passes and the non-unit-stride axes of 2D/3D transforms ----
@@ -295,7 +290,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = cswap(v[m]);
 	}
-	if (p.postOp == OP_TWIDDLE_4STEP && !(p.debugFlags & 1)) {
+	if (p.postOp == OP_TWIDDLE_4STEP) {
 		uint32_t colIdx, rr;
 		if (p.fsColFromDim1) colIdx = g1; else p.fsColDiv.divmod(col0 + c, colIdx, rr);
 		pow2_col_twiddle<T, LOGE, TPF>(v, p, tau, colIdx);

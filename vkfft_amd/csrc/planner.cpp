@@ -332,8 +332,6 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.fsN = (uint32_t)b.fsN;
 	p.fsColDiv = make_fastdiv(b.fsColDiv);
 	p.fsColFromDim1 = b.fsColFromDim1 ? 1 : 0;
-	p.fsInv2 = (b.fsN && (b.fsN & (b.fsN - 1)) == 0 && b.fsN <= (1ull << 24) && !b.dp) ? (float)(2.0 / (double)b.fsN) : 0.f; // sincospi path only where exact
-	if (const char* e = getenv("VKFFT_MI355X_DEBUG")) p.debugFlags = (uint32_t)atoi(e);
 	p.scale = b.scale;
 	p.divL = make_fastdiv((uint32_t)b.L);
 	p.divOutLen = make_fastdiv(p.outLen);
