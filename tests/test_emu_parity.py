@@ -78,6 +78,13 @@ def test_bluestein(run, oracle, N, dp):
     parity.check_c2c(run, oracle, (N,), 2, dp, kind="bluestein")
 
 
+@pytest.mark.parametrize("N,dp,uploads", [(4099, False, 3), (15319, False, 3), (21269, True, 3), (524309, False, 5)])
+def test_bluestein_multi_pass_fused(run, oracle, N, dp, uploads):
+    """Rows whose padded power-of-two length needs two / three column factors: 3 / 5 passes (pow2_col_blue_kernel)."""
+    up = parity.check_c2c(run, oracle, (N,), 2 if N < 100000 else 1, dp, kind="bluestein", use_c_oracle=False)
+    assert up == [uploads]
+
+
 @pytest.mark.parametrize("N,passes", [(1 << 15, 2), (1 << 16, 2), (1 << 18, 2), (3 ** 10, 2), (1 << 21, 3), (5 ** 9, 3)])
 def test_fourstep(run, oracle, N, passes):
     up = parity.check_c2c(run, oracle, (N,), 1, False, use_c_oracle=N <= (1 << 16))

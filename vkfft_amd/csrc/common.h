@@ -81,6 +81,7 @@ enum : uint32_t {
 	OP_DCT3H_PRE = 28, OP_DCT3H_POST = 29,
 	OP_DST2H_PRE = 30, OP_DST2H_POST = 31,
 	OP_DST3H_PRE = 32, OP_DST3H_POST = 33,
+	OP_FOURSTEP_INV_COL_PRE = 35, // pre : column layout, swap, Four-Step twiddle (middle pass of a three-factor inverse run backwards)
 	OP_FOURSTEP_INV_PRE = 34, // pre : rows of the transposed Four-Step scratch, swap, Four-Step twiddle (first pass of the inverse run backwards)
 };
 

@@ -329,6 +329,8 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 //   MODE 1: x[n] conj(chirp[n]) (zero for n >= N) -> column FFT over j0 (n = m + j0*n1) -> twiddle -> T[m][k0]      (N in, M out)
 //   MODE 2: column FFT over m -> * FFT(chirp)[k0 + n0*k1]/M -> inverse column FFT (swap identity) -> T[m][k0] in place (M, M)
 //   MODE 3: rows T[m][.] -> conj twiddle -> inverse FFT over k0 -> * conj(chirp[n]), n = m + j0*n1 < N -> y[n]        (M in, N out)
+// Three factors M = n0*n1*n2 (rows up to 2^29 points): five passes — MODE 1, the plain middle Four-Step pass (pow2_col_kernel),
+// MODE 2 on the innermost factor, MODE 4 = the middle pass run backwards (conj twiddle, inverse column FFT, in place), MODE 3.
 // Same register-resident column core as pow2_col_kernel; MODE 3 loads its tile transposed through LDS (rows are contiguous
 // in T, lanes must run along m for the output side).
 template <typename T, typename SCH, int TC, int MODE>
@@ -381,13 +383,28 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 	} else if constexpr (MODE == 2) {
 		const uint32_t lane = valid ? (tau * (uint32_t)p.inStrideJ + c) * ES : kGbInvalid;
 		const uint32_t step = (uint32_t)(TPF * (uint32_t)p.inStrideJ) * ES;
-		const GBuf gbh = make_gbuf((const cx<T>*)p.aux2 + col0); // FFT(chirp)/M at spectrum index (col0 + c) + n0 * k1
+		// FFT(chirp)/M at the natural spectrum index of output k of column (g0, g1): k*opStrideJ + g0*opStride0 + g1*opStride1
+		const GBuf gbh = make_gbuf(p.aux2);
+		const uint32_t bhLane = valid ? (tau * p.opStrideJ + (col0 + c) * p.opStride0 + g1 * p.opStride1) * ES : kGbInvalid;
+		const uint32_t bhStep = (uint32_t)TPF * p.opStrideJ * ES;
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = gb_load<T>(gin, lane, m * step);
 		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
 #pragma unroll
-		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], gb_load<T>(gbh, lane, m * step)));
+		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], gb_load<T>(gbh, bhLane, m * bhStep)));
 		if constexpr (SCH::NS > 1) __syncthreads(); // the exchange buffer is reused
+		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
+#pragma unroll
+		for (int m = 0; m < E; m++) gb_store<T>(gout, lane, m * step, cswap(v[m]));
+	} else if constexpr (MODE == 4) {
+		// middle pass of a three-factor inverse run backwards, in place in the column layout: conj twiddle, inverse column FFT
+		const uint32_t lane = valid ? (tau * (uint32_t)p.inStrideJ + c) * ES : kGbInvalid;
+		const uint32_t step = (uint32_t)(TPF * (uint32_t)p.inStrideJ) * ES;
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = cswap(gb_load<T>(gin, lane, m * step));
+		uint32_t colIdx, rr;
+		p.fsColDiv.divmod(col0 + c, colIdx, rr);
+		pow2_col_twiddle<T, LOGE, TPF>(v, p, tau, colIdx); // swap(u conj(w)) = swap(u) w
 		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
 #pragma unroll
 		for (int m = 0; m < E; m++) gb_store<T>(gout, lane, m * step, cswap(v[m]));
@@ -527,7 +544,7 @@ template <typename T, typename SCH, int TC, int MODE> void pow2_col_blue_launch(
 struct Pow2ColBlueVariant { Pow2Variant v; int mode; };
 #define VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, mode) \
 	{ { (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, tc, (((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (tc)), &pow2_col_blue_launch<T, Pow2Sched<b0, b1, b2, b3>, tc, mode> }, mode }
-#define VKFFT_P2CB(T, dp, b0, b1, b2, b3, tc) VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 1), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 2), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 3)
+#define VKFFT_P2CB(T, dp, b0, b1, b2, b3, tc) VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 1), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 2), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 3), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 4)
 static const Pow2ColBlueVariant kPow2ColBlueVariants[] = {
 	VKFFT_P2CB(float, false, 3, 3, 0, 0, 32),
 	VKFFT_P2CB(float, false, 4, 3, 0, 0, 32),

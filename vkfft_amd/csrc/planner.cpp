@@ -362,7 +362,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	}
 
 	// Four-Step two-level table
-	if (b.postOp == OP_TWIDDLE_4STEP || b.preOp == OP_FOURSTEP_INV_PRE) {
+	if (b.postOp == OP_TWIDDLE_4STEP || b.preOp == OP_FOURSTEP_INV_PRE || b.preOp == OP_FOURSTEP_INV_COL_PRE) {
 		uint32_t lo = (ceil_log2(b.fsN) + 1) / 2;
 		uint64_t nlo = 1ull << lo, nhi = (b.fsN + nlo - 1) / nlo;
 		size_t off = ar.alloc((nlo + nhi) * es);
@@ -691,7 +691,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		if (unit && !fusedM && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein) {
 			// multi-pass rows: a power-of-two padded length runs as three passes on the column kernels (below)
 			uint64_t Mp = 1; while (Mp < 2 * N - 1) Mp *= 2;
-			if (Mp > cap && Mp <= (1ull << 20)) M = Mp;
+			if (Mp > cap && Mp <= (1ull << 29)) M = Mp;
 		}
 		std::vector<uint64_t> spM;
 		if (M > cap) {
@@ -758,7 +758,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 				PassBuild m2 = b;
 				m2.L = n1; m2.inStrideJ = m2.outStrideJ = (int64_t)n0; m2.colIn = m2.colOut = true;
 				m2.dims = withOthers({n0, 1, 1}, 1, 1);
-				m2.midOp = OP_BLUESTEIN_MID; m2.aux2Off = bhatOff;
+				m2.midOp = OP_BLUESTEIN_MID; m2.aux2Off = bhatOff; m2.opStrideJ = (uint32_t)n0; m2.opStride0 = 1; m2.opStride1 = 0;
 				m2.inRole = m2.outRole = ROLE_TEMP; m2.label = "bluestein-2";
 				setFast(m2, v2, bits2, tc2, th2);
 				PassBuild c3 = b;
@@ -771,6 +771,67 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 				setFast(c3, v3, bits3, tc3, th3);
 				for (PassBuild* q : {&a, &m2, &c3}) { PassPlan pp; int r = finish_pass(*q, ar, pp); if (r) return r; passes.push_back(pp); }
 				out.uploadsPerAxis[j.axisIndex] = 3;
+				out.tempBytes = std::max<uint64_t>(out.tempBytes, nsub * M * es);
+				return 0;
+			}
+		}
+		if (spM.size() == 3 && (M & (M - 1)) == 0 && !d.disableFastKernels) {
+			// three factors: five passes (see pow2_col_blue_kernel) instead of the seven of two Four-Step transforms + multiply
+			const uint64_t n0 = spM[0], n1 = spM[1], n2 = spM[2], M1 = n1 * n2;
+			int v1, v3, v4, v5, vb, bits1[4], bits3[4], bits4[4], bits5[4], bitsb[4], tc1, tc3, tc4, tc5, tcb, th1, th3, th4, th5, thb;
+			if (pow2_col_blue_lookup(ilog2(n0), dp, 1, &v1, bits1, &tc1, &th1) && pow2_col_lookup(ilog2(n1), dp, &vb, bitsb, &tcb, &thb)
+			    && pow2_col_blue_lookup(ilog2(n2), dp, 2, &v3, bits3, &tc3, &th3) && pow2_col_blue_lookup(ilog2(n1), dp, 4, &v4, bits4, &tc4, &th4)
+			    && pow2_col_blue_lookup(ilog2(n0), dp, 3, &v5, bits5, &tc5, &th5)) {
+				uint64_t nsub = 1;
+				for (auto& o : j.others) nsub *= o.count;
+				std::vector<HostDim> dense = j.others;
+				{ int64_t run = (int64_t)M; for (auto& o : dense) { o.inStride = o.outStride = run; run *= (int64_t)o.count; } }
+				auto withOthers = [&](std::vector<HostDim> lead, int inKind, int outKind) {
+					for (size_t i = 0; i < j.others.size(); i++) lead.push_back({j.others[i].count, inKind ? dense[i].inStride : j.others[i].inStride, outKind ? dense[i].outStride : j.others[i].outStride});
+					return lead;
+				};
+				auto setFast = [&](PassBuild& q, int kernel, int variant, const int bits[4], int tc, int thr) {
+					q.fastKernel = kernel; q.fastVariant = variant; q.fastThreads = thr; q.forceT = (uint32_t)tc;
+					q.radices.clear();
+					for (int k = 0; k < 4; k++) if (bits[k]) q.radices.push_back(1u << bits[k]);
+					q.noCollapse = true;
+				};
+				const int64_t sB = (int64_t)(n2 * n0); // stride of the middle factor's index inside T[m = i1*n2 + i2][k0]
+				PassBuild p1 = b;
+				p1.L = n0; p1.inStrideJ = (int64_t)M1; p1.outStrideJ = 1; p1.colIn = true; p1.colOut = false;
+				p1.dims = withOthers({{M1, 1, (int64_t)n0}}, 0, 1);
+				p1.preOp = OP_BLUESTEIN_PRE; p1.auxOff2ForPre = chirpOff; p1.bsSwapIn = j.inverse; p1.opN = (uint32_t)N; p1.opStrideJ = (uint32_t)M1; p1.opStride0 = 1;
+				p1.postOp = OP_TWIDDLE_4STEP; p1.fsN = M; p1.fsColDiv = 1;
+				p1.inRole = j.inRole; p1.outRole = ROLE_TEMP; p1.label = "bluestein5-1";
+				setFast(p1, KERNEL_POW2_COL_BLUE, v1, bits1, tc1, th1);
+				PassBuild p2 = b; // forward middle pass: FFT over i1, twiddle w_M1^(k1*i2), in place
+				p2.L = n1; p2.inStrideJ = p2.outStrideJ = sB; p2.colIn = p2.colOut = true;
+				p2.dims = withOthers({{n2 * n0, 1, 1}}, 1, 1);
+				p2.postOp = OP_TWIDDLE_4STEP; p2.fsN = M1; p2.fsColDiv = (uint32_t)n0;
+				p2.inRole = p2.outRole = ROLE_TEMP; p2.label = "bluestein5-2";
+				setFast(p2, KERNEL_POW2_COL, vb, bitsb, tcb, thb);
+				PassBuild p3 = b; // FFT over i2, * FFT(chirp)[k0 + n0*(k1 + n1*k2)], inverse FFT over k2, in place
+				p3.L = n2; p3.inStrideJ = p3.outStrideJ = (int64_t)n0; p3.colIn = p3.colOut = true;
+				p3.dims = withOthers({{n0, 1, 1}, {n1, sB, sB}}, 1, 1);
+				p3.midOp = OP_BLUESTEIN_MID; p3.aux2Off = bhatOff; p3.opStrideJ = (uint32_t)(n0 * n1); p3.opStride0 = 1; p3.opStride1 = (uint32_t)n0;
+				p3.inRole = p3.outRole = ROLE_TEMP; p3.label = "bluestein5-3";
+				setFast(p3, KERNEL_POW2_COL_BLUE, v3, bits3, tc3, th3);
+				PassBuild p4 = b; // the middle pass backwards
+				p4.L = n1; p4.inStrideJ = p4.outStrideJ = sB; p4.colIn = p4.colOut = true;
+				p4.dims = withOthers({{n2 * n0, 1, 1}}, 1, 1);
+				p4.preOp = OP_FOURSTEP_INV_COL_PRE; p4.fsN = M1; p4.fsColDiv = (uint32_t)n0;
+				p4.inRole = p4.outRole = ROLE_TEMP; p4.label = "bluestein5-4";
+				setFast(p4, KERNEL_POW2_COL_BLUE, v4, bits4, tc4, th4);
+				PassBuild p5 = b;
+				p5.L = n0; p5.inStrideJ = 1; p5.outStrideJ = (int64_t)M1; p5.colIn = p5.colOut = true;
+				p5.dims = withOthers({{M1, (int64_t)n0, 1}}, 1, 0);
+				p5.preOp = OP_FOURSTEP_INV_PRE; p5.fsN = M; p5.fsColDiv = 1;
+				p5.postOp = OP_BLUESTEIN_POST; p5.auxOff2ForPre = chirpOff; p5.bsSwapOut = j.inverse; p5.opN = (uint32_t)N; p5.opStrideJ = (uint32_t)M1; p5.opStride0 = 1;
+				p5.scale = j.scale;
+				p5.inRole = ROLE_TEMP; p5.outRole = j.outRole; p5.label = "bluestein5-5";
+				setFast(p5, KERNEL_POW2_COL_BLUE, v5, bits5, tc5, th5);
+				for (PassBuild* q : {&p1, &p2, &p3, &p4, &p5}) { PassPlan pp; int r = finish_pass(*q, ar, pp); if (r) return r; passes.push_back(pp); }
+				out.uploadsPerAxis[j.axisIndex] = 5;
 				out.tempBytes = std::max<uint64_t>(out.tempBytes, nsub * M * es);
 				return 0;
 			}
