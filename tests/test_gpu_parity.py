@@ -79,6 +79,48 @@ def test_full_size_properties(product_lib, k):
     app.delete()
 
 
+@pytest.mark.parametrize("N,kw", [(3840, {}), (2187, {}), (4093, {}), (15319, {}), (59049, {}), (4096, dict(r2c=True)), (4096, dict(dct=2)),
+                                  (4096, dict(dct=4)), (2000, dict(dst=2))])
+def test_full_size_properties_other_kernel_families(product_lib, N, kw):
+    """1 GiB buffers through the non-power-of-two, Bluestein, multi-pass and real-transform kernels: properties that need no
+    host reference of the full data set (spot transforms against torch's double FFT, Parseval where it applies, round trip)."""
+    import torch
+    real = bool(kw)
+    g = torch.Generator(device="cuda"); g.manual_seed(99 + N)
+    if kw.get("r2c"):
+        rowf = N + 2; B = (1 << 28) // rowf
+        x = torch.empty(B, rowf, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g); x[:, N:] = 0
+    elif real:
+        B = (1 << 28) // N
+        x = torch.empty(B, N, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    else:
+        B = (1 << 27) // N
+        x = torch.empty(B, 2 * N, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    buf = x.clone()
+    app = api.App([N], B, buffer_ptr=buf.data_ptr(), lib=product_lib, **kw)
+    app.forward(); torch.cuda.synchronize()
+    rows = (0, B // 2, B - 1)
+    if kw.get("r2c"):
+        X = torch.view_as_complex(buf.view(B, N // 2 + 1, 2))
+        for b in rows:
+            ref = torch.fft.rfft(x[b, :N].double())
+            assert (torch.linalg.norm(X[b].to(torch.complex128) - ref) / torch.linalg.norm(ref)).item() < 2e-6, (N, b)
+    elif not real:
+        X = torch.view_as_complex(buf.view(B, N, 2)); xc = torch.view_as_complex(x.view(B, N, 2))
+        for b in rows:
+            ref = torch.fft.fft(xc[b].to(torch.complex128))
+            assert (torch.linalg.norm(X[b].to(torch.complex128) - ref) / torch.linalg.norm(ref)).item() < 3e-6, (N, b)
+        e_in = (x.double() ** 2).sum().item(); e_out = (buf.double() ** 2).sum().item()
+        assert abs(e_out / (N * e_in) - 1) < 1e-5
+    app.inverse(); torch.cuda.synchronize()
+    scale = float(N) if (not real or kw.get("r2c")) else 2.0 * N  # R2R types 2-4: forward o inverse = 2N x
+    keep = x[:, :N] if kw.get("r2c") else x
+    got = buf.view(B, -1)[:, :N] if kw.get("r2c") else buf
+    rt = (torch.linalg.norm(got.double() - scale * keep.double()) / torch.linalg.norm(scale * keep.double())).item()
+    assert rt < 6e-6, (N, kw, rt)
+    app.delete()
+
+
 def test_full_size_linearity(product_lib):
     import torch
     N, B = 1 << 16, 1 << 8
