@@ -108,7 +108,7 @@ static void report(const char* tag, const Problem& q, const Timing& t) {
 	    tag, (unsigned long long)q.X, (unsigned long long)q.Y, (unsigned long long)q.Z, (unsigned long long)q.B, q.P ? "double" : "single",
 	    q.R2C ? " R2C" : q.DCT ? " DCT" : q.DST ? " DST" : "", mib, t.ms, t.stderr_ms, (unsigned long long)t.iters,
 	    (unsigned long long)t.uploads[0], (unsigned long long)t.uploads[1], (unsigned long long)t.uploads[2],
-	    4.0 * passes * gb / (t.ms * 1e-3) / 2.0, 4.0 * gb / (t.ms * 1e-3));
+	    4.0 * passes * gb / (t.ms * 1e-3), 4.0 * gb / (t.ms * 1e-3));
 }
 
 // round trip on the device with host-side invariants only (no host FFT: the library has no CPU path and neither has this tool)

@@ -40,6 +40,11 @@ template <typename T> struct Io32 {
 	__device__ inline void str(uint32_t j, T v) const { gb_store_real<T>(gout, oa(j), 0, v); }
 };
 
+// element k of a complex table of the pass: buffer addressing (one 32-bit VGPR offset instead of a 64-bit address per load)
+template <typename T> __device__ inline cx<T> table_load(const void* tab, uint32_t k) {
+	return gb_load<T>(make_gbuf(tab), k * (uint32_t)sizeof(cx<T>), 0);
+}
+
 template <typename T> __device__ inline cx<T> twiddle4(const PassParams& p, uint32_t e) {
 	const cx<T>* tab = (const cx<T>*)p.aux;
 	const uint32_t lo = e & ((1u << p.fsLoBits) - 1u), hi = e >> p.fsLoBits;
@@ -102,10 +107,10 @@ __device__ inline cx<T> pre_gather(const PassParams& p, const IO& io, uint32_t p
 		const uint32_t N = p.opN, H = N >> 1, m = H - pos;
 		const bool dst = op == OP_DST3H_PRE;
 		auto X = [&](uint32_t k) -> T { return k >= N ? (T)0 : io.ldr(dst ? N - 1 - k : k); }; // x_N = 0; DST-III reads the reversed input
-		const cx<T>* c = (const cx<T>*)p.aux;
-		const cx<T> a = cmul(cconj(c[pos]), cx<T>{X(pos), -X(N - pos)});
-		const cx<T> b = cconj(cmul(cconj(c[m]), cx<T>{X(m), -X(N - m)}));
-		const cx<T> w = cconj(((const cx<T>*)p.aux2)[pos]);
+		const auto c = [&](uint32_t k) { return table_load<T>(p.aux, k); };
+		const cx<T> a = cmul(cconj(c(pos)), cx<T>{X(pos), -X(N - pos)});
+		const cx<T> b = cconj(cmul(cconj(c(m)), cx<T>{X(m), -X(N - m)}));
+		const cx<T> w = cconj(table_load<T>(p.aux2, pos));
 		const cx<T> d = cmul(w, csub(a, b)), s2 = cadd(a, b);
 		return {s2.x - d.y, s2.y + d.x};
 	}

@@ -110,6 +110,36 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 				x[bm][R - 1 - i] = p.swapIn ? cswap(m) : m;
 			}
 		}
+	} else if constexpr (first && PRE == OP_DCT3H_PRE) {
+		// half-length DCT/DST-III: the Hermitian spectrum V_k = e^{+i pi k/2N}(x_k - i x_{N-k}), k = 0..H, is built ONCE in LDS
+		// (every real read once, one table entry per k), then each FFT input is the even C2R fold of V_n and V_{H-n}.  Gathering
+		// straight from global memory (pre_gather) reads every real twice and keeps 4 reals + 3 table entries per point in
+		// flight: the unrolled kernels spilled up to 1 KB/lane.
+		const uint32_t Nr = p.opN, H = Nr >> 1;
+		const bool dst = p.preOp == OP_DST3H_PRE;
+		auto X = [&](uint32_t k) -> T { return k >= Nr ? (T)0 : io.ldr(dst ? Nr - 1 - k : k); };
+		constexpr int PV = (N + 1 + TPF - 1) / TPF;
+#pragma unroll
+		for (int b = 0; b < PV; b++) {
+			const uint32_t k = tau + b * TPF;
+			if (k <= H) ldsf[k] = cmul(cconj(table_load<T>(p.aux, k)), cx<T>{X(k), -X(Nr - k)});
+		}
+		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+#pragma unroll
+		for (int b = 0; b < P; b++) {
+			const uint32_t t = opfft_bfly<NB, TPF, P, PAIR>(tau, b);
+			if (PAIR || (b + 1) * TPF <= NB || t < (uint32_t)NB) {
+#pragma unroll
+				for (int i = 0; i < R; i++) {
+					const uint32_t n = t + i * NB;
+					const cx<T> a = ldsf[n], bq = cconj(ldsf[H - n]);
+					const cx<T> d = cmul(cconj(table_load<T>(p.aux2, n)), csub(a, bq)), s2 = cadd(a, bq);
+					const cx<T> z = {s2.x - d.y, s2.y + d.x};
+					x[b][i] = p.swapIn ? cswap(z) : z;
+				}
+			}
+		}
+		if constexpr (!last) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); } // V is consumed before stage 0 overwrites the buffer
 	} else {
 #pragma unroll
 		for (int b = 0; b < P; b++) {
@@ -196,7 +226,7 @@ template <typename T, typename SCH, int TPF, int FPW, bool COL, int PRE, int POS
 __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	constexpr int N = SCH::N;
 	static_assert(!TRANS || (COL && (POST == OP_NONE || POST == OP_TWIDDLE_4STEP)), "transposed store: first Four-Step pass of a column tile");
-	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || TRANS || POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST)>();
+	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || TRANS || PRE == OP_DCT3H_PRE || POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST)>();
 	constexpr bool waveOnly = !COL && (TPF <= 64) && (64 % TPF == 0); // a row FFT that never straddles wavefronts
 	__shared__ cx<T> lds[FPW * LDSPF];
 	const uint32_t tid = threadIdx.x;

@@ -9,10 +9,13 @@
 #if defined(VKFFT_HOSTEMU)
 #define VKFFT_WAVE_SYNC() hostemu::wave_sync()
 #define VKFFT_OPAQUE_ZERO(z) uint32_t z = 0
+#define VKFFT_SCHED_FENCE() do { } while (0)
 #else
 // hides a (wave-uniform) pointer's provenance from the optimiser: stops loop-invariant twiddle loads from being
 // hoisted out of the persistent tile loop and pinned in dozens of VGPRs
 #define VKFFT_OPAQUE_ZERO(z) uint32_t z = 0; asm volatile("" : "+s"(z))
+// keeps the instruction scheduler from hoisting every load of an unrolled gather loop above the first use (register pressure)
+#define VKFFT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // orders this wave's LDS writes before its later LDS reads without an s_barrier
 #define VKFFT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #endif

@@ -204,10 +204,13 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	// stage twiddles (+ the tables of an FFT-Rader stage)
 	uint64_t lutElems = 0, S = 1;
 	uint32_t raderP = 0;
+	// radices above 16 other than 32: Rader stages of the interpreter — except inside the hand-specialised kernels, whose
+	// schedules may hold the composite butterfly 25 = 5*5
+	auto plainRadix = [&](uint32_t R) { return R <= 16 || R == 32 || b.fastKernel != KERNEL_GENERIC; };
 	for (uint32_t R : rad) {
 		if (S > 1) lutElems += (uint64_t)(R - 1) * S;
-		if (R > 16 && R != 32 && R <= b.raderDirectMax) lutElems += R;
-		if (R > 16 && R != 32 && R > b.raderDirectMax) raderP = R;
+		if (!plainRadix(R) && R <= b.raderDirectMax) lutElems += R;
+		if (!plainRadix(R) && R > b.raderDirectMax) raderP = R;
 		S *= R;
 	}
 	std::vector<uint32_t> subRad;
@@ -226,7 +229,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		uint32_t R = rad[si];
 		StageDesc& sd = p.st[si];
 		sd.radix = R; sd.S = (uint32_t)S; sd.lutOff = (uint32_t)cur;
-		sd.kind = (R <= 16 || R == 32) ? 0 : (R <= b.raderDirectMax ? 1 : 2);
+		sd.kind = plainRadix(R) ? 0 : (R <= b.raderDirectMax ? 1 : 2);
 		if (S > 1) {
 			for (uint32_t i = 1; i < R; i++)
 				for (uint64_t s = 0; s < S; s++) ar.putc(lutOff, cur + (uint64_t)(i - 1) * S + s, unit_root((uint64_t)i * s, (uint64_t)R * S), dp);
