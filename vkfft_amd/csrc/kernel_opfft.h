@@ -92,6 +92,9 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 	constexpr bool pairIn = ROW && first && PRE == OP_DCT2H_PRE && opfft_can_pair<SCH, SI, TPF>();
 	constexpr bool pairOut = ROW && last && POST == OP_DCT3H_POST && opfft_can_pair<SCH, SI, TPF>();
 	constexpr bool PAIR = pairIn || pairOut;
+	// LDS padding per exchange: rows pick it by conflict count (MixPad); column tiles need none (lanes run along the columns)
+	using PAD = MixPad<SCH, TPF, (int)sizeof(cx<T>)>;
+	constexpr int PADIN = ROW ? PAD::shift(SI - 1) : 0, PADOUT = ROW ? PAD::shift(SI) : 0;
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	cx<T> x[P][R];
 	if constexpr (pairIn) {
@@ -150,7 +153,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 					if constexpr (first) {
 						const cx<T> v = pre_gather<T>(p, io, t + i * NB, nat, op_resolve<PRE>(p.preOp));
 						x[b][i] = p.swapIn ? cswap(v) : v;
-					} else x[b][i] = ldsf[mix_slot(t + i * NB)];
+					} else x[b][i] = ldsf[mix_slot<PADIN>(t + i * NB)];
 				}
 			}
 		}
@@ -175,9 +178,9 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 				for (int k = 0; k < R; k++) {
 					if constexpr (last) {
 						const cx<T> v = p.swapOut ? cswap(x[b][k]) : x[b][k];
-						if constexpr (staged) ldsf[mix_slot(ob + k * S)] = v;
+						if constexpr (staged) ldsf[ob + k * S] = v; // natural order, unpadded: read back along k
 						else post_scatter<T>(p, io, ob + k * S, v, colIdx, nat, op_resolve<POST>(p.postOp));
-					} else ldsf[mix_slot(ob + k * S)] = x[b][k];
+					} else ldsf[mix_slot<PADOUT>(ob + k * S)] = x[b][k];
 				}
 			}
 		}
@@ -203,7 +206,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 	} else if constexpr (staged && !TRANS) {
 		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
 		constexpr int PO = (N + 1 + TPF - 1) / TPF; // R2C even split: N + 1 outputs from the length-N complex FFT
-		auto rd = [&](uint32_t a) { return ldsf[mix_slot(a)]; };
+		auto rd = [&](uint32_t a) { return ldsf[a]; };
 #pragma unroll
 		for (int b = 0; b < PO; b++) {
 			const uint32_t k = tau + b * TPF;
@@ -212,9 +215,9 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 	}
 }
 
-template <int N, int FPW, bool COL, bool NEEDS_LDS> __host__ __device__ constexpr int opfft_pitch() {
+template <int N, int FPW, bool COL, bool NEEDS_LDS, int ROWELEMS> __host__ __device__ constexpr int opfft_pitch() {
 	if (!NEEDS_LDS) return 1;
-	int pitch = N + (N >> 4) + 1;
+	int pitch = COL ? N + 1 : (ROWELEMS > N + 1 ? ROWELEMS : N + 1);
 	if (COL) { // lanes run along the FPW columns: column pitch = (32/FPW) * odd spreads a half-wave over all banks
 		const int q = FPW >= 32 ? 1 : 32 / FPW;
 		while (pitch % (2 * q) != q) pitch++;
@@ -226,7 +229,7 @@ template <typename T, typename SCH, int TPF, int FPW, bool COL, int PRE, int POS
 __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	constexpr int N = SCH::N;
 	static_assert(!TRANS || (COL && (POST == OP_NONE || POST == OP_TWIDDLE_4STEP)), "transposed store: first Four-Step pass of a column tile");
-	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || TRANS || PRE == OP_DCT3H_PRE || POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST)>();
+	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || TRANS || PRE == OP_DCT3H_PRE || POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST), MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems()>();
 	constexpr bool waveOnly = !COL && (TPF <= 64) && (64 % TPF == 0); // a row FFT that never straddles wavefronts
 	__shared__ cx<T> lds[FPW * LDSPF];
 	const uint32_t tid = threadIdx.x;
@@ -265,7 +268,7 @@ __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 			const uint32_t idx = tid + b * NT;
 			if (TOT % NT == 0 || idx < (uint32_t)TOT) {
 				const uint32_t c = idx / (uint32_t)N, k = idx % (uint32_t)N;
-				cx<T> v = lds[c * LDSPF + mix_slot(k)];
+				cx<T> v = lds[c * LDSPF + k];
 				if constexpr (POST == OP_TWIDDLE_4STEP) {
 					uint32_t ci = g1;
 					if (!p.fsColFromDim1) { uint32_t rr; p.fsColDiv.divmod(f0 + c, ci, rr); }
