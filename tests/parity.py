@@ -73,7 +73,7 @@ def opfft_cases():
     cases = []
     for dp, tag in ((False, "f32"), (True, "f64")):
         for col in (False, True):
-            txt = open(os.path.join(root, "opfft_table_%s_%s.inc" % (tag, "col" if col else "row"))).read()
+            txt = "".join(open(os.path.join(root, "opfft_table_%s_%s_%d.inc" % (tag, "col" if col else "row", h))).read() for h in (0, 1))
             for fam, L in re.findall(r"// (\w+) L=(\d+)", txt):
                 if fam == "dst1" and int(L) == 4:
                     continue  # DST-I of length 1: size-1 axes are omitted (reference InitializeApp.h:1378-1381), nothing to run

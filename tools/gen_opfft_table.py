@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates vkfft_amd/csrc/opfft_table_{f32,f64}_{row,col}.inc: the curated instances of kernel_opfft.h (single-pass FFT
+"""Generates vkfft_amd/csrc/opfft_table_{f32,f64}_{row,col}_{0,1}.inc: the curated instances of kernel_opfft.h (single-pass FFT
 with a fused pre/post map: R2C/C2R even split, DCT/DST I-IV, strided C2C of non-power-of-two length).  One line per
 (complex FFT length L, precision, row|col, op family): radix list, threads per FFT, FFTs (rows or columns) per workgroup.
 Re-run after changing the heuristics; the generated files are committed."""
@@ -117,7 +117,10 @@ def main():
                     lines.append("VKFFT_OPX(%s, %s, %s, %s, %s, %d, %d, %d, %d, %d, %d, %d, %s) // %s L=%d" %
                                  (tname, "true" if dp else "false", "true" if col else "false", pre, post, *rr, tpf, fpw, "true" if fam == "c2cT" else "false", fam, n))
                     total += 1
-            open(os.path.join(root, "opfft_table_%s_%s.inc" % (tag, "col" if col else "row")), "w").write("\n".join(lines) + "\n")
+            # two translation units per table (kernels_opfft_*_{0,1}.hip): halves the longest compile of a parallel build
+            head, body = lines[0], lines[1:]
+            for half in (0, 1):
+                open(os.path.join(root, "opfft_table_%s_%s_%d.inc" % (tag, "col" if col else "row", half)), "w").write("\n".join([head] + body[half::2]) + "\n")
     print("wrote", total, "entries")
 
 

@@ -4,6 +4,7 @@
 #include "kernel_generic.h"
 #include "kernel_pow2.h"
 #include "kernel_opfft.h"
+#include "kernel_mixed.h"
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -56,18 +57,47 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
 }
 
-// ---- op-FFT registry: four table parts, one translation unit each (kernels_opfft_*.hip) ---------------------------
-const OpfftVariant* opfft_table_f32_row(int*);
-const OpfftVariant* opfft_table_f32_col(int*);
-const OpfftVariant* opfft_table_f64_row(int*);
-const OpfftVariant* opfft_table_f64_col(int*);
-static const OpfftVariant* opfft_part(int part, int* count) {
-	switch (part) {
-	case 0: return opfft_table_f32_row(count);
-	case 1: return opfft_table_f32_col(count);
-	case 2: return opfft_table_f64_row(count);
-	default: return opfft_table_f64_col(count);
+// ---- mixed-radix registry: three table parts, one translation unit each (kernels_mixed_*.hip) --------------------
+const MixedVariant* mixed_table_0(int*);
+const MixedVariant* mixed_table_1(int*);
+const MixedVariant* mixed_table_2(int*);
+static const MixedVariant* mixed_part(int part, int* count) { return part == 0 ? mixed_table_0(count) : part == 1 ? mixed_table_1(count) : mixed_table_2(count); }
+bool mixed_row_lookup(uint64_t n, bool dp, int* variant, int rad[5], int* fpw, int* threads) {
+	for (int part = 0; part < 3; part++) {
+		int cnt = 0;
+		const MixedVariant* tab = mixed_part(part, &cnt);
+		for (int i = 0; i < cnt; i++) {
+			if ((uint64_t)tab[i].n != n || tab[i].dp != dp) continue;
+			*variant = (part << 16) | i;
+			for (int k = 0; k < 5; k++) rad[k] = tab[i].rad[k];
+			*fpw = tab[i].fpw; *threads = tab[i].tpf * tab[i].fpw;
+			return true;
+		}
 	}
+	return false;
+}
+int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
+	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
+	if (grid64 == 0) return 0;
+	int cnt = 0;
+	const MixedVariant* tab = mixed_part((pp.variant >> 16) % 3, &cnt);
+	const int idx = pp.variant & 0xffff;
+	if (grid64 > 0x7fffffffull || pp.variant < 0 || idx >= cnt) return 4039;
+	tab[idx].launch(prm, dim3((uint32_t)grid64), stream);
+	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
+
+// ---- op-FFT registry: eight table parts, one translation unit each (kernels_opfft_*.hip) ---------------------------
+#define VKFFT_OPFFT_PARTS(X) X(f32_row_0) X(f32_row_1) X(f32_col_0) X(f32_col_1) X(f64_row_0) X(f64_row_1) X(f64_col_0) X(f64_col_1)
+#define VKFFT_DECL(t) const OpfftVariant* opfft_table_##t(int*);
+VKFFT_OPFFT_PARTS(VKFFT_DECL)
+#undef VKFFT_DECL
+static const OpfftVariant* opfft_part(int part, int* count) { // part = 2 * ((dp ? 2 : 0) + (col ? 1 : 0)) + half
+	typedef const OpfftVariant* (*Fn)(int*);
+#define VKFFT_REF(t) &opfft_table_##t,
+	static const Fn fns[8] = { VKFFT_OPFFT_PARTS(VKFFT_REF) };
+#undef VKFFT_REF
+	return fns[part & 7](count);
 }
 static uint32_t opfft_family(uint32_t op) { // DST members run on the DCT instance of their family
 	switch (op) {
@@ -80,18 +110,20 @@ static uint32_t opfft_family(uint32_t op) { // DST members run on the DCT instan
 	}
 }
 bool opfft_lookup(uint64_t n, bool dp, bool col, bool trans, uint32_t pre, uint32_t post, int* variant, int rad[5], int* fpw, int* threads) {
-	const int part = (dp ? 2 : 0) + (col ? 1 : 0);
-	int cnt = 0;
-	const OpfftVariant* tab = opfft_part(part, &cnt);
 	pre = opfft_family(pre); post = opfft_family(post);
-	int first = -1;
-	for (int i = 0; i < cnt && first < 0; i++)
-		if ((uint64_t)tab[i].n == n && (uint32_t)tab[i].pre == pre && (uint32_t)tab[i].post == post && tab[i].trans == trans) first = i;
-	if (first < 0) return false;
-	*variant = (part << 16) | first;
-	for (int k = 0; k < 5; k++) rad[k] = tab[first].rad[k];
-	*fpw = tab[first].fpw; *threads = tab[first].tpf * tab[first].fpw;
-	return true;
+	for (int half = 0; half < 2; half++) {
+		const int part = 2 * ((dp ? 2 : 0) + (col ? 1 : 0)) + half;
+		int cnt = 0;
+		const OpfftVariant* tab = opfft_part(part, &cnt);
+		for (int i = 0; i < cnt; i++) {
+			if ((uint64_t)tab[i].n != n || (uint32_t)tab[i].pre != pre || (uint32_t)tab[i].post != post || tab[i].trans != trans) continue;
+			*variant = (part << 16) | i;
+			for (int k = 0; k < 5; k++) rad[k] = tab[i].rad[k];
+			*fpw = tab[i].fpw; *threads = tab[i].tpf * tab[i].fpw;
+			return true;
+		}
+	}
+	return false;
 }
 int launch_opfft(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
