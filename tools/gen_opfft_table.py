@@ -82,7 +82,10 @@ def plan_col(n, dp, real):
     def fits(fpw, budget, emax):
         tpf = tpf_for(n, rad, emax)
         return fpw * pitch(n, fpw, True) * es <= budget and tpf * fpw <= 1024, tpf
-    for budget, minf in ((80 * 1024, 16), (156 * 1024, 8)):
+    # 4-byte reals: 32 columns are the first width with 128-byte segments (64-byte segments measured ~40 % slower), worth
+    # one workgroup per CU; complex data and fp64 reals reach 128 bytes at 16 columns
+    tiers = ((80 * 1024, 32), (156 * 1024, 32), (80 * 1024, 16), (156 * 1024, 8)) if (real and not dp) else ((80 * 1024, 16), (156 * 1024, 8))
+    for budget, minf in tiers:
         for fpw in cands:
             if fpw < minf: continue
             for emax in ((16, 32) if not dp else (16,)):
