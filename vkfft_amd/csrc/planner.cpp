@@ -694,7 +694,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		if (unit && !fusedM && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein) {
 			// multi-pass rows: a power-of-two padded length runs as three passes on the column kernels (below)
 			uint64_t Mp = 1; while (Mp < 2 * N - 1) Mp *= 2;
-			if (Mp > cap && Mp <= (1ull << 29)) M = Mp;
+			if (Mp > cap && Mp * (dp ? 16 : 8) <= (1ull << 30)) M = Mp; // 32-bit byte offsets inside one padded row (buffer addressing)
 		}
 		std::vector<uint64_t> spM;
 		if (M > cap) {
