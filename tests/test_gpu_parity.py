@@ -346,3 +346,29 @@ def test_cli_driver_on_device(product_lib):
     assert out.returncode == 0, out.stdout + out.stderr
     m = re.search(r"scaled_bandwidth: ([0-9.]+) GB/s", out.stdout)
     assert m and float(m.group(1)) > 100.0, out.stdout
+
+
+def test_multi_gpu_drivers_on_one_device(product_lib):
+    """The multi-GPU drivers (vkfft_amd/distributed.py) on the device with a single rank: the slab 3D transform (its exchange
+    degenerates to the identity) against torch's fftn, and one batch shard of a sharded plan against the unsharded result.
+    (The two-rank paths, including the all-to-all, are covered on CPU by tests/test_distributed_gloo.py.)"""
+    import torch
+    from vkfft_amd.distributed import BatchShardedFFT, SlabFFT3D
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    nx, ny, nz = 96, 64, 40
+    x = torch.view_as_complex(torch.empty(nz, ny, nx, 2, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g))
+    plan = SlabFFT3D(nx, ny, nz, lib=product_lib)
+    y = plan.forward(x.clone())
+    ref = torch.fft.fftn(x.to(torch.complex128), dim=(0, 1, 2))
+    assert (torch.linalg.norm(y.to(torch.complex128) - ref) / torch.linalg.norm(ref)).item() < 2e-6
+    z = plan.inverse(y)
+    assert (torch.linalg.norm(z.to(torch.complex128) - x.to(torch.complex128) * (nx * ny * nz)) / torch.linalg.norm(x.to(torch.complex128) * (nx * ny * nz))).item() < 4e-6
+    # batch sharding: rank 1 of 3 transforms rows [lo, hi) of a 100-row batch exactly as the unsharded plan does
+    N, B = 1080, 100
+    a = torch.empty(B, 2 * N, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    whole = a.clone()
+    app = api.App([N], B, buffer_ptr=whole.data_ptr(), lib=product_lib); app.forward(); torch.cuda.synchronize(); app.delete()
+    shard = BatchShardedFFT([N], B, 1, 3, lib=product_lib)
+    part = a[shard.lo:shard.hi].clone()
+    shard.forward(part.data_ptr()); torch.cuda.synchronize(); shard.delete()
+    assert torch.equal(part, whole[shard.lo:shard.hi])
