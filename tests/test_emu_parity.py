@@ -122,6 +122,14 @@ def test_dct_dst(run, oracle, type, dst, shape):
         parity.check_r2r(run, oracle, shape, 2, True, type, dst)
 
 
+@pytest.mark.parametrize("N,dp,type,dst", [(240, False, 1, False), (1014, False, 1, False), (478, False, 2, False), (478, False, 3, True), (239, False, 2, True),
+                                           (240, True, 1, False), (718, True, 3, False)])
+def test_r2r_whose_embedding_length_needs_bluestein(run, oracle, N, dp, type, dst):
+    """DCT/DST whose embedding FFT length has a prime factor outside the radix / Rader stages (DCT-I of 240: 478 = 2 * 239):
+    the real transform's maps around a fused Bluestein transform (kernel_blue_r2r.h)."""
+    parity.check_r2r(run, oracle, (N,), 6, dp, type, dst)
+
+
 def test_golden_reference_fixtures(run, golden):
     """library (emulated) vs the reference's own outputs captured on an MI355X"""
     mod, data = golden

@@ -221,7 +221,7 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 		if (res != VKFFT_SUCCESS) { deleteVkFFT(app); return res; }
 	}
 	if (c.printMemoryLayout || getenv("VKFFT_MI355X_PRINT_PLAN")) { // one line per launch: which kernel family serves it
-		static const char* kname[] = {"generic", "pow2_row", "pow2_col", "r2c_pair", "?", "mixed_row", "opfft", "pow2_blue", "pow2_col_blue"};
+		static const char* kname[] = {"generic", "pow2_row", "pow2_col", "r2c_pair", "?", "mixed_row", "opfft", "pow2_blue", "pow2_col_blue", "pow2_blue_r2r"};
 		for (int dir = 0; dir < 2; dir++) {
 			VkFFTPlan* pl = dir ? app->localFFTPlan_inverse : app->localFFTPlan;
 			if (!pl) continue;
@@ -229,7 +229,7 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 			for (size_t i = 0; i < dpn->passes.size(); i++) {
 				const PassPlan& q = dpn->passes[i];
 				fprintf(stderr, "[vkfft_mi355x] %s pass %zu: %-10s kernel=%s variant=%d L=%u threads=%u tile=%u grid=%llu\n", dir ? "inverse" : "forward", i, q.label.c_str(),
-				        kname[q.kernel < 9 ? q.kernel : 4], q.variant, q.prm.L, q.threads, q.prm.T,
+				        kname[q.kernel < 10 ? q.kernel : 4], q.variant, q.prm.L, q.threads, q.prm.T,
 				        (unsigned long long)q.prm.tilesPerG0 * q.prm.dim[1].count * q.prm.dim[2].count);
 			}
 		}

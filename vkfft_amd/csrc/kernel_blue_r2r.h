@@ -1,0 +1,114 @@
+// DCT/DST whose embedding FFT length has a prime factor the radix / Rader stages do not cover (e.g. DST-I of N = 100:
+// 2N + 2 = 202 = 2 * 101, DCT-I of N = 240: 478 = 2 * 239): the real transform's pre/post maps (vkFFT_R2R.h) around a fused
+// Bluestein transform of the embedding length (vkFFT_Bluestein.h:32,201), in one kernel.  Same register-resident persistent
+// structure as pow2_blue_kernel (kernel_pow2.h): the embedding sequence of length blueN <= M/2 is gathered with pre_gather<PRE>,
+// chirp-multiplied, zero-padded to M = 2^k, transformed, multiplied by FFT(chirp)/M, transformed back, chirp-multiplied, and its
+// outputs leave through post_scatter<POST>.  Families: DCT-I, DST-I, DCT/DST-II and -III in their full-length forms.
+#pragma once
+#include "kernel_generic.h"
+#include "kernel_pow2.h"
+#include "kernel_opfft.h"
+
+namespace vkfft_mi355x {
+
+template <typename T, typename SCH, int FPW, int PRE, int POST>
+__global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_blue_r2r_kernel(const PassParams p) {
+	constexpr int LOGN = SCH::LOGN, M = 1 << LOGN, LOGE = SCH::LOGE, E = 1 << LOGE, TPF = M / E, EH = E / 2;
+	constexpr int LDSPF = SCH::NS > 1 ? M + (M >> LOGE) : 1;
+	constexpr bool waveOnly = TPF <= 64;
+	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
+	__shared__ cx<T> lds[FPW * LDSPF];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t f = tid / TPF, tau = tid % TPF;
+	const uint32_t n = p.blueN; // embedding length (2N-2, 2N+2 or N); p.opN stays the real transform's N for the maps
+	const GBuf glut = make_gbuf(p.lut), gch = make_gbuf(p.aux3), gbh = make_gbuf(p.aux2);
+	cx<T> ch[EH], bh[E];
+#pragma unroll
+	for (int m = 0; m < EH; m++) { const uint32_t pos = tau + m * TPF; ch[m] = gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0); }
+#pragma unroll
+	for (int m = 0; m < E; m++) bh[m] = gb_load<T>(gbh, (tau + m * TPF) * ES, 0);
+	const uint32_t tiles = p.tilesPerG0 * p.dim[1].count * p.dim[2].count;
+	for (uint32_t wgi = blockIdx.x; wgi < tiles; wgi += gridDim.x) {
+		uint32_t wg = wgi;
+		const uint32_t tile = wg % p.tilesPerG0;
+		wg /= p.tilesPerG0;
+		const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
+		const uint32_t f0 = tile * FPW, g0 = f0 + f;
+		const bool valid = g0 < p.dim[0].count;
+		const int64_t inBase = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride;
+		const int64_t outBase = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride;
+		Io32<T> io;
+		io.gin = make_gbuf((const char*)p.in + inBase * (int64_t)p.inElemBytes);
+		io.gout = make_gbuf((char*)p.out + outBase * (int64_t)p.outElemBytes);
+		io.inOff = valid ? f * (uint32_t)p.dim[0].inStride * p.inElemBytes : kGbInvalid;
+		io.outOff = valid ? f * (uint32_t)p.dim[0].outStride * p.outElemBytes : kGbInvalid;
+		io.inSj = (uint32_t)p.inStrideJ * p.inElemBytes;
+		io.outSj = (uint32_t)p.outStrideJ * p.outElemBytes;
+		const uint32_t nat = g0 * p.opStride0 + g1 * p.opStride1;
+		cx<T> v[E];
+#pragma unroll
+		for (int m = 0; m < EH; m++) { // embedding points >= n are the zero padding (n <= M/2)
+			const uint32_t pos = tau + m * TPF;
+			cx<T> x = {(T)0, (T)0};
+			if (pos < n) x = pre_gather<T>(p, io, pos, nat, op_resolve<PRE>(p.preOp));
+			if (p.swapIn) x = cswap(x);
+			v[m] = cmulc(x, ch[m]);
+		}
+#pragma unroll
+		for (int m = EH; m < E; m++) v[m] = cx<T>{(T)0, (T)0};
+		pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], bh[m]));
+		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); } // the exchange buffer is reused
+		pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
+#pragma unroll
+		for (int m = 0; m < EH; m++) {
+			const uint32_t pos = tau + m * TPF;
+			cx<T> y = cmulc(cswap(v[m]), ch[m]);
+			if (p.swapOut) y = cswap(y);
+			if (pos < n) post_scatter<T>(p, io, pos, y, 0, nat, op_resolve<POST>(p.postOp)); // applies the scale
+		}
+		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); }
+	}
+}
+
+// ---- registry: one entry per (log2 M, dp, family) ------------------------------------------------------------------
+struct Pow2BlueR2rVariant { Pow2Variant v; int pre; };
+template <typename T, typename SCH, int FPW, int PRE, int POST> void pow2_blue_r2r_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
+	constexpr int threads = ((1 << SCH::LOGN) >> SCH::LOGE) * FPW;
+	const unsigned resident = pow2_num_cus() * 8u;
+	hipLaunchKernelGGL((pow2_blue_r2r_kernel<T, SCH, FPW, PRE, POST>), dim3(grid.x < resident ? grid.x : resident), dim3(threads), 0, s, prm);
+}
+#define VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, pre, post) \
+	{ { (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, fpw, (((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (fpw)), &pow2_blue_r2r_launch<T, Pow2Sched<b0, b1, b2, b3>, fpw, pre, post> }, pre }
+#define VKFFT_P2BR(T, dp, b0, b1, b2, b3, fpw) \
+	VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, OP_DCT1_PRE, OP_DCT1_POST), VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, OP_DST1_PRE, OP_DST1_POST), \
+	VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, OP_DCT2_PRE, OP_DCT2_POST), VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, OP_DCT3_PRE, OP_DCT3_POST)
+static const Pow2BlueR2rVariant kPow2BlueR2rVariants[] = {
+	VKFFT_P2BR(float, false, 3, 3, 0, 0, 32),
+	VKFFT_P2BR(float, false, 4, 3, 0, 0, 16),
+	VKFFT_P2BR(float, false, 4, 4, 0, 0, 16),
+	VKFFT_P2BR(float, false, 4, 3, 2, 0, 8),
+	VKFFT_P2BR(float, false, 4, 3, 3, 0, 4),
+	VKFFT_P2BR(float, false, 4, 4, 3, 0, 2),
+	VKFFT_P2BR(float, false, 4, 4, 4, 0, 1),
+	VKFFT_P2BR(float, false, 4, 3, 3, 3, 1),
+	VKFFT_P2BR(double, true, 3, 3, 0, 0, 32),
+	VKFFT_P2BR(double, true, 3, 2, 2, 0, 16),
+	VKFFT_P2BR(double, true, 3, 3, 2, 0, 8),
+	VKFFT_P2BR(double, true, 3, 3, 3, 0, 4),
+	VKFFT_P2BR(double, true, 3, 3, 2, 2, 2),
+	VKFFT_P2BR(double, true, 3, 3, 3, 2, 1),
+	VKFFT_P2BR(double, true, 3, 3, 3, 3, 1),
+};
+constexpr int kNumPow2BlueR2rVariants = (int)(sizeof(kPow2BlueR2rVariants) / sizeof(kPow2BlueR2rVariants[0]));
+
+inline int launch_pow2_blue_r2r(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
+	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
+	if (grid64 == 0) return 0;
+	if (grid64 > 0x7fffffffull || pp.variant < 0 || pp.variant >= kNumPow2BlueR2rVariants) return 4039;
+	kPow2BlueR2rVariants[pp.variant].v.launch(prm, dim3((uint32_t)grid64), stream);
+	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
+
+} // namespace vkfft_mi355x

@@ -108,7 +108,7 @@ struct PassBuild {
 	bool colIn = false, colOut = false;
 	bool dp = false;
 	uint32_t preOp = OP_NONE, midOp = OP_NONE, postOp = OP_NONE;
-	uint32_t inLen = 0, outLen = 0, opN = 0;
+	uint32_t inLen = 0, outLen = 0, opN = 0, blueN = 0;
 	bool swapIn = false, swapOut = false, bsSwapIn = false, bsSwapOut = false;
 	uint64_t fsN = 0; uint32_t fsColDiv = 1; bool fsColFromDim1 = false;
 	uint32_t opStrideJ = 1, opStride0 = 0, opStride1 = 0; // natural-position index of element j of sub-FFT (g0,g1) for position-indexed ops
@@ -330,7 +330,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.bluesteinSwapIn = b.bsSwapIn; p.bluesteinSwapOut = b.bsSwapOut;
 	p.inLen = b.inLen ? b.inLen : (uint32_t)b.L;
 	p.outLen = b.outLen ? b.outLen : (uint32_t)b.L;
-	p.opN = b.opN;
+	p.opN = b.opN; p.blueN = b.blueN;
 	p.opStrideJ = b.opStrideJ; p.opStride0 = b.opStride0; p.opStride1 = b.opStride1;
 	p.fsN = (uint32_t)b.fsN;
 	p.fsColDiv = make_fastdiv(b.fsColDiv);
@@ -659,6 +659,32 @@ static int emit_multipass_strided(const PassBuild& proto, uint64_t N, const std:
 	return 0;
 }
 
+// Bluestein tables of a length-N transform through padded length M: chirp[n] = exp(+i pi n^2 / N) (the kernels multiply by its
+// conjugate; vkFFT_RecursiveFFTGenerators.h:139-148) and FFT_M of the wrapped chirp, scaled by 1/M.
+static void make_bluestein_tables(uint64_t N, uint64_t M, bool dp, Arena& ar, size_t& chirpOff, size_t& bhatOff) {
+	const size_t es = dp ? 16 : 8;
+	chirpOff = ar.alloc(N * es); bhatOff = ar.alloc(M * es);
+	// FFT(chirp) is identical for the forward and the inverse plan of an application: keep the last one
+	static std::mutex mtx; static uint64_t cN = 0, cM = 0; static std::vector<cld> cChirp, cBhat;
+	std::lock_guard<std::mutex> lock(mtx);
+	if (cN != N || cM != M) {
+		cChirp.assign(N, cld(0, 0));
+		std::vector<cld> bext(M, cld(0, 0));
+		for (uint64_t n = 0; n < N; n++) {
+			unsigned __int128 sq = (unsigned __int128)n * n;
+			uint64_t e = (uint64_t)(sq % (2 * N));
+			cld c = std::conj(unit_root_pi(e, N));
+			cChirp[n] = c;
+			bext[n] = c;
+			if (n) bext[M - n] = c;
+		}
+		host_fft(bext);
+		cBhat.swap(bext); cN = N; cM = M;
+	}
+	for (uint64_t n = 0; n < N; n++) ar.putc(chirpOff, n, cChirp[n], dp);
+	for (uint64_t k = 0; k < M; k++) ar.putc(bhatOff, k, cBhat[k] / (ld)M, dp);
+}
+
 // ---- C2C along one axis -------------------------------------------------------------------------------
 static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
 	const bool dp = j.dp;
@@ -707,28 +733,8 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 			}
 		}
 		const size_t es = dp ? 16 : 8;
-		size_t chirpOff = ar.alloc(N * es), bhatOff = ar.alloc(M * es);
-		{
-			// FFT(chirp) is identical for the forward and the inverse plan of an application: keep the last one
-			static std::mutex mtx; static uint64_t cN = 0, cM = 0; static std::vector<cld> cChirp, cBhat;
-			std::lock_guard<std::mutex> lock(mtx);
-			if (cN != N || cM != M) {
-				cChirp.assign(N, cld(0, 0));
-				std::vector<cld> bext(M, cld(0, 0));
-				for (uint64_t n = 0; n < N; n++) {
-					unsigned __int128 sq = (unsigned __int128)n * n;
-					uint64_t e = (uint64_t)(sq % (2 * N));
-					cld c = std::conj(unit_root_pi(e, N)); // exp(+i pi n^2 / N), vkFFT_RecursiveFFTGenerators.h:139-148
-					cChirp[n] = c;
-					bext[n] = c;
-					if (n) bext[M - n] = c;
-				}
-				host_fft(bext);
-				cBhat.swap(bext); cN = N; cM = M;
-			}
-			for (uint64_t n = 0; n < N; n++) ar.putc(chirpOff, n, cChirp[n], dp);
-			for (uint64_t k = 0; k < M; k++) ar.putc(bhatOff, k, cBhat[k] / (ld)M, dp);
-		}
+		size_t chirpOff, bhatOff;
+		make_bluestein_tables(N, M, dp, ar, chirpOff, bhatOff);
 		if (spM.size() == 2 && (M & (M - 1)) == 0 && !d.disableFastKernels) {
 			// power-of-two padded length whose two factors are column-kernel lengths: three passes (kernel_pow2.h,
 			// pow2_col_blue_kernel) — the middle one is FFT over m, * FFT(chirp), inverse FFT over m in registers
@@ -1098,9 +1104,36 @@ static int plan_r2r_axis(const TransformDesc& d, int type, bool dst, uint64_t N,
 	}
 	default: return 3004;
 	}
-	if (!is_supported_len(b.L, dmax)) return 3004;
-	if (b.L > (unit ? max_row_len(dp, d.maxLds) : max_col_len(dp, d.maxLds, 1))) return 3004;
 	b.label = dst ? "dst" : "dct";
+	if (!is_supported_len(b.L, dmax)) {
+		// the embedding length has a prime factor outside the radix / Rader stages (e.g. DST-I of 100: 202 = 2 * 101): the
+		// real transform's maps around a fused Bluestein transform of the embedding length (kernel_blue_r2r.h), unit-stride rows
+		if (!unit || d.disableFastKernels || type == 4) return 3004;
+		uint64_t Lb = b.L;
+		if (type == 2 || type == 3) { // full-length forms (the half-length post-map is not element-wise)
+			Lb = N;
+			b.preOp = type == 2 ? (dst ? OP_DST2_PRE : OP_DCT2_PRE) : (dst ? OP_DST3_PRE : OP_DCT3_PRE);
+			b.postOp = type == 2 ? (dst ? OP_DST2_POST : OP_DCT2_POST) : (dst ? OP_DST3_POST : OP_DCT3_POST);
+			b.swapIn = b.swapOut = type == 3;
+			b.outLen = (uint32_t)N;
+			if (b.auxOff == (size_t)-1) { // quarter-wave table e^{-i pi k / 2N} (already there for even N)
+				size_t aux = ar.alloc(N * es);
+				for (uint64_t k = 0; k < N; k++) ar.putc(aux, k, unit_root(k, 4 * N), dp);
+				b.auxOff = aux;
+			}
+		}
+		uint64_t Mp = 64; while (Mp < 2 * Lb - 1) Mp *= 2;
+		int variant, bits[4], fpw, thr;
+		const uint64_t rowPitch = others.empty() ? N : (uint64_t)std::max<int64_t>(std::llabs(others[0].inStride), std::llabs(others[0].outStride));
+		if ((rowPitch * 64 + 2 * N) * (dp ? 8 : 4) >= 0x7FFFFF00ull || !pow2_blue_r2r_lookup(ilog2(Mp), dp, b.preOp, &variant, bits, &fpw, &thr)) return 3004;
+		size_t chirpOff, bhatOff;
+		make_bluestein_tables(Lb, Mp, dp, ar, chirpOff, bhatOff);
+		b.L = Mp; b.blueN = (uint32_t)Lb;
+		b.midOp = OP_BLUESTEIN_MID; b.aux2Off = bhatOff; b.auxOff2ForPre = chirpOff;
+		b.fastKernel = KERNEL_POW2_BLUE_R2R; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
+		b.radices.clear();
+		for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
+	} else if (b.L > (unit ? max_row_len(dp, d.maxLds) : max_col_len(dp, d.maxLds, 1))) return 3004;
 	PassPlan pp; int r = finish_pass(b, ar, pp); if (r) return r == 3002 ? 3004 : r;
 	passes.push_back(pp);
 	out.uploadsPerAxis[axisIndex] = 1;
