@@ -78,7 +78,7 @@ def test_bluestein(run, oracle, N, dp):
     parity.check_c2c(run, oracle, (N,), 2, dp, kind="bluestein")
 
 
-@pytest.mark.parametrize("N,dp,uploads", [(4099, False, 3), (15319, False, 3), (21269, True, 3), (524309, False, 5)])
+@pytest.mark.parametrize("N,dp,uploads", [(4099, False, 1), (8191, False, 1), (4093, True, 1), (8209, False, 3), (15319, False, 3), (21269, True, 3), (524309, False, 5)])
 def test_bluestein_multi_pass_fused(run, oracle, N, dp, uploads):
     """Rows whose padded power-of-two length needs two / three column factors: 3 / 5 passes (pow2_col_blue_kernel)."""
     up = parity.check_c2c(run, oracle, (N,), 2 if N < 100000 else 1, dp, kind="bluestein", use_c_oracle=False)
@@ -122,8 +122,15 @@ def test_dct_dst(run, oracle, type, dst, shape):
         parity.check_r2r(run, oracle, shape, 2, True, type, dst)
 
 
+@pytest.mark.parametrize("shape,dp", [((5606,), False), ((916,), True), ((1217,), False), ((139, 12), False), ((2 * 2803, 6), False)])
+def test_r2c_whose_half_length_needs_bluestein(run, oracle, shape, dp):
+    """Real rows whose (half) length has a prime factor outside the radix / Rader stages (5606 = 2 * 2803): the full-length
+    R2C / C2R maps around a fused Bluestein transform (kernel_blue_r2r.h)."""
+    parity.check_r2c(run, oracle, shape, 3, dp)
+
+
 @pytest.mark.parametrize("N,dp,type,dst", [(240, False, 1, False), (1014, False, 1, False), (478, False, 2, False), (478, False, 3, True), (239, False, 2, True),
-                                           (240, True, 1, False), (718, True, 3, False)])
+                                           (240, True, 1, False), (718, True, 3, False), (1902, True, 4, False), (1451, False, 4, True), (879, False, 4, False)])
 def test_r2r_whose_embedding_length_needs_bluestein(run, oracle, N, dp, type, dst):
     """DCT/DST whose embedding FFT length has a prime factor outside the radix / Rader stages (DCT-I of 240: 478 = 2 * 239):
     the real transform's maps around a fused Bluestein transform (kernel_blue_r2r.h)."""

@@ -264,8 +264,15 @@ def test_dct_fp64(run, oracle, type, shape, b):
     parity.check_r2r(run, oracle, shape, b, True, type, False)
 
 
+@pytest.mark.parametrize("shape,dp", [((5606,), False), ((916,), True), ((1217,), False), ((139, 12), False), ((2 * 2803, 6), False)])
+def test_r2c_whose_half_length_needs_bluestein(run, oracle, shape, dp):
+    """Real rows whose (half) length has a prime factor outside the radix / Rader stages (5606 = 2 * 2803): the full-length
+    R2C / C2R maps around a fused Bluestein transform (kernel_blue_r2r.h)."""
+    parity.check_r2c(run, oracle, shape, 3, dp)
+
+
 @pytest.mark.parametrize("N,dp,type,dst", [(240, False, 1, False), (1014, False, 1, False), (478, False, 2, False), (478, False, 3, True), (239, False, 2, True),
-                                           (240, True, 1, False), (718, True, 3, False)])
+                                           (240, True, 1, False), (718, True, 3, False), (1902, True, 4, False), (1451, False, 4, True), (879, False, 4, False)])
 def test_r2r_whose_embedding_length_needs_bluestein(run, oracle, N, dp, type, dst):
     """DCT/DST whose embedding FFT length has a prime factor outside the radix / Rader stages (DCT-I of 240: 478 = 2 * 239):
     the real transform's maps around a fused Bluestein transform (kernel_blue_r2r.h)."""

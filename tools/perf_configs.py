@@ -50,7 +50,7 @@ if __name__ == "__main__":
              (0, (2401,), False), (0, (1331,), False), (0, (2197,), False), (0, (127,), False), (0, (257,), False), (0, (1009,), False), (0, (4093,), False),
              (0, (1024,), True), (0, (4096,), True), (0, (1080,), True), (0, (65536,), True),
              (1, (1024, 1024), False), (12, (1024, 1024), False), (0, (512, 512, 512), False), (1, (4096,), False), (12, (4096,), False), (13, (4096,), False), (11, (1025,), False), (14, (1024,), False), (12, (1024,), False), (13, (1024,), False),
-             (0, (3 ** 10,), False), (0, (5 ** 8,), False), (0, (7 ** 7,), False), (0, (11 ** 5,), False), (0, (13 ** 5,), False), (0, (3 ** 13,), False), (0, (15319,), False), (0, (2000083,), False), (0, (21269,), False), (0, (524309,), False)]
+             (0, (3 ** 10,), False), (0, (5 ** 8,), False), (0, (7 ** 7,), False), (0, (11 ** 5,), False), (0, (13 ** 5,), False), (0, (3 ** 13,), False), (0, (15319,), False), (0, (2000083,), False), (0, (21269,), False), (0, (524309,), False), (0, (8191,), False), (1, (5606,), False), (14, (1451,), False)]
     if len(sys.argv) > 1:
         cases = cases[int(sys.argv[1]):int(sys.argv[2])]
     for k, shape, dp in cases:

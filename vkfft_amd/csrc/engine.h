@@ -100,7 +100,8 @@ int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipS
 bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads);
 bool pow2_col_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* tc, int* threads);
 bool pow2_col_blue_lookup(uint32_t log2l, bool dp, int mode, int* variant, int bits[4], int* tc, int* threads); // multi-pass Bluestein passes 1..3
-bool pow2_blue_r2r_lookup(uint32_t log2m, bool dp, uint32_t pre, int* variant, int bits[4], int* fpw, int* threads); // Bluestein-wrapped DCT/DST
+bool pow2_blue_r2r_lookup(uint32_t log2m, bool dp, uint32_t pre, int* variant, int bits[4], int* fpw, int* threads); // Bluestein-wrapped DCT/DST/R2C
+int launch_pow2_blue_r2r(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 bool pow2_blue_lookup(uint32_t log2m, bool dp, int* variant, int bits[4], int* fpw, int* threads); // fused Bluestein on padded length 2^log2m
 bool mixed_row_lookup(uint64_t n, bool dp, int* variant, int rad[5], int* fpw, int* threads);
 int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream);

@@ -3,10 +3,11 @@
 // Bluestein transform of the embedding length (vkFFT_Bluestein.h:32,201), in one kernel.  Same register-resident persistent
 // structure as pow2_blue_kernel (kernel_pow2.h): the embedding sequence of length blueN <= M/2 is gathered with pre_gather<PRE>,
 // chirp-multiplied, zero-padded to M = 2^k, transformed, multiplied by FFT(chirp)/M, transformed back, chirp-multiplied, and its
-// outputs leave through post_scatter<POST>.  Families: DCT-I, DST-I, DCT/DST-II and -III in their full-length forms.
+// outputs leave through post_scatter<POST>.  Families: DCT-I, DST-I, DCT/DST-II and -III in their full-length forms, DCT/DST-IV,
+// and R2C / C2R in their full-length ("callback") forms for real rows whose half length has such a prime factor.
 #pragma once
 #include "kernel_generic.h"
-#include "kernel_pow2.h"
+#include "kernel_pow2_core.h"
 #include "kernel_opfft.h"
 
 namespace vkfft_mi355x {
@@ -21,7 +22,8 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 	const uint32_t tid = threadIdx.x;
 	const uint32_t f = tid / TPF, tau = tid % TPF;
 	const uint32_t n = p.blueN; // embedding length (2N-2, 2N+2 or N); p.opN stays the real transform's N for the maps
-	const GBuf glut = make_gbuf(p.lut), gch = make_gbuf(p.aux3), gbh = make_gbuf(p.aux2);
+	// aux3 = chirp[0..n) followed by FFT(chirp)/M [0..M): aux and aux2 belong to the real transform's own maps
+	const GBuf glut = make_gbuf(p.lut), gch = make_gbuf(p.aux3), gbh = make_gbuf((const cx<T>*)p.aux3 + n);
 	cx<T> ch[EH], bh[E];
 #pragma unroll
 	for (int m = 0; m < EH; m++) { const uint32_t pos = tau + m * TPF; ch[m] = gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0); }
@@ -83,7 +85,9 @@ template <typename T, typename SCH, int FPW, int PRE, int POST> void pow2_blue_r
 	{ { (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, fpw, (((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (fpw)), &pow2_blue_r2r_launch<T, Pow2Sched<b0, b1, b2, b3>, fpw, pre, post> }, pre }
 #define VKFFT_P2BR(T, dp, b0, b1, b2, b3, fpw) \
 	VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, OP_DCT1_PRE, OP_DCT1_POST), VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, OP_DST1_PRE, OP_DST1_POST), \
-	VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, OP_DCT2_PRE, OP_DCT2_POST), VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, OP_DCT3_PRE, OP_DCT3_POST)
+	VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, OP_DCT2_PRE, OP_DCT2_POST), VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, OP_DCT3_PRE, OP_DCT3_POST), \
+	VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, OP_DCT4_PRE, OP_DCT4_POST), VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, OP_R2C_FULL, OP_R2C_FULL), \
+	VKFFT_P2BR1(T, dp, b0, b1, b2, b3, fpw, OP_C2R_FULL, OP_C2R_FULL)
 static const Pow2BlueR2rVariant kPow2BlueR2rVariants[] = {
 	VKFFT_P2BR(float, false, 3, 3, 0, 0, 32),
 	VKFFT_P2BR(float, false, 4, 3, 0, 0, 16),
@@ -93,6 +97,7 @@ static const Pow2BlueR2rVariant kPow2BlueR2rVariants[] = {
 	VKFFT_P2BR(float, false, 4, 4, 3, 0, 2),
 	VKFFT_P2BR(float, false, 4, 4, 4, 0, 1),
 	VKFFT_P2BR(float, false, 4, 3, 3, 3, 1),
+	VKFFT_P2BR(float, false, 4, 4, 3, 3, 1),
 	VKFFT_P2BR(double, true, 3, 3, 0, 0, 32),
 	VKFFT_P2BR(double, true, 3, 2, 2, 0, 16),
 	VKFFT_P2BR(double, true, 3, 3, 2, 0, 8),
@@ -100,15 +105,34 @@ static const Pow2BlueR2rVariant kPow2BlueR2rVariants[] = {
 	VKFFT_P2BR(double, true, 3, 3, 2, 2, 2),
 	VKFFT_P2BR(double, true, 3, 3, 3, 2, 1),
 	VKFFT_P2BR(double, true, 3, 3, 3, 3, 1),
+	VKFFT_P2BR(double, true, 4, 3, 3, 3, 1),
 };
 constexpr int kNumPow2BlueR2rVariants = (int)(sizeof(kPow2BlueR2rVariants) / sizeof(kPow2BlueR2rVariants[0]));
 
-inline int launch_pow2_blue_r2r(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
+int launch_pow2_blue_r2r(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
 	if (grid64 == 0) return 0;
 	if (grid64 > 0x7fffffffull || pp.variant < 0 || pp.variant >= kNumPow2BlueR2rVariants) return 4039;
 	kPow2BlueR2rVariants[pp.variant].v.launch(prm, dim3((uint32_t)grid64), stream);
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
+
+bool pow2_blue_r2r_lookup(uint32_t log2m, bool dp, uint32_t pre, int* variant, int bits[4], int* fpw, int* threads) {
+	switch (pre) { // DST members run on the DCT instance of their family
+	case OP_DST2_PRE: pre = OP_DCT2_PRE; break;
+	case OP_DST3_PRE: pre = OP_DCT3_PRE; break;
+	case OP_DST4_PRE: pre = OP_DCT4_PRE; break;
+	default: break;
+	}
+	for (int i = 0; i < kNumPow2BlueR2rVariants; i++) {
+		const Pow2BlueR2rVariant& e = kPow2BlueR2rVariants[i];
+		if (e.v.log2n != (int)log2m || e.v.dp != dp || (uint32_t)e.pre != pre) continue;
+		*variant = i;
+		for (int k = 0; k < 4; k++) bits[k] = e.v.bits[k];
+		*fpw = e.v.fpw; *threads = e.v.threads;
+		return true;
+	}
+	return false;
 }
 
 } // namespace vkfft_mi355x

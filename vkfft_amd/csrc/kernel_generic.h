@@ -128,7 +128,7 @@ __device__ inline cx<T> pre_gather(const PassParams& p, const IO& io, uint32_t p
 	case OP_DCT4_PRE: case OP_DST4_PRE: {
 		const uint32_t N = p.opN;
 		const bool dst = op == OP_DST4_PRE;
-		if (p.L * 2 == N) { // even N: half-length complex FFT
+		if ((p.blueN ? p.blueN : p.L) * 2 == N) { // even N: half-length complex FFT
 			uint32_t i0 = 2 * pos, i1 = N - 1 - 2 * pos;
 			if (dst) { i0 = N - 1 - i0; i1 = N - 1 - i1; }
 			T a = io.ldr(i0), b = io.ldr(i1);
@@ -230,7 +230,7 @@ __device__ inline void post_store(const PassParams& p, const IO& io, uint32_t k,
 	case OP_DCT4_POST: case OP_DST4_POST: {
 		const uint32_t N = p.opN;
 		T v;
-		if (p.L * 2 == N) {
+		if ((p.blueN ? p.blueN : p.L) * 2 == N) {
 			const uint32_t m = (k & 1) ? (N - 1 - k) >> 1 : k >> 1;
 			cx<T> c = cmul(rd(m), ((const cx<T>*)p.aux2)[m]);
 			v = (k & 1) ? (T)-2 * c.y : (T)2 * c.x;

@@ -44,7 +44,7 @@ __device__ inline void post_scatter(const PassParams& p, const IO& io, const uin
 		return;
 	}
 	case OP_DCT4_POST: case OP_DST4_POST:
-		if (p.L * 2 == N) { // half-length form: FFT output m feeds outputs 2m and N-1-2m
+		if ((p.blueN ? p.blueN : p.L) * 2 == N) { // half-length form: FFT output m feeds outputs 2m and N-1-2m
 			post_store<T>(p, io, 2 * a, colIdx, nat, rd, op);
 			post_store<T>(p, io, N - 1 - 2 * a, colIdx, nat, rd, op);
 		} else if (a < N) post_store<T>(p, io, a, colIdx, nat, rd, op);

@@ -1,108 +1,8 @@
-// Hand-specialised power-of-two kernels for the headline path (batched unit-stride C2C, N = 2^2..2^13/14).
-//
-// Design (MI355X-first, not a translation of the reference's generated code):
-//   * every thread keeps E = 2^LOGE points in registers; register m holds point tau + m*TPF of its FFT
-//     (TPF = N/E threads per FFT), which is simultaneously
-//        - the coalesced global access pattern (lane tau -> consecutive 8/16-byte elements),
-//        - the input set of the thread's Stockham butterflies in EVERY stage (t + i*N/R), and
-//        - the output set of the last stage,
-//     so data goes HBM -> registers -> (LDS exchange between stages only) -> registers -> HBM:
-//     one HBM read, one HBM write, (stages-1) LDS round trips, no LDS staging of loads/stores;
-//   * stage radices up to 16 (2^B0 * 2^B1 * ...), butterflies fully unrolled in registers;
-//   * twiddles come from a per-stage LUT laid out [(i-1)*S + s] so that the lanes of a wave read
-//     consecutive entries (the same layout the reference's LUT uses, vkFFT_ManageLUT.h:985-1011);
-//   * LDS exchange index a -> a + (a >> LOGE): conflict-free ds_write_b64 for the strided Stockham
-//     scatter (t-s)*R + s + k*S and conflict-free ds_read_b64 for the gather tau + m*TPF;
-//   * FFTs with TPF <= 64 live inside one wavefront: their exchanges need no s_barrier, only LDS
-//     ordering within the wave (wave-synchronous exchange);
-//   * inverse transforms reuse the forward code through the re/im swap identity; normalisation is a
-//     multiply at the store.
+// Hand-specialised power-of-two kernels and their registries (design notes: kernel_pow2_core.h).
 #pragma once
-#include "engine.h"
-#include "butterflies.h"
-#include "memops.h"
-#include <cstdlib>
+#include "kernel_pow2_core.h"
 
 namespace vkfft_mi355x {
-
-
-
-template <int B0, int B1, int B2, int B3> struct Pow2Sched {
-	static constexpr int bits[4] = {B0, B1, B2, B3};
-	static constexpr int NS = (B0 > 0) + (B1 > 0) + (B2 > 0) + (B3 > 0);
-	static constexpr int LOGN = B0 + B1 + B2 + B3;
-	static constexpr int LOGE = B0 > B1 ? (B0 > B2 ? (B0 > B3 ? B0 : B3) : (B2 > B3 ? B2 : B3)) : (B1 > B2 ? (B1 > B3 ? B1 : B3) : (B2 > B3 ? B2 : B3));
-	__host__ __device__ static constexpr int logS(int si) { return si == 0 ? 0 : si == 1 ? B0 : si == 2 ? B0 + B1 : B0 + B1 + B2; }
-	__host__ __device__ static constexpr int lutOff(int si) { // complex elements before stage si's run
-		int off = 0;
-		for (int j = 1; j < si; j++) off += ((1 << bits[j]) - 1) << logS(j);
-		return off;
-	}
-};
-
-// LDS slot of FFT element a: row kernels pad the index (a + a>>LOGE) inside the FFT's own slab; column
-// kernels keep TCP = TC+1 columns per element row ([a][c], odd pitch) and ldsf already points at column c.
-template <int TCP, int LOGE> __device__ inline uint32_t pow2_slot(uint32_t a) {
-	if constexpr (TCP == 0) return a + (a >> LOGE);
-	else return a * TCP;
-}
-
-// stage-twiddle source: global LUT through a buffer resource (row kernels) or a copy of the LUT in LDS (persistent
-// column kernel: keeps the vector-memory queue free for the next tile's prefetch — vmcnt retires in issue order,
-// so any later VMEM load that is consumed would drag the prefetched tile's latency into the critical path)
-template <typename T> struct TwGlobal {
-	GBuf lut;
-	__device__ inline cx<T> get(uint32_t s, uint32_t constOff) const { return gb_load<T>(lut, s * (uint32_t)sizeof(cx<T>), constOff * (uint32_t)sizeof(cx<T>)); }
-};
-template <typename T> struct TwLds {
-	const cx<T>* tab;
-	__device__ inline cx<T> get(uint32_t s, uint32_t constOff) const { return tab[constOff + s]; }
-};
-
-template <typename T, typename SCH, int SI, int TPF, int TCP, typename TW>
-__device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const TW lut, const uint32_t tau, const bool waveOnly) {
-	constexpr int LOGE = SCH::LOGE, E = 1 << LOGE;
-	constexpr int LOGR = SCH::bits[SI], R = 1 << LOGR, NB = E / R;
-	constexpr int LOGS = SCH::logS(SI), S = 1 << LOGS;
-	constexpr bool last = (SI == SCH::NS - 1);
-#pragma unroll
-	for (int b = 0; b < NB; b++) {
-		cx<T> x[R];
-#pragma unroll
-		for (int i = 0; i < R; i++) x[i] = v[b + i * NB];
-		const uint32_t t = tau + b * TPF;
-		const uint32_t s = t & (S - 1);
-		if constexpr (SI > 0) {
-			constexpr int LO = SCH::lutOff(SI);
-#pragma unroll
-			for (int i = 1; i < R; i++) x[i] = cmul(x[i], lut.get(s, (uint32_t)(LO + (i - 1) * S)));
-		}
-		dft<R, T>(x);
-		if constexpr (last) {
-#pragma unroll
-			for (int k = 0; k < R; k++) v[b + k * NB] = x[k];
-		} else {
-			const uint32_t ob = ((t - s) << LOGR) + s;
-#pragma unroll
-			for (int k = 0; k < R; k++) {
-				const uint32_t a = ob + k * S;
-				ldsf[pow2_slot<TCP, LOGE>(a)] = x[k];
-			}
-		}
-	}
-	if constexpr (!last) {
-		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
-#pragma unroll
-		for (int m = 0; m < E; m++) {
-			const uint32_t a = tau + m * TPF;
-			v[m] = ldsf[pow2_slot<TCP, LOGE>(a)];
-		}
-		if constexpr (SI + 2 < SCH::NS) { // another exchange will overwrite the buffer: all reads must be done first
-			if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
-		}
-		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, TCP, TW>(v, ldsf, lut, tau, waveOnly);
-	}
-}
 
 template <typename T, typename SCH, int FPW>
 __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_row_kernel(const PassParams p) {
@@ -144,24 +44,6 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_ro
 	}
 #pragma unroll
 	for (int m = 0; m < E; m++) gb_store<T>(gout, laneOut, (uint32_t)(m * TPF) * ES, v[m]);
-}
-
-inline unsigned pow2_num_cus() {
-	static unsigned n = 0;
-	if (!n) {
-#if defined(VKFFT_HOSTEMU)
-		n = 4;
-#else
-		int dev = 0, v = 0;
-		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = (unsigned)v; else n = 256;
-#endif
-	}
-	return n;
-}
-inline unsigned pow2_persist_mult() { // tuning knob: resident-grid multiplier (1 = exactly resident)
-	static int m = 0;
-	if (!m) { const char* e = getenv("VKFFT_MI355X_PERSIST_MULT"); m = e ? atoi(e) : 1; if (m < 1) m = 1; }
-	return (unsigned)m;
 }
 
 // ---- fused Bluestein (chirp-z) rows of length n <= M/2 on a power-of-two padded length M ---------------------------
@@ -437,10 +319,6 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 }
 
 // ---- registry --------------------------------------------------------------------------------------------
-struct Pow2Variant {
-	int log2n; bool dp; int bits[4]; int fpw; int threads; // fpw: FFTs per workgroup (row) / columns per workgroup (col)
-	void (*launch)(const PassParams&, dim3, hipStream_t);
-};
 
 template <typename T, typename SCH, int FPW> void pow2_row_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
 	constexpr int threads = ((1 << SCH::LOGN) >> SCH::LOGE) * FPW;
@@ -526,6 +404,7 @@ static const Pow2Variant kPow2BlueVariants[] = {
 	VKFFT_P2B(float, false, 4, 4, 3, 0, 2),
 	VKFFT_P2B(float, false, 4, 4, 4, 0, 1),
 	VKFFT_P2B(float, false, 4, 3, 3, 3, 1),
+	VKFFT_P2B(float, false, 4, 4, 3, 3, 1),
 	VKFFT_P2B(double, true, 3, 3, 0, 0, 32),
 	VKFFT_P2B(double, true, 3, 2, 2, 0, 16),
 	VKFFT_P2B(double, true, 3, 3, 2, 0, 8),
@@ -533,6 +412,7 @@ static const Pow2Variant kPow2BlueVariants[] = {
 	VKFFT_P2B(double, true, 3, 3, 2, 2, 2),
 	VKFFT_P2B(double, true, 3, 3, 3, 2, 1),
 	VKFFT_P2B(double, true, 3, 3, 3, 3, 1),
+	VKFFT_P2B(double, true, 4, 3, 3, 3, 1),
 };
 constexpr int kNumPow2BlueVariants = (int)(sizeof(kPow2BlueVariants) / sizeof(kPow2BlueVariants[0]));
 

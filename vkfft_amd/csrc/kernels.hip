@@ -5,7 +5,6 @@
 #include "kernel_pow2.h"
 #include "kernel_opfft.h"
 #include "kernel_mixed.h"
-#include "kernel_blue_r2r.h"
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -171,18 +170,6 @@ bool pow2_col_blue_lookup(uint32_t log2l, bool dp, int mode, int* variant, int b
 		*variant = i;
 		for (int k = 0; k < 4; k++) bits[k] = e.v.bits[k];
 		*tc = e.v.fpw; *threads = e.v.threads;
-		return true;
-	}
-	return false;
-}
-bool pow2_blue_r2r_lookup(uint32_t log2m, bool dp, uint32_t pre, int* variant, int bits[4], int* fpw, int* threads) {
-	pre = opfft_family(pre);
-	for (int i = 0; i < kNumPow2BlueR2rVariants; i++) {
-		const Pow2BlueR2rVariant& e = kPow2BlueR2rVariants[i];
-		if (e.v.log2n != (int)log2m || e.v.dp != dp || (uint32_t)e.pre != pre) continue;
-		*variant = i;
-		for (int k = 0; k < 4; k++) bits[k] = e.v.bits[k];
-		*fpw = e.v.fpw; *threads = e.v.threads;
 		return true;
 	}
 	return false;

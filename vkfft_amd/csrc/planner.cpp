@@ -661,9 +661,10 @@ static int emit_multipass_strided(const PassBuild& proto, uint64_t N, const std:
 
 // Bluestein tables of a length-N transform through padded length M: chirp[n] = exp(+i pi n^2 / N) (the kernels multiply by its
 // conjugate; vkFFT_RecursiveFFTGenerators.h:139-148) and FFT_M of the wrapped chirp, scaled by 1/M.
-static void make_bluestein_tables(uint64_t N, uint64_t M, bool dp, Arena& ar, size_t& chirpOff, size_t& bhatOff) {
+static void make_bluestein_tables(uint64_t N, uint64_t M, bool dp, Arena& ar, size_t& chirpOff, size_t& bhatOff, bool oneBlock = false) {
 	const size_t es = dp ? 16 : 8;
-	chirpOff = ar.alloc(N * es); bhatOff = ar.alloc(M * es);
+	if (oneBlock) { chirpOff = ar.alloc((N + M) * es); bhatOff = chirpOff + N * es; } // FFT(chirp) right behind the chirp: one pointer serves both
+	else { chirpOff = ar.alloc(N * es); bhatOff = ar.alloc(M * es); }
 	// FFT(chirp) is identical for the forward and the inverse plan of an application: keep the last one
 	static std::mutex mtx; static uint64_t cN = 0, cM = 0; static std::vector<cld> cChirp, cBhat;
 	std::lock_guard<std::mutex> lock(mtx);
@@ -723,7 +724,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 			if (Mp > cap && Mp * (dp ? 16 : 8) <= (1ull << 30)) M = Mp; // 32-bit byte offsets inside one padded row (buffer addressing)
 		}
 		std::vector<uint64_t> spM;
-		if (M > cap) {
+		if (M > cap && !fusedM) { // (the fused kernel holds its padded row in up to 139 KiB of LDS: one pass)
 			if (!unit) return 3002;
 			// M must split into column-kernel lengths; prefer a power of two when the smooth size does not split well
 			if (!choose_split(M, dp, d.maxLds, dmax, !d.disableFastKernels, spM)) {
@@ -963,9 +964,21 @@ static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vecto
 	PassBuild b;
 	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax; b.allowFast = false; b.allowOp = !d.disableFastKernels;
 	b.opN = (uint32_t)N; b.scale = scale;
-	const bool even = (N % 2 == 0);
+	bool even = (N % 2 == 0);
 	b.L = even ? N / 2 : N;
-	if (!is_supported_len(b.L, dmax)) return 3003;
+	uint64_t blueM = 0; // padded length of the Bluestein-wrapped full-length form (kernel_blue_r2r.h), 0: not used
+	int blueVariant = 0, blueBits[4] = {0, 0, 0, 0}, blueFpw = 0, blueThr = 0;
+	if (!is_supported_len(b.L, dmax)) {
+		// the (half) length has a prime factor outside the radix / Rader stages: full-length "callback" form (real -> (x, 0),
+		// keep the first N/2+1 outputs; vkFFT_R2C.h:27) around a fused Bluestein transform of length N
+		if (d.disableFastKernels) return 3003;
+		uint64_t Mp = 64; while (Mp < 2 * N - 1) Mp *= 2;
+		uint64_t pitch = N + 2;
+		if (!othersReal.empty()) pitch = (uint64_t)std::max<int64_t>(std::llabs(othersReal[0].inStride), 2 * std::llabs(othersCplx[0].inStride));
+		if ((pitch * 64 + 2 * N) * (dp ? 8 : 4) >= 0x7FFFFF00ull) return 3003; // 32-bit buffer offsets inside a tile of rows
+		if (!pow2_blue_r2r_lookup(ilog2(Mp), dp, inverse ? OP_C2R_FULL : OP_R2C_FULL, &blueVariant, blueBits, &blueFpw, &blueThr)) return 3003;
+		blueM = Mp; even = false; b.L = N;
+	}
 	// rows: combine the real-side and complex-side strides per dim
 	std::vector<HostDim> dims;
 	for (size_t i = 0; i < othersReal.size(); i++) {
@@ -1030,6 +1043,14 @@ static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vecto
 	b.inRole = inverse ? cplxRole : realRole;
 	b.outRole = inverse ? realRole : cplxRole;
 	b.label = inverse ? "c2r" : "r2c";
+	if (blueM) {
+		size_t chirpOff, bhatOff;
+		make_bluestein_tables(N, blueM, dp, ar, chirpOff, bhatOff, true);
+		b.L = blueM; b.blueN = (uint32_t)N;
+		b.midOp = OP_BLUESTEIN_MID; b.auxOff2ForPre = chirpOff;
+		b.fastKernel = KERNEL_POW2_BLUE_R2R; b.fastVariant = blueVariant; b.fastThreads = blueThr; b.forceT = (uint32_t)blueFpw;
+		for (int k = 0; k < 4; k++) if (blueBits[k]) b.radices.push_back(1u << blueBits[k]);
+	}
 	PassPlan pp; int r = finish_pass(b, ar, pp); if (r) return r == 3002 ? 3003 : r;
 	passes.push_back(pp);
 	out.uploadsPerAxis[0] = 1;
@@ -1108,7 +1129,7 @@ static int plan_r2r_axis(const TransformDesc& d, int type, bool dst, uint64_t N,
 	if (!is_supported_len(b.L, dmax)) {
 		// the embedding length has a prime factor outside the radix / Rader stages (e.g. DST-I of 100: 202 = 2 * 101): the
 		// real transform's maps around a fused Bluestein transform of the embedding length (kernel_blue_r2r.h), unit-stride rows
-		if (!unit || d.disableFastKernels || type == 4) return 3004;
+		if (!unit || d.disableFastKernels) return 3004;
 		uint64_t Lb = b.L;
 		if (type == 2 || type == 3) { // full-length forms (the half-length post-map is not element-wise)
 			Lb = N;
@@ -1127,9 +1148,9 @@ static int plan_r2r_axis(const TransformDesc& d, int type, bool dst, uint64_t N,
 		const uint64_t rowPitch = others.empty() ? N : (uint64_t)std::max<int64_t>(std::llabs(others[0].inStride), std::llabs(others[0].outStride));
 		if ((rowPitch * 64 + 2 * N) * (dp ? 8 : 4) >= 0x7FFFFF00ull || !pow2_blue_r2r_lookup(ilog2(Mp), dp, b.preOp, &variant, bits, &fpw, &thr)) return 3004;
 		size_t chirpOff, bhatOff;
-		make_bluestein_tables(Lb, Mp, dp, ar, chirpOff, bhatOff);
+		make_bluestein_tables(Lb, Mp, dp, ar, chirpOff, bhatOff, true); // aux / aux2 stay with the real transform's own tables
 		b.L = Mp; b.blueN = (uint32_t)Lb;
-		b.midOp = OP_BLUESTEIN_MID; b.aux2Off = bhatOff; b.auxOff2ForPre = chirpOff;
+		b.midOp = OP_BLUESTEIN_MID; b.auxOff2ForPre = chirpOff;
 		b.fastKernel = KERNEL_POW2_BLUE_R2R; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
 		b.radices.clear();
 		for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
