@@ -153,6 +153,7 @@ struct PassParams {
 	FastDiv divS[kMaxStages];
 	uint32_t ldsElems;   // elements per LDS buffer (two buffers are used)
 	uint32_t tilesPerG0; // ceil(dim[0].count / T)
+	uint32_t reverseTiles; // 1: workgroup i works on tile (grid - 1 - i): inverse plans sweep the buffer back to front
 	uint32_t inElemBytes, outElemBytes; // bytes per global element on each side (real scalar or complex)
 };
 

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 	for (int m = 0; m < E; m++) bh[m] = gb_load<T>(gbh, (tau + m * TPF) * ES, 0);
 	const uint32_t tiles = p.tilesPerG0 * p.dim[1].count * p.dim[2].count;
 	for (uint32_t wgi = blockIdx.x; wgi < tiles; wgi += gridDim.x) {
-		uint32_t wg = wgi;
+		uint32_t wg = p.reverseTiles ? tiles - 1u - wgi : wgi;
 		const uint32_t tile = wg % p.tilesPerG0;
 		wg /= p.tilesPerG0;
 		const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;

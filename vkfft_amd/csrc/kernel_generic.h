@@ -439,7 +439,7 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 	const uint32_t tid = threadIdx.x, nthr = blockDim.x;
 
 	// which tile of which (g1,g2)
-	uint32_t wg = blockIdx.x;
+	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
 	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;

@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	__shared__ cx<T> lds[FPW * LDSPF];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t f = COL ? tid % FPW : tid / TPF, tau = COL ? tid / FPW : tid % TPF;
-	uint32_t wg = blockIdx.x;
+	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
 	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;

@@ -13,7 +13,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_ro
 	__shared__ cx<T> lds[FPW * LDSPF];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t f = tid / TPF, tau = tid % TPF;
-	uint32_t wg = blockIdx.x;
+	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
 	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 	const uint32_t tiles = p.tilesPerG0 * p.dim[1].count * p.dim[2].count;
 	const T sc = (T)p.scale;
 	for (uint32_t wgi = blockIdx.x; wgi < tiles; wgi += gridDim.x) {
-		uint32_t wg = wgi;
+		uint32_t wg = p.reverseTiles ? tiles - 1u - wgi : wgi;
 		const uint32_t tile = wg % p.tilesPerG0;
 		wg /= p.tilesPerG0;
 		const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;

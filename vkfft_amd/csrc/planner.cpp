@@ -1302,6 +1302,10 @@ int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
 		}
 	}
 	if (d.userTempBytes && out.tempBytes > d.userTempBytes) return 2016;
+	// inverse plans sweep their tiles back to front: a forward transform followed by the inverse on the same buffer (the usual
+	// pattern, and the benchmark protocol) then starts on the data the previous launch wrote last, which is still in the
+	// 256 MiB Infinity Cache; costs nothing otherwise
+	if (d.inverse && !getenv("VKFFT_MI355X_NO_REVERSE")) for (PassPlan& q : out.passes) q.prm.reverseTiles = 1;
 	return 0;
 }
 
