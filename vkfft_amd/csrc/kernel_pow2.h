@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 	__shared__ cx<T> lds[L * TCP];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t c = tid % TC, tau = tid / TC;
-	uint32_t wg = blockIdx.x;
+	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
 	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 	__shared__ cx<T> lds[L * TCP];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t c = tid % TC, tau = tid / TC;
-	uint32_t wg = blockIdx.x;
+	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
 	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
