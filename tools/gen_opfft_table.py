@@ -7,7 +7,7 @@ import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gen_mixed_table import best_radices
 
-POW2 = [1 << k for k in range(2, 13)]
+POW2 = [1 << k for k in range(2, 14)]  # complex FFT lengths up to 8192 (fp32) / 4096 (fp64): R2C rows up to 16384 / 8192 reals
 # complex FFT lengths L of popular non-power-of-two real sizes (N = L for DCT-II/III, N = 2L for R2C / DCT-IV)
 NONPOW2 = [6, 10, 12, 20, 24, 30, 40, 48, 50, 60, 80, 96, 100, 120, 125, 160, 192, 200, 240, 243, 250, 320, 343, 360, 384, 400, 480, 500, 540, 600, 625,
            640, 720, 729, 768, 800, 960, 1000, 1080, 1200, 1280, 1440, 1536, 1600, 1920, 2000, 2160, 2187, 2400, 2560, 3000, 3072, 3125, 3840, 4000]
@@ -110,7 +110,7 @@ def main():
                 for n in sorted(set(lens) | (set(FOURSTEP_EXTRA) if fourstep and not dp else set())):
                     ispow2 = n & (n - 1) == 0
                     if pow2only and not ispow2: continue
-                    if dp and n > 2048: continue
+                    if dp and n > 4096: continue
                     if fourstep and ispow2 and n <= 1024: continue  # pow2_col_kernel covers these
                     if fam in ("dct2", "dct3") and n % 2 == 0: continue  # even lengths take the half-length form
                     r = plan_col(n, dp, real) if col else plan_row(n, dp, {"dct2h": "first", "dct3h": "last"}.get(fam))
