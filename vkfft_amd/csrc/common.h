@@ -141,7 +141,10 @@ struct PassParams {
 	uint32_t bluesteinSwapIn, bluesteinSwapOut;
 	uint32_t inLen, outLen; // elements gathered / stored per sub-FFT (differ from L for real transforms, Bluestein)
 	uint32_t opN;        // logical transform size of the pre/post op (e.g. real length N of R2C / DCT)
-	uint32_t blueN;      // Bluestein-wrapped real transforms: length of the embedding sequence (opN stays the real N)
+	uint32_t blueN;      // Bluestein-wrapped / multi-pass real transforms: length of the embedding sequence (opN stays the real N)
+	// multi-pass real transforms: the pre-map of the first pass / post-map of the last pass address the ROW by the natural FFT index
+	// n = g0*opStride0 + g1*opStride1 + j*opStrideJ; natDimMask bit i = grid dim i is part of that index (not of the row's address)
+	uint32_t preNat, postNat, natDimMask, natOutLen;
 	uint32_t opStrideJ, opStride0, opStride1; // position-indexed ops (Bluestein chirp, pointwise LUT): natural index = j*opStrideJ + g0*opStride0 + g1*opStride1
 	uint32_t fsN;        // 4-step: twiddle exponent denominator (product of all pass lengths of this decomposition level)
 	uint32_t fsLoBits;   // 4-step two-level LUT: aux = 2^fsLoBits low entries followed by the high entries

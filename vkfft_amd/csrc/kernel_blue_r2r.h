@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 			const uint32_t pos = tau + m * TPF;
 			cx<T> y = cmulc(cswap(v[m]), ch[m]);
 			if (p.swapOut) y = cswap(y);
-			if (pos < n) post_scatter<T>(p, io, pos, y, 0, nat, op_resolve<POST>(p.postOp)); // applies the scale
+			if (pos < n) post_scatter<T>(p, io, pos, y, 0, nat, op_resolve<POST>(p.postOp), p.outLen); // applies the scale
 		}
 		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); }
 	}

@@ -92,7 +92,7 @@ __device__ inline cx<T> pre_gather(const PassParams& p, const IO& io, uint32_t p
 			a = io.ldr(N - 1 - pos);
 			b = pos == 0 ? (T)0 : io.ldr(pos - 1);
 		}
-		cx<T> w = cconj(((const cx<T>*)p.aux)[pos]);
+		cx<T> w = cconj(((const cx<T>*)(p.preNat ? p.aux3 : p.aux))[pos]); // (preNat: first pass of a multi-pass plan, whose aux is the Four-Step table: the map's own table is aux3)
 		return cmul(w, cx<T>{a, -b});
 	}
 	case OP_DCT2H_PRE: case OP_DST2H_PRE: { // L = N/2: z[n] = v[2n] + i v[2n+1], v = Makhoul permutation of x
@@ -132,11 +132,11 @@ __device__ inline cx<T> pre_gather(const PassParams& p, const IO& io, uint32_t p
 			uint32_t i0 = 2 * pos, i1 = N - 1 - 2 * pos;
 			if (dst) { i0 = N - 1 - i0; i1 = N - 1 - i1; }
 			T a = io.ldr(i0), b = io.ldr(i1);
-			return cmul(cx<T>{a, b}, ((const cx<T>*)p.aux)[pos]);
+			return cmul(cx<T>{a, b}, ((const cx<T>*)(p.preNat ? p.aux3 : p.aux))[pos]);
 		}
 		if (pos >= N) return zero; // L = 2N, zero padded
 		T a = io.ldr(dst ? N - 1 - pos : pos);
-		return cscale(((const cx<T>*)p.aux)[pos], a);
+		return cscale(((const cx<T>*)(p.preNat ? p.aux3 : p.aux))[pos], a);
 	}
 	case OP_BLUESTEIN_PRE: {
 		const uint32_t n = natBase + pos * p.opStrideJ; // natural position inside the transform
@@ -250,6 +250,42 @@ __device__ inline void post_store(const PassParams& p, const IO& io, uint32_t k,
 		io.stc(k, cscale(v, sc));
 		return;
 	}
+	}
+}
+
+// scatter form of the post-maps: FFT output `a` of this sub-FFT with value v -> its output element(s)
+template <typename T, typename IO>
+__device__ inline void post_scatter(const PassParams& p, const IO& io, const uint32_t a, const cx<T> v, const uint32_t colIdx, const uint32_t nat, const uint32_t op, const uint32_t outLimit) {
+	auto rd = [&](uint32_t) { return v; };
+	const uint32_t N = p.opN;
+	switch (op) {
+	default: // OP_NONE, OP_TWIDDLE_4STEP, OP_MUL_LUT, OP_BLUESTEIN_POST, OP_R2C_FULL, OP_C2R_FULL, OP_DCT1_POST: output a <- FFT output a
+		if (a < outLimit) post_store<T>(p, io, a, colIdx, nat, rd, op);
+		return;
+	case OP_DST1_POST:
+		if (a >= 1 && a <= N) post_store<T>(p, io, a - 1, colIdx, nat, rd, op);
+		return;
+	case OP_DCT2_POST:
+		post_store<T>(p, io, a, colIdx, nat, rd, op);
+		return;
+	case OP_DST2_POST:
+		post_store<T>(p, io, N - 1 - a, colIdx, nat, rd, op);
+		return;
+	case OP_DCT3_POST: case OP_DST3_POST:
+		post_store<T>(p, io, a < (N + 1) / 2 ? 2 * a : 2 * (N - 1 - a) + 1, colIdx, nat, rd, op);
+		return;
+	case OP_DCT3H_POST: case OP_DST3H_POST: { // FFT output a = v[2a] + i v[2a+1]; v[m] is output m < N/2 ? 2m : 2(N-1-m)+1
+		const uint32_t m0 = 2 * a, m1 = 2 * a + 1, H = N >> 1;
+		post_store<T>(p, io, m0 < H ? 2 * m0 : 2 * (N - 1 - m0) + 1, colIdx, nat, rd, op);
+		post_store<T>(p, io, m1 < H ? 2 * m1 : 2 * (N - 1 - m1) + 1, colIdx, nat, rd, op);
+		return;
+	}
+	case OP_DCT4_POST: case OP_DST4_POST:
+		if ((p.blueN ? p.blueN : p.L) * 2 == N) { // half-length form: FFT output m feeds outputs 2m and N-1-2m
+			post_store<T>(p, io, 2 * a, colIdx, nat, rd, op);
+			post_store<T>(p, io, N - 1 - 2 * a, colIdx, nat, rd, op);
+		} else if (a < N) post_store<T>(p, io, a, colIdx, nat, rd, op);
+		return;
 	}
 }
 
@@ -459,8 +495,15 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 			else p.divL.divmod(idx, f, pos);
 			cx<T> v = {(T)0, (T)0};
 			if (f < nvalid) {
-				const Io64<T> io{p.in, p.out, inBase + (int64_t)f * p.dim[0].inStride, 0, p.inStrideJ, p.outStrideJ};
-				v = pre_gather<T>(p, io, pos, (g0base + f) * p.opStride0 + g1 * p.opStride1, p.preOp);
+				if (p.preNat) { // multi-pass real transform: FFT input n of the row = pre-map of the row's elements
+					const uint32_t n = (g0base + f) * p.opStride0 + g1 * p.opStride1 + pos * p.opStrideJ;
+					const int64_t rowBase = ((p.natDimMask & 2u) ? 0 : (int64_t)g1 * p.dim[1].inStride) + ((p.natDimMask & 4u) ? 0 : (int64_t)g2 * p.dim[2].inStride);
+					const Io64<T> io{p.in, p.out, rowBase, 0, 1, 1};
+					v = pre_gather<T>(p, io, n, 0, p.preOp);
+				} else {
+					const Io64<T> io{p.in, p.out, inBase + (int64_t)f * p.dim[0].inStride, 0, p.inStrideJ, p.outStrideJ};
+					v = pre_gather<T>(p, io, pos, (g0base + f) * p.opStride0 + g1 * p.opStride1, p.preOp);
+				}
 			}
 			if (p.swapIn) v = cswap(v);
 			bufA[(pos + (pos >> ps)) * Tp + f] = v;
@@ -527,6 +570,13 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 			};
 			uint32_t colIdx = 0;
 			if (p.postOp == OP_TWIDDLE_4STEP) { if (p.fsColFromDim1) colIdx = g1; else { uint32_t qq, rr; p.fsColDiv.divmod(g0base + f, qq, rr); colIdx = qq; } }
+			if (p.postNat) { // multi-pass real transform: FFT output n of the row -> post-map -> the row's elements
+				const uint32_t n = (g0base + f) * p.opStride0 + g1 * p.opStride1 + k * p.opStrideJ;
+				const int64_t rowBase = ((p.natDimMask & 2u) ? 0 : (int64_t)g1 * p.dim[1].outStride) + ((p.natDimMask & 4u) ? 0 : (int64_t)g2 * p.dim[2].outStride);
+				const Io64<T> io{p.in, p.out, 0, rowBase, 1, 1};
+				post_scatter<T>(p, io, n, rd(k), 0, 0, p.postOp, p.natOutLen);
+				continue;
+			}
 			const Io64<T> io{p.in, p.out, 0, outBase + (int64_t)f * p.dim[0].outStride, p.inStrideJ, p.outStrideJ};
 			post_store<T>(p, io, k, colIdx, (g0base + f) * p.opStride0 + g1 * p.opStride1, rd, p.postOp);
 		}

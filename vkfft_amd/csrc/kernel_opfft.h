@@ -16,42 +16,6 @@
 
 namespace vkfft_mi355x {
 
-// scatter form of the post-maps: FFT output `a` of this sub-FFT with value v -> its output element(s)
-template <typename T, typename IO>
-__device__ inline void post_scatter(const PassParams& p, const IO& io, const uint32_t a, const cx<T> v, const uint32_t colIdx, const uint32_t nat, const uint32_t op) {
-	auto rd = [&](uint32_t) { return v; };
-	const uint32_t N = p.opN;
-	switch (op) {
-	default: // OP_NONE, OP_TWIDDLE_4STEP, OP_MUL_LUT, OP_BLUESTEIN_POST, OP_R2C_FULL, OP_C2R_FULL, OP_DCT1_POST: output a <- FFT output a
-		if (a < p.outLen) post_store<T>(p, io, a, colIdx, nat, rd, op);
-		return;
-	case OP_DST1_POST:
-		if (a >= 1 && a <= N) post_store<T>(p, io, a - 1, colIdx, nat, rd, op);
-		return;
-	case OP_DCT2_POST:
-		post_store<T>(p, io, a, colIdx, nat, rd, op);
-		return;
-	case OP_DST2_POST:
-		post_store<T>(p, io, N - 1 - a, colIdx, nat, rd, op);
-		return;
-	case OP_DCT3_POST: case OP_DST3_POST:
-		post_store<T>(p, io, a < (N + 1) / 2 ? 2 * a : 2 * (N - 1 - a) + 1, colIdx, nat, rd, op);
-		return;
-	case OP_DCT3H_POST: case OP_DST3H_POST: { // FFT output a = v[2a] + i v[2a+1]; v[m] is output m < N/2 ? 2m : 2(N-1-m)+1
-		const uint32_t m0 = 2 * a, m1 = 2 * a + 1, H = N >> 1;
-		post_store<T>(p, io, m0 < H ? 2 * m0 : 2 * (N - 1 - m0) + 1, colIdx, nat, rd, op);
-		post_store<T>(p, io, m1 < H ? 2 * m1 : 2 * (N - 1 - m1) + 1, colIdx, nat, rd, op);
-		return;
-	}
-	case OP_DCT4_POST: case OP_DST4_POST:
-		if ((p.blueN ? p.blueN : p.L) * 2 == N) { // half-length form: FFT output m feeds outputs 2m and N-1-2m
-			post_store<T>(p, io, 2 * a, colIdx, nat, rd, op);
-			post_store<T>(p, io, N - 1 - 2 * a, colIdx, nat, rd, op);
-		} else if (a < N) post_store<T>(p, io, a, colIdx, nat, rd, op);
-		return;
-	}
-}
-
 // the DST member of a DCT family at run time, everything else at compile time
 template <int OP> __device__ inline uint32_t op_resolve(const uint32_t runtimeOp) {
 	if constexpr (OP == OP_DCT2_PRE) return runtimeOp == OP_DST2_PRE ? OP_DST2_PRE : OP_DCT2_PRE;
@@ -179,7 +143,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 					if constexpr (last) {
 						const cx<T> v = p.swapOut ? cswap(x[b][k]) : x[b][k];
 						if constexpr (staged) ldsf[ob + k * S] = v; // natural order, unpadded: read back along k
-						else post_scatter<T>(p, io, ob + k * S, v, colIdx, nat, op_resolve<POST>(p.postOp));
+						else post_scatter<T>(p, io, ob + k * S, v, colIdx, nat, op_resolve<POST>(p.postOp), p.outLen);
 					} else ldsf[mix_slot<PADOUT>(ob + k * S)] = x[b][k];
 				}
 			}

@@ -109,6 +109,7 @@ struct PassBuild {
 	bool dp = false;
 	uint32_t preOp = OP_NONE, midOp = OP_NONE, postOp = OP_NONE;
 	uint32_t inLen = 0, outLen = 0, opN = 0, blueN = 0;
+	bool preNat = false, postNat = false; uint32_t natDimMask = 1, natOutLen = 0; // multi-pass real transforms (PassParams::preNat ...)
 	bool swapIn = false, swapOut = false, bsSwapIn = false, bsSwapOut = false;
 	uint64_t fsN = 0; uint32_t fsColDiv = 1; bool fsColFromDim1 = false;
 	uint32_t opStrideJ = 1, opStride0 = 0, opStride1 = 0; // natural-position index of element j of sub-FFT (g0,g1) for position-indexed ops
@@ -331,6 +332,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.inLen = b.inLen ? b.inLen : (uint32_t)b.L;
 	p.outLen = b.outLen ? b.outLen : (uint32_t)b.L;
 	p.opN = b.opN; p.blueN = b.blueN;
+	p.preNat = b.preNat ? 1 : 0; p.postNat = b.postNat ? 1 : 0; p.natDimMask = b.natDimMask; p.natOutLen = b.natOutLen;
 	p.opStrideJ = b.opStrideJ; p.opStride0 = b.opStride0; p.opStride1 = b.opStride1;
 	p.fsN = (uint32_t)b.fsN;
 	p.fsColDiv = make_fastdiv(b.fsColDiv);
@@ -521,6 +523,10 @@ struct MultiPassIO {
 	size_t firstAux = (size_t)-1, lastAux = (size_t)-1, lastAux2 = (size_t)-1;
 	bool bsSwapIn = false, bsSwapOut = false;
 	uint32_t opN = 0;
+	// real transforms through a multi-pass complex FFT of the embedding length: the first load / last store apply the real
+	// transform's pre / post map to the ROW, addressed by the natural FFT index (PassParams::preNat / postNat)
+	bool natural = false, firstRealIn = false, lastRealOut = false;
+	uint32_t natOutLen = 0, blueN = 0;
 };
 
 static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<uint64_t>& sp, const MultiPassIO& io, Arena& ar, std::vector<PassPlan>& passes) {
@@ -553,6 +559,7 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 	if (io.firstPre != OP_NONE) {
 		a.preOp = io.firstPre; a.auxOff2ForPre = io.firstAux; a.bsSwapIn = io.bsSwapIn; a.opN = io.opN;
 		a.opStrideJ = (uint32_t)M; a.opStride0 = 1; a.opStride1 = 0;
+		if (io.natural) { a.preNat = true; a.natDimMask = 1; a.realIn = io.firstRealIn; a.blueN = io.blueN; }
 	}
 	PassPlan pa; int r = finish_pass(a, ar, pa); if (r) return r;
 	passes.push_back(pa);
@@ -568,6 +575,7 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 		if (io.lastPost != OP_NONE) {
 			c.postOp = io.lastPost; c.auxOff = io.lastAux; c.aux2Off = io.lastAux2; c.bsSwapOut = io.bsSwapOut; c.opN = io.opN;
 			c.opStrideJ = (uint32_t)n0; c.opStride0 = 1; c.opStride1 = 0;
+			if (io.natural) { c.postNat = true; c.natDimMask = 1; c.natOutLen = io.natOutLen; c.realOut = io.lastRealOut; c.blueN = io.blueN; }
 		}
 		PassPlan pb; r = finish_pass(c, ar, pb); if (r) return r;
 		passes.push_back(pb);
@@ -593,6 +601,7 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 		if (io.lastPost != OP_NONE) {
 			c.postOp = io.lastPost; c.auxOff = io.lastAux; c.aux2Off = io.lastAux2; c.bsSwapOut = io.bsSwapOut; c.opN = io.opN;
 			c.opStrideJ = (uint32_t)(n0 * n1); c.opStride0 = 1; c.opStride1 = (uint32_t)n0;
+			if (io.natural) { c.postNat = true; c.natDimMask = 3; c.natOutLen = io.natOutLen; c.realOut = io.lastRealOut; c.blueN = io.blueN; }
 		}
 		PassPlan pc; r = finish_pass(c, ar, pc); if (r) return r;
 		passes.push_back(pb); passes.push_back(pc);
@@ -991,7 +1000,27 @@ static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vecto
 	if (b.L > max_row_len(dp, d.maxLds)) {
 		// long even rows: multi-pass half-length complex FFT + the pair pass of the even decomposition
 		// (reference: VkFFTPlanR2CMultiUploadDecomposition, vkFFT_Plan_R2C.h:30; kernel vkFFT_R2C_even_decomposition.h:40)
-		if (!even) return 3003;
+		if (!even) {
+			// odd rows longer than one pass: the full-length "callback" form (vkFFT_R2C.h:27) through a multi-pass complex FFT of
+			// length N; first load real -> (x, 0) / Hermitian expansion, last store the first N/2+1 outputs / the real part
+			if (blueM) return 3003;
+			std::vector<uint64_t> sp;
+			if (!choose_split(N, dp, d.maxLds, dmax, !d.disableFastKernels, sp)) return 3003;
+			MultiPassIO io;
+			for (auto& h : dims) { io.othersIn.push_back({h.count, h.inStride, h.inStride}); io.othersOut.push_back({h.count, h.outStride, h.outStride}); }
+			io.inRole = inverse ? cplxRole : realRole; io.outRole = inverse ? realRole : cplxRole;
+			io.swapIn = io.swapOut = inverse; io.scale = scale;
+			io.firstPre = inverse ? OP_C2R_FULL : OP_R2C_FULL; io.lastPost = io.firstPre;
+			io.natural = true; io.firstRealIn = !inverse; io.lastRealOut = inverse;
+			io.natOutLen = (uint32_t)(inverse ? N : N / 2 + 1); io.opN = (uint32_t)N; io.blueN = (uint32_t)N;
+			PassBuild proto; proto.dp = dp; proto.maxLds = d.maxLds; proto.raderDirectMax = dmax; proto.allowFast = !d.disableFastKernels; proto.allowOp = !d.disableFastKernels;
+			int r = emit_multipass(proto, N, sp, io, ar, passes); if (r) return r == 3002 ? 3003 : r;
+			uint64_t nsub = 1; for (auto& h : dims) nsub *= h.count;
+			out.tempBytes = std::max<uint64_t>(out.tempBytes, nsub * N * es);
+			out.uploadsPerAxis[0] = (uint32_t)sp.size();
+			out.axisSplit[0][0] = N;
+			return 0;
+		}
 		const uint64_t H = N / 2;
 		std::vector<uint64_t> sp;
 		if (!choose_split(H, dp, d.maxLds, dmax, !d.disableFastKernels, sp)) return 3003;
@@ -1154,7 +1183,42 @@ static int plan_r2r_axis(const TransformDesc& d, int type, bool dst, uint64_t N,
 		b.fastKernel = KERNEL_POW2_BLUE_R2R; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
 		b.radices.clear();
 		for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
-	} else if (b.L > (unit ? max_row_len(dp, d.maxLds) : max_col_len(dp, d.maxLds, 1))) return 3004;
+	} else if (b.L > (unit ? max_row_len(dp, d.maxLds) : max_col_len(dp, d.maxLds, 1))) {
+		// longer than one pass: the full-length form of the real transform through a multi-pass (Four-Step) complex FFT of the
+		// embedding length; the first load / last store apply the pre / post map to the row by natural index (the reference
+		// lifts the same limit: vkFFT_Scheduler.h:2894-2897)
+		if (!unit) return 3004;
+		uint64_t Lm = b.L;
+		MultiPassIO io;
+		if (type == 2 || type == 3) {
+			Lm = N;
+			io.firstPre = type == 2 ? (dst ? OP_DST2_PRE : OP_DCT2_PRE) : (dst ? OP_DST3_PRE : OP_DCT3_PRE);
+			io.lastPost = type == 2 ? (dst ? OP_DST2_POST : OP_DCT2_POST) : (dst ? OP_DST3_POST : OP_DCT3_POST);
+			io.swapIn = io.swapOut = type == 3;
+			if (b.auxOff == (size_t)-1) { size_t aux = ar.alloc(N * es); for (uint64_t k = 0; k < N; k++) ar.putc(aux, k, unit_root(k, 4 * N), dp); b.auxOff = aux; }
+			io.firstAux = type == 3 ? b.auxOff : (size_t)-1; io.lastAux = b.auxOff;
+		} else if (type == 4) { // zero-padded 2N form: its maps are element-wise
+			Lm = 2 * N;
+			size_t aux = ar.alloc(N * es), aux2 = ar.alloc(N * es);
+			for (uint64_t n = 0; n < N; n++) { ar.putc(aux, n, unit_root(n, 4 * N), dp); ar.putc(aux2, n, unit_root(2 * n + 1, 8 * N), dp); }
+			io.firstPre = b.preOp; io.lastPost = b.postOp; io.firstAux = aux; io.lastAux = aux; io.lastAux2 = aux2;
+		} else { io.firstPre = b.preOp; io.lastPost = b.postOp; }
+		if (Lm >= (1ull << 31) || !is_supported_len(Lm, dmax)) return 3004;
+		std::vector<uint64_t> sp;
+		if (!choose_split(Lm, dp, d.maxLds, dmax, !d.disableFastKernels, sp)) return 3004;
+		io.othersIn = others; io.othersOut = others;
+		for (auto& o : io.othersIn) o.outStride = o.inStride;
+		for (auto& o : io.othersOut) o.inStride = o.outStride;
+		io.inRole = inRole; io.outRole = outRole; io.scale = scale;
+		io.natural = true; io.firstRealIn = io.lastRealOut = true; io.natOutLen = (uint32_t)N; io.opN = (uint32_t)N; io.blueN = (uint32_t)Lm;
+		PassBuild proto; proto.dp = dp; proto.maxLds = d.maxLds; proto.raderDirectMax = dmax; proto.allowFast = !d.disableFastKernels; proto.allowOp = !d.disableFastKernels;
+		int r = emit_multipass(proto, Lm, sp, io, ar, passes); if (r) return r == 3002 ? 3004 : r;
+		uint64_t nsub = 1; for (auto& o : others) nsub *= o.count;
+		out.tempBytes = std::max<uint64_t>(out.tempBytes, nsub * Lm * es);
+		out.uploadsPerAxis[axisIndex] = (uint32_t)sp.size();
+		out.axisSplit[axisIndex][0] = N;
+		return 0;
+	}
 	PassPlan pp; int r = finish_pass(b, ar, pp); if (r) return r == 3002 ? 3004 : r;
 	passes.push_back(pp);
 	out.uploadsPerAxis[axisIndex] = 1;
