@@ -23,6 +23,8 @@ struct AppState {
 	hipEvent_t* events = nullptr;
 	uint32_t numEvents = 0;
 	ExecStreams xs;                // helper streams for chunk-pipelined multi-pass plans
+	uint32_t sweep = 0;            // zig-zag state: direction of the next launch's tile sweep
+	bool sweepEnabled = true;
 };
 
 VkFFTResult hip_to_result(hipError_t e, VkFFTResult code) { return e == hipSuccess ? VKFFT_SUCCESS : code; }
@@ -210,6 +212,7 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 	AppState* st = new (std::nothrow) AppState();
 	if (!st) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_MALLOC_FAILED; }
 	app->impl = st;
+	st->sweepEnabled = getenv("VKFFT_MI355X_NO_REVERSE") == nullptr;
 
 	VkFFTResult res = VKFFT_SUCCESS;
 	if (!c.makeForwardPlanOnly) {
@@ -309,7 +312,7 @@ VKFFT_API VkFFTResult VkFFTAppend(VkFFTApplication* app, int inverse, VkFFTLaunc
 	}
 	hipStream_t stream = 0;
 	if (c.stream && c.num_streams >= 1) stream = c.stream[0];
-	int r = execute_direction(*dp, lb, stream, &st->xs);
+	int r = execute_direction(*dp, lb, stream, &st->xs, st->sweepEnabled ? &st->sweep : nullptr);
 	if (r) { fprintf(stderr, "vkfft_mi355x: kernel launch failed\n"); return (VkFFTResult)r; }
 	return VKFFT_SUCCESS;
 }

@@ -94,7 +94,8 @@ struct ExecStreams {
 	hipStream_t aux[3] = {nullptr, nullptr, nullptr};
 	hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
 };
-int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream, const ExecStreams* xs = nullptr);
+// sweep: the application's zig-zag state: every launch walks the buffer opposite to the previous one; nullptr = always front to back
+int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream, const ExecStreams* xs = nullptr, uint32_t* sweep = nullptr);
 
 // fast-kernel registry queries used by the planner
 bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads);

@@ -202,7 +202,7 @@ static void bind(const DirectionPlan& plan, const PassPlan& pp, const LaunchBuff
 	prm.rader = pp.raderOff != (size_t)-1 ? ar + pp.raderOff : nullptr;
 }
 
-int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream, const ExecStreams* xs) {
+int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream, const ExecStreams* xs, uint32_t* sweep) {
 	const int np = (int)plan.passes.size();
 	for (int i = 0; i < np; i++) {
 		if (i == plan.chunkFirst && plan.chunkBatch > 0) {
@@ -246,6 +246,7 @@ int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipS
 		const PassPlan& pp = plan.passes[i];
 		PassParams prm = pp.prm;
 		bind(plan, pp, bufs, prm);
+		if (sweep) { prm.reverseTiles = *sweep & 1u; *sweep ^= 1u; } // zig-zag: opposite to the previous launch of this application
 		int r = launch_with_hostloop(pp, prm, stream, 0);
 		if (r) return r;
 	}

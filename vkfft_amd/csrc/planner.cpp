@@ -1366,14 +1366,6 @@ int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
 		}
 	}
 	if (d.userTempBytes && out.tempBytes > d.userTempBytes) return 2016;
-	// zig-zag sweep: consecutive launches walk the buffer in opposite directions (front to back, back to front, ...), so that every
-	// launch starts on the data the previous one touched last, which is still in the 256 MiB Infinity Cache — across the passes of
-	// one plan and across a forward transform followed by the inverse on the same buffer (the usual pattern, and the benchmark
-	// protocol).  Forward plans start front to back; inverse plans continue where a forward plan of the same pass count ended.
-	if (!getenv("VKFFT_MI355X_NO_REVERSE")) {
-		const size_t np = out.passes.size();
-		for (size_t i = 0; i < np; i++) out.passes[i].prm.reverseTiles = (uint32_t)((i + ((d.inverse && (np & 1)) ? 1 : 0)) & 1);
-	}
 	return 0;
 }
 
