@@ -264,6 +264,16 @@ def test_dct_fp64(run, oracle, type, shape, b):
     parity.check_r2r(run, oracle, shape, b, True, type, False)
 
 
+@pytest.mark.parametrize("kind,shape,dp,type,dst", [("r2c", (11583,), False, 0, False), ("r2c", (18375,), False, 0, False), ("r2r", (32768,), False, 2, False),
+                                                    ("r2r", (16385,), False, 1, False), ("r2r", (32768,), False, 4, False), ("r2r", (40000,), False, 3, False)])
+def test_real_transforms_longer_than_one_pass(run, oracle, kind, shape, dp, type, dst):
+    """Odd R2C rows and DCT/DST whose embedding length exceeds one pass (natural-index pre/post maps around a Four-Step FFT)."""
+    if kind == "r2c":
+        parity.check_r2c(run, oracle, shape, 2, dp)
+    else:
+        parity.check_r2r(run, oracle, shape, 2, dp, type, dst)
+
+
 @pytest.mark.parametrize("shape,dp", [((5606,), False), ((916,), True), ((1217,), False), ((139, 12), False), ((2 * 2803, 6), False)])
 def test_r2c_whose_half_length_needs_bluestein(run, oracle, shape, dp):
     """Real rows whose (half) length has a prime factor outside the radix / Rader stages (5606 = 2 * 2803): the full-length
