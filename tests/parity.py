@@ -85,6 +85,8 @@ def opfft_transform_of(fam, L, col):
     """(shape, kwargs of Runner.transform, real data?) of the smallest transform whose plan uses this table entry."""
     if fam in ("c2c4", "c2cT"):  # Four-Step passes of a 1D transform: L * L (two passes) exercises the first-pass kernel,
         return ((L * L * (L if fam == "c2c4" else 1),), {}, False)  # L^3 (three passes) the middle one
+    if fam in ("r2cf", "c2rf"):
+        return (L,), dict(r2c=True), True
     n = {"r2c": 2 * L, "c2r": 2 * L, "dct2": L, "dct3": L, "dct2h": 2 * L, "dct3h": 2 * L, "dct4": 2 * L, "dct1": L // 2 + 1, "dst1": L // 2 - 1, "c2c": L}[fam]
     kw = {"r2c": dict(r2c=True), "c2r": dict(r2c=True), "dct2": dict(dct=2), "dct3": dict(dct=3), "dct2h": dict(dct=2), "dct3h": dict(dct=3), "dct4": dict(dct=4), "dct1": dict(dct=1),
           "dst1": dict(dst=1), "c2c": {}}[fam]
@@ -101,7 +103,7 @@ def check_opfft_case(runner, oracle, fam, L, col, dp, load_elems=0, max_points=1
         if int(np.prod(shape)) > max_points:
             return  # (covered by the smaller factor lengths; a 2^23+ point host reference per table entry is too slow)
         check_c2c(runner, oracle, shape, 1 if fam != "c2c" else batch, dp, use_c_oracle=False)
-    elif fam in ("r2c", "c2r"):
+    elif fam in ("r2c", "c2r", "r2cf", "c2rf"):
         check_r2c(runner, oracle, shape, batch, dp)
     else:
         check_r2r(runner, oracle, shape, batch, dp, int(fam[3]), fam.startswith("dst"))
@@ -112,7 +114,7 @@ def check_opfft_case(runner, oracle, fam, L, col, dp, load_elems=0, max_points=1
             return
         if fam == "c2c":
             x = seeded_complex(n * batch, dp, L)
-        elif fam in ("r2c", "c2r"):
+        elif fam in ("r2c", "c2r", "r2cf", "c2rf"):
             W = shape[0]
             x = np.zeros((batch * n // W, 2 * (W // 2 + 1)), dtype=np.float64 if dp else np.float32)
             x[:, :W] = rng.uniform(-1, 1, (batch * n // W, W))

@@ -24,12 +24,16 @@ FAMILIES = {
     "dct4": ("OP_DCT4_PRE", "OP_DCT4_POST", True, True, True, False),
     "dct1": ("OP_DCT1_PRE", "OP_DCT1_POST", True, True, True, True),
     "dst1": ("OP_DST1_PRE", "OP_DST1_POST", True, True, True, True),
+    "r2cf": ("OP_R2C_FULL", "OP_R2C_FULL", False, True, False, False),    # odd real rows: full-length "callback" form
+    "c2rf": ("OP_C2R_FULL", "OP_C2R_FULL", False, True, False, False),
     "c2c": ("OP_NONE", "OP_NONE", False, False, True, False),
     "c2c4": ("OP_NONE", "OP_TWIDDLE_4STEP", False, False, True, False),   # middle Four-Step pass: column FFT + twiddle, in place
     "c2cT": ("OP_NONE", "OP_TWIDDLE_4STEP", False, False, True, False),   # first Four-Step pass: column FFT + twiddle + transposed store
 }
 # factor lengths of multi-pass plans of prime-power sizes (3^k, 5^k, 7^k, 11^k, 13^k: BASELINE config 3)
 FOURSTEP_EXTRA = [9, 27, 81, 25, 49, 11, 121, 1331, 13, 169, 2197]
+# odd real-row lengths (R2C / C2R of odd N run a complex FFT of the full length N)
+ODD_EXTRA = [15, 25, 27, 45, 75, 81, 105, 135, 225, 315, 375, 405, 675, 945, 1125, 1215, 2025, 3375]
 
 
 def pitch(n, fpw, col):
@@ -107,8 +111,10 @@ def main():
             for fam, (pre, post, real, row_ok, col_ok, pow2only) in FAMILIES.items():
                 if (col and not col_ok) or (not col and not row_ok): continue
                 fourstep = fam in ("c2c", "c2c4", "c2cT")
-                for n in sorted(set(lens) | (set(FOURSTEP_EXTRA) if fourstep and not dp else set())):
+                oddreal = fam in ("r2cf", "c2rf")
+                for n in sorted(set(lens) | (set(FOURSTEP_EXTRA) if fourstep and not dp else set()) | (set(ODD_EXTRA) if oddreal else set())):
                     ispow2 = n & (n - 1) == 0
+                    if oddreal and n % 2 == 0: continue
                     if pow2only and not ispow2: continue
                     if dp and n > 4096: continue
                     if fourstep and ispow2 and n <= 1024: continue  # pow2_col_kernel covers these
