@@ -81,8 +81,17 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 			fibers[i] = {(void*)sp, READY, stackPool[i]};
 		}
 		unsigned live = nthr;
+		// Thread order between barriers (VKFFT_HOSTEMU_ORDER): 0 ascending (default), 1 descending, 2 pseudo-random (changes every
+		// round).  A missing barrier shows up as a wrong result only when a thread reads what a LATER-scheduled thread writes, so
+		// the suite is also run with the other orders (tests/test_emu_fuzz.py) to expose hazards ascending order would mask.
+		static const int order = getenv("VKFFT_HOSTEMU_ORDER") ? atoi(getenv("VKFFT_HOSTEMU_ORDER")) : 0;
+		uint32_t rng = 0x9E3779B9u ^ (bx * 2654435761u);
+		std::vector<unsigned> perm(nthr);
 		while (live) {
-			for (unsigned i = 0; i < nthr; i++) {
+			for (unsigned i = 0; i < nthr; i++) perm[i] = order == 1 ? nthr - 1 - i : i;
+			if (order == 2) for (unsigned i = nthr; i > 1; i--) { rng = rng * 1664525u + 1013904223u; std::swap(perm[i - 1], perm[(rng >> 8) % i]); }
+			for (unsigned ii = 0; ii < nthr; ii++) {
+				const unsigned i = perm[ii];
 				if (fibers[i].st != READY) continue;
 				cur = (int)i;
 				set_tid(i);
