@@ -30,8 +30,6 @@ static cld unit_root(uint64_t num, uint64_t den) {
 	ld ang = 2 * PI_LD * x;
 	return cld(cosl(ang), -sinl(ang));
 }
-// exp(-i*pi*num/den)
-static cld unit_root_pi(uint64_t num, uint64_t den) { return unit_root(num, 2 * den); }
 
 struct Arena {
 	std::vector<unsigned char>& b;
@@ -492,11 +490,41 @@ static void host_fft_rec(std::vector<cld>& a, const std::vector<cld>& roots) {
 		a[k] = acc;
 	}
 }
+// exp(-2 pi i k / M) for k = 0..count-1 from a two-level table: 2*sqrt(M) sincosl calls and one complex multiply per entry
+// (|error| ~ 1e-19: below the long double rounding of the direct evaluation's argument reduction for large M)
+static void fill_roots(std::vector<cld>& roots, uint64_t M) {
+	uint32_t sh = 0; while ((1ull << (2 * sh)) < M) sh++;
+	const uint64_t nlo = 1ull << sh, nhi = (M + nlo - 1) >> sh;
+	std::vector<cld> lo(nlo), hi(nhi);
+	for (uint64_t i = 0; i < nlo; i++) lo[i] = unit_root(i, M);
+	for (uint64_t i = 0; i < nhi; i++) hi[i] = unit_root(i << sh, M);
+	roots.resize(M);
+	for (uint64_t k = 0; k < M; k++) roots[k] = (k & (nlo - 1)) ? hi[k >> sh] * lo[k & (nlo - 1)] : hi[k >> sh];
+}
+// power-of-two lengths (every padded Bluestein length of the fast paths): iterative radix-2, no allocation per level
+static void host_fft_pow2(std::vector<cld>& a, const std::vector<cld>& roots) {
+	const size_t n = a.size();
+	for (size_t i = 1, j = 0; i < n; i++) {
+		size_t bit = n >> 1;
+		for (; j & bit; bit >>= 1) j ^= bit;
+		j ^= bit;
+		if (i < j) std::swap(a[i], a[j]);
+	}
+	for (size_t len = 2; len <= n; len <<= 1) {
+		const size_t half = len >> 1, step = n / len;
+		for (size_t i = 0; i < n; i += len)
+			for (size_t j = 0; j < half; j++) {
+				const cld u = a[i + j], v = a[i + j + half] * roots[j * step];
+				a[i + j] = u + v; a[i + j + half] = u - v;
+			}
+	}
+}
 static void host_fft(std::vector<cld>& a) {
 	const size_t M = a.size();
-	std::vector<cld> roots(M);
-	for (size_t k = 0; k < M; k++) roots[k] = unit_root(k, M);
-	host_fft_rec(a, roots);
+	std::vector<cld> roots;
+	fill_roots(roots, M);
+	if ((M & (M - 1)) == 0) host_fft_pow2(a, roots);
+	else host_fft_rec(a, roots);
 }
 
 static uint64_t next_smooth(uint64_t n, int maxPrime) {
@@ -680,10 +708,12 @@ static void make_bluestein_tables(uint64_t N, uint64_t M, bool dp, Arena& ar, si
 	if (cN != N || cM != M) {
 		cChirp.assign(N, cld(0, 0));
 		std::vector<cld> bext(M, cld(0, 0));
+		std::vector<cld> r2n; // exp(-2 pi i e / 2N), e < 2N
+		fill_roots(r2n, 2 * N);
 		for (uint64_t n = 0; n < N; n++) {
 			unsigned __int128 sq = (unsigned __int128)n * n;
 			uint64_t e = (uint64_t)(sq % (2 * N));
-			cld c = std::conj(unit_root_pi(e, N));
+			cld c = std::conj(r2n[e]);
 			cChirp[n] = c;
 			bext[n] = c;
 			if (n) bext[M - n] = c;
