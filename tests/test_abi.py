@@ -79,3 +79,17 @@ def test_cli_driver_builds_and_prints_usage(product_lib):
     subprocess.check_call(["make", "-s", "-C", root, "build/vkfft_mi355x_cli"])
     out = subprocess.run([os.path.join(root, "build", "vkfft_mi355x_cli"), "-h"], capture_output=True, text=True)
     assert out.returncode == 0 and "-benchmark_vkfft" in out.stdout and "-vkfft <id>" in out.stdout
+
+
+def test_public_header_compiles_as_c99():
+    """include/vkFFT.h is a C header like the reference's (callers may be plain C): compile a caller-side translation unit with
+    gcc -std=c99 against it (HIP runtime API header from /opt/rocm)."""
+    import subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ('#include "vkFFT.h"\n'
+           'int main(void) { VkFFTConfiguration c = VKFFT_ZERO_INIT; VkFFTApplication a = VKFFT_ZERO_INIT; VkFFTLaunchParams l = VKFFT_ZERO_INIT;\n'
+           '  (void)c; (void)a; (void)l; return VkFFTGetVersion() == 10304 ? 0 : 1; }\n')
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "caller.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"), "-I/opt/rocm/include",
+                               "-c", os.path.join(d, "caller.c"), "-o", os.path.join(d, "caller.o")])
