@@ -592,7 +592,7 @@ template <typename T> __global__ void __launch_bounds__(256) r2c_even_pair_kerne
 	const uint32_t H = p.opN >> 1;
 	const uint32_t npair = H / 2 + 1;
 	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-	uint32_t row = blockIdx.y;
+	uint32_t row = p.reverseTiles ? gridDim.y - 1u - blockIdx.y : blockIdx.y; // zig-zag sweep
 	if (k >= npair) return;
 	const uint32_t g0 = row % p.dim[0].count; row /= p.dim[0].count;
 	const uint32_t g1 = row % p.dim[1].count, g2 = row / p.dim[1].count;
