@@ -245,3 +245,19 @@ def test_index_permutations_are_bit_exact(run):
         k = np.arange(N)
         ref = np.exp(-2j * np.pi * ((p * k) % N) / N)
         assert np.abs(y - ref).max() < 2e-6  # every output bin at its natural-order position
+
+
+@pytest.mark.parametrize("N,batch,chunk_kib,lag,ring,queues", [(1 << 15, 7, 256, 2, 3, 1), (1 << 15, 7, 512, 1, 2, 1), (1 << 16, 5, 512, 2, 4, 1), (1 << 15, 9, 512, 3, 4, 1),
+                                                               (1 << 17, 3, 1024, 1, 2, 1), (1 << 15, 37, 256, 2, 3, 8), (1 << 15, 21, 512, 1, 2, 4), (1 << 16, 19, 512, 3, 5, 8)])
+def test_fused_fourstep_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag, ring, queues):
+    """fused Four-Step (kernel_pow2_fused.h): ticket decode, per-XCD queues and queue helping, chunk ring reuse, partial last chunk and
+    the reversed sweep of the inverse (the emulator drains the queues with one workgroup, in ticket order)"""
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_CHUNK_KIB", str(chunk_kib))
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_LAG", str(lag))
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_RING", str(ring))
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_QUEUES", str(queues))
+    x = parity.seeded_complex(N * batch, False, N + batch)
+    y, z, up = run.transform(x, (N,), batch, both=True)
+    assert up == [2]
+    assert rel_l2(y, oracle.truth_c2c(x, (N,), batch)) < 1e-6
+    assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6

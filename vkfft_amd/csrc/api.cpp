@@ -22,7 +22,6 @@ struct AppState {
 	uint64_t tempOwnedBytes = 0;
 	hipEvent_t* events = nullptr;
 	uint32_t numEvents = 0;
-	ExecStreams xs;                // helper streams for chunk-pipelined multi-pass plans
 	uint32_t sweep = 0;            // zig-zag state: direction of the next launch's tile sweep
 	bool sweepEnabled = true;
 };
@@ -87,8 +86,6 @@ VKFFT_API void deleteVkFFT(VkFFTApplication* app) {
 			for (uint32_t i = 0; i < st->numEvents; i++) if (st->events[i]) (void)hipEventDestroy(st->events[i]);
 			free(st->events);
 		}
-		for (int i = 0; i < st->xs.nAux; i++) { if (st->xs.aux[i]) (void)hipStreamDestroy(st->xs.aux[i]); if (st->xs.join[i]) (void)hipEventDestroy(st->xs.join[i]); }
-		if (st->xs.fork) (void)hipEventDestroy(st->xs.fork);
 		delete st;
 	}
 	free_direction(app->localFFTPlan);
@@ -205,8 +202,15 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 	d.fixMaxRadixBluestein = (int)c.fixMaxRadixBluestein;
 	if (c.fixMaxRaderPrimeMult) d.raderMultMax = c.fixMaxRaderPrimeMult;
 	if (c.userTempBuffer && c.tempBufferSize) d.userTempBytes = c.tempBufferSize[0];
-	if (const char* e = getenv("VKFFT_MI355X_CHUNK_MIB")) d.chunkTargetBytes = (uint64_t)atoll(e) << 20;
-	if (const char* e = getenv("VKFFT_MI355X_CHUNK_STREAMS")) d.chunkStreams = (uint32_t)atoi(e);
+	// fused Four-Step tuning knobs (experiments only; defaults are the planner's)
+	if (const char* e = getenv("VKFFT_MI355X_FUSED")) d.fused = atoi(e) != 0;
+	if (const char* e = getenv("VKFFT_MI355X_FUSED_MODE")) d.fusedMode = atoi(e);
+	if (const char* e = getenv("VKFFT_MI355X_FUSED_CHUNK_KIB")) d.fusedChunkBytes = (uint64_t)atoll(e) << 10;
+	if (const char* e = getenv("VKFFT_MI355X_FUSED_LAG")) d.fusedLag = (uint32_t)atoi(e);
+	if (const char* e = getenv("VKFFT_MI355X_FUSED_RING")) d.fusedRing = (uint32_t)atoi(e);
+	if (const char* e = getenv("VKFFT_MI355X_FUSED_WGS")) d.fusedWgPerCu = (uint32_t)atoi(e);
+	if (const char* e = getenv("VKFFT_MI355X_FUSED_QUEUES")) d.fusedQueues = (uint32_t)atoi(e);
+	if (const char* e = getenv("VKFFT_MI355X_FUSED_MARGIN")) d.fusedMarginPct = (uint32_t)atoi(e);
 	if (const char* e = getenv("VKFFT_MI355X_GENERIC_ONLY")) d.disableFastKernels = atoi(e) != 0;
 
 	AppState* st = new (std::nothrow) AppState();
@@ -224,15 +228,20 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 		if (res != VKFFT_SUCCESS) { deleteVkFFT(app); return res; }
 	}
 	if (c.printMemoryLayout || getenv("VKFFT_MI355X_PRINT_PLAN")) { // one line per launch: which kernel family serves it
-		static const char* kname[] = {"generic", "pow2_row", "pow2_col", "r2c_pair", "?", "mixed_row", "opfft", "pow2_blue", "pow2_col_blue", "pow2_blue_r2r"};
+		static const char* kname[] = {"generic", "pow2_row", "pow2_col", "r2c_pair", "?", "mixed_row", "opfft", "pow2_blue", "pow2_col_blue", "pow2_blue_r2r", "pow2_fused"};
 		for (int dir = 0; dir < 2; dir++) {
 			VkFFTPlan* pl = dir ? app->localFFTPlan_inverse : app->localFFTPlan;
 			if (!pl) continue;
 			const DirectionPlan* dpn = (const DirectionPlan*)pl->impl;
 			for (size_t i = 0; i < dpn->passes.size(); i++) {
 				const PassPlan& q = dpn->passes[i];
+				if (q.kernel == KERNEL_POW2_FUSED) {
+					fprintf(stderr, "[vkfft_mi355x] %s pass %zu: %-10s kernel=pow2_fused variant=%d N=%ux%u threads=%u chunk=%u transforms x %u chunks, %u queues, lag %u, ring %u (%.1f MiB)\n", dir ? "inverse" : "forward", i,
+					        q.label.c_str(), q.variant, q.fused.n0, q.fused.n1, q.threads, 1u << q.fused.logG, q.fused.C, q.fused.Q, q.fused.D, q.fused.NS, (double)dpn->tempBytes / 1048576.0);
+					continue;
+				}
 				fprintf(stderr, "[vkfft_mi355x] %s pass %zu: %-10s kernel=%s variant=%d L=%u threads=%u tile=%u grid=%llu\n", dir ? "inverse" : "forward", i, q.label.c_str(),
-				        kname[q.kernel < 10 ? q.kernel : 4], q.variant, q.prm.L, q.threads, q.prm.T,
+				        kname[q.kernel < 11 ? q.kernel : 4], q.variant, q.prm.L, q.threads, q.prm.T,
 				        (unsigned long long)q.prm.tilesPerG0 * q.prm.dim[1].count * q.prm.dim[2].count);
 			}
 		}
@@ -245,20 +254,6 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 		if (hipMalloc(&st->tempOwned, need) != hipSuccess) { deleteVkFFT(app); return VKFFT_ERROR_FAILED_TO_ALLOCATE; }
 		st->tempOwnedBytes = need;
 		c.allocateTempBuffer = 1;
-	}
-	// ---- helper streams of chunk-pipelined plans ---------------------------------------------------------------
-	{
-		uint32_t want = 1;
-		if (app->localFFTPlan) want = std::max(want, ((DirectionPlan*)app->localFFTPlan->impl)->chunkBatch ? ((DirectionPlan*)app->localFFTPlan->impl)->chunkStreams : 1u);
-		if (app->localFFTPlan_inverse) want = std::max(want, ((DirectionPlan*)app->localFFTPlan_inverse->impl)->chunkBatch ? ((DirectionPlan*)app->localFFTPlan_inverse->impl)->chunkStreams : 1u);
-		if (want > 1) {
-			if (hipEventCreateWithFlags(&st->xs.fork, hipEventDisableTiming) != hipSuccess) { deleteVkFFT(app); return VKFFT_ERROR_FAILED_TO_CREATE_EVENT; }
-			for (uint32_t i = 0; i + 1 < want && i < 3; i++) {
-				if (hipStreamCreateWithFlags(&st->xs.aux[i], hipStreamNonBlocking) != hipSuccess) { deleteVkFFT(app); return VKFFT_ERROR_FAILED_TO_CREATE_COMMAND_QUEUE; }
-				st->xs.nAux = (int)i + 1;
-				if (hipEventCreateWithFlags(&st->xs.join[i], hipEventDisableTiming) != hipSuccess) { deleteVkFFT(app); return VKFFT_ERROR_FAILED_TO_CREATE_EVENT; }
-			}
-		}
 	}
 	// ---- multi-stream events ------------------------------------------------------------------------------
 	if (c.num_streams > 1 && c.stream) {
@@ -312,7 +307,7 @@ VKFFT_API VkFFTResult VkFFTAppend(VkFFTApplication* app, int inverse, VkFFTLaunc
 	}
 	hipStream_t stream = 0;
 	if (c.stream && c.num_streams >= 1) stream = c.stream[0];
-	int r = execute_direction(*dp, lb, stream, &st->xs, st->sweepEnabled ? &st->sweep : nullptr);
+	int r = execute_direction(*dp, lb, stream, st->sweepEnabled ? &st->sweep : nullptr);
 	if (r) { fprintf(stderr, "vkfft_mi355x: kernel launch failed\n"); return (VkFFTResult)r; }
 	return VKFFT_SUCCESS;
 }

@@ -160,4 +160,23 @@ struct PassParams {
 	uint32_t inElemBytes, outElemBytes; // bytes per global element on each side (real scalar or complex)
 };
 
+// ---- fused Four-Step launch (kernel_pow2_fused.h): both passes of a two-factor transform in one persistent kernel ----
+constexpr uint32_t kFusedCtrTicket = 0, kFusedCtrExit = 256, kFusedCtrDone = 320; // uint32 indices into FusedParams::ctr (ticket counter of queue q at 32*q)
+constexpr uint32_t kFusedMaxQueues = 8;
+
+struct FusedParams {
+	const void* in; void* out; void* scratch; uint32_t* ctr;
+	const void* lutA; const void* lutB; const void* tw4; // stage twiddles of the two factors, two-level Four-Step table
+	int64_t inBatchStride, outBatchStride; // complex elements between consecutive transforms
+	uint32_t fsLoBits;
+	uint32_t n0, n1, batch;
+	uint32_t logG;        // transforms per chunk = 2^logG
+	uint32_t logTiles;    // tiles per transform and phase = 2^logTiles
+	uint32_t C, NS, D;    // chunks; ring slots per queue; lag (in slots) between a chunk's A and B tiles; NS > D >= 1
+	uint32_t Q;           // work queues (1, or one per XCD): chunk c belongs to queue c % Q
+	uint32_t swapIn, swapOut, reverse;
+	double scale;
+	unsigned long long* prof; // development only (VKFFT_MI355X_FUSED_PROFILE): per-workgroup cycle sums of the tile phases, else nullptr
+};
+
 } // namespace vkfft_mi355x

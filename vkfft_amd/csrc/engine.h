@@ -11,7 +11,7 @@
 namespace vkfft_mi355x {
 
 enum BufRole : int { ROLE_BUFFER = 0, ROLE_TEMP = 1, ROLE_INPUT = 2, ROLE_OUTPUT = 3 };
-enum KernelKind : int { KERNEL_GENERIC = 0, KERNEL_POW2_ROW = 1, KERNEL_POW2_COL = 2, KERNEL_R2C_PAIR = 3, KERNEL_MIXED_ROW = 5, KERNEL_OPFFT = 6, KERNEL_POW2_BLUE = 7, KERNEL_POW2_COL_BLUE = 8, KERNEL_POW2_BLUE_R2R = 9 };
+enum KernelKind : int { KERNEL_GENERIC = 0, KERNEL_POW2_ROW = 1, KERNEL_POW2_COL = 2, KERNEL_R2C_PAIR = 3, KERNEL_MIXED_ROW = 5, KERNEL_OPFFT = 6, KERNEL_POW2_BLUE = 7, KERNEL_POW2_COL_BLUE = 8, KERNEL_POW2_BLUE_R2R = 9, KERNEL_POW2_FUSED = 10 };
 
 struct HostDim {
 	uint64_t count;
@@ -32,8 +32,10 @@ struct PassPlan {
 	std::vector<HostDim> hostLoop; // outer dims iterated on the host (rare: >3 non-collapsible batch dims)
 	// arena offsets (bytes) of the tables, SIZE_MAX = none
 	size_t lutOff = (size_t)-1, auxOff = (size_t)-1, aux2Off = (size_t)-1, aux3Off = (size_t)-1, raderOff = (size_t)-1;
-	// chunking: this pass's dim index whose range the executor may split ( -1: none )
-	int chunkDim = -1;
+	// fused Four-Step launch (KERNEL_POW2_FUSED): parameter block (pointers bound at launch) and its extra arena offsets
+	FusedParams fused = {};
+	size_t fusedLutBOff = (size_t)-1, fusedCtrOff = (size_t)-1;
+	int fusedWgPerCu = 0; // 0: what the occupancy query reports
 	std::string label;
 };
 
@@ -42,12 +44,6 @@ struct DirectionPlan {
 	std::vector<unsigned char> arena;  // host image of every LUT of this direction
 	void* dArena = nullptr;            // device copy
 	uint64_t tempBytes = 0;            // scratch this direction needs (0: none)
-	// chunked execution of passes [chunkFirst, chunkLast] over the outermost batch dim, so that the
-	// intermediate stays resident in the 256 MiB Infinity Cache between passes
-	int chunkFirst = -1, chunkLast = -1;
-	uint64_t chunkBatch = 0, totalBatch = 0;
-	uint64_t chunkTempStrideBytes = 0; // scratch slice per concurrently running chunk
-	uint32_t chunkStreams = 1;         // chunks in flight (stream-level pipelining)
 	uint32_t uploadsPerAxis[4] = {0, 0, 0, 0};
 	uint32_t bigSequenceEvenR2C = 0;
 	uint64_t axisSplit[4][4] = {};
@@ -75,9 +71,12 @@ struct TransformDesc {
 	int fixMaxRadixBluestein = 0;
 	uint64_t raderMultMin = 17, raderMultMax = 128;
 	uint64_t userTempBytes = 0;  // >0: temp supplied by the caller with this size
-	uint64_t chunkTargetBytes = 0; // working-set target of the Infinity-Cache chunking (0 = off: measured slower on MI355X)
 	bool disableFastKernels = false;
-	uint32_t chunkStreams = 2;
+	// fused Four-Step (kernel_pow2_fused.h); the numeric fields are tuning knobs, 0 = planner default
+	bool fused = true;
+	int fusedMode = 0;
+	uint64_t fusedChunkBytes = 0;
+	uint32_t fusedLag = 0, fusedRing = 0, fusedWgPerCu = 0, fusedQueues = 0, fusedMarginPct = 0;
 };
 
 // returns 0 or a VkFFTResult code
@@ -88,14 +87,8 @@ struct LaunchBuffers {
 	void* base[4] = {nullptr, nullptr, nullptr, nullptr}; // by BufRole
 };
 int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
-// optional helper streams for chunk-pipelined execution (created by the API layer, owned by the application)
-struct ExecStreams {
-	int nAux = 0;
-	hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-	hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
-};
 // sweep: the application's zig-zag state: every launch walks the buffer opposite to the previous one; nullptr = always front to back
-int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream, const ExecStreams* xs = nullptr, uint32_t* sweep = nullptr);
+int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream, uint32_t* sweep = nullptr);
 
 // fast-kernel registry queries used by the planner
 bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads);
@@ -104,6 +97,9 @@ bool pow2_col_blue_lookup(uint32_t log2l, bool dp, int mode, int* variant, int b
 bool pow2_blue_r2r_lookup(uint32_t log2m, bool dp, uint32_t pre, int* variant, int bits[4], int* fpw, int* threads); // Bluestein-wrapped DCT/DST/R2C
 int launch_pow2_blue_r2r(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 bool pow2_blue_lookup(uint32_t log2m, bool dp, int* variant, int bits[4], int* fpw, int* threads); // fused Bluestein on padded length 2^log2m
+// fused Four-Step of 2^log2n = 2^la * 2^lb (kernels_fused.hip)
+bool pow2_fused_lookup(uint32_t log2n, bool dp, int mode, int* variant, int* la, int* lb, int bitsA[4], int bitsB[4], int* tca, int* tcb, int* threads, int* wgPerCu);
+int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t stream);
 bool mixed_row_lookup(uint64_t n, bool dp, int* variant, int rad[5], int* fpw, int* threads);
 int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 // op-FFT family (kernel_opfft.h): pre/post are the DCT member of their family (DST variants share the instance)

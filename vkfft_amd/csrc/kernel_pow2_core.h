@@ -41,6 +41,7 @@ template <int B0, int B1, int B2, int B3> struct Pow2Sched {
 		for (int j = 1; j < si; j++) off += ((1 << bits[j]) - 1) << logS(j);
 		return off;
 	}
+	__host__ __device__ static constexpr int lutTotal() { return lutOff(NS); } // complex elements of all stage twiddle runs
 };
 
 // LDS slot of FFT element a: row kernels pad the index (a + a>>LOGE) inside the FFT's own slab; column
@@ -50,9 +51,9 @@ template <int TCP, int LOGE> __device__ inline uint32_t pow2_slot(uint32_t a) {
 	else return a * TCP;
 }
 
-// stage-twiddle source: global LUT through a buffer resource (row kernels) or a copy of the LUT in LDS (persistent
-// column kernel: keeps the vector-memory queue free for the next tile's prefetch — vmcnt retires in issue order,
-// so any later VMEM load that is consumed would drag the prefetched tile's latency into the critical path)
+// stage-twiddle source: global LUT through a buffer resource (one-tile kernels) or a copy of the LUT staged in LDS once per
+// workgroup (persistent fused Four-Step kernel: short-latency reads need no deep prefetch, which is what drives the
+// register count of the radix-32 stages, and the vector-memory queue stays free for the tile's own loads)
 template <typename T> struct TwGlobal {
 	GBuf lut;
 	__device__ inline cx<T> get(uint32_t s, uint32_t constOff) const { return gb_load<T>(lut, s * (uint32_t)sizeof(cx<T>), constOff * (uint32_t)sizeof(cx<T>)); }

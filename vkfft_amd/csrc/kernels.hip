@@ -202,48 +202,23 @@ static void bind(const DirectionPlan& plan, const PassPlan& pp, const LaunchBuff
 	prm.rader = pp.raderOff != (size_t)-1 ? ar + pp.raderOff : nullptr;
 }
 
-int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream, const ExecStreams* xs, uint32_t* sweep) {
+int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream, uint32_t* sweep) {
 	const int np = (int)plan.passes.size();
 	for (int i = 0; i < np; i++) {
-		if (i == plan.chunkFirst && plan.chunkBatch > 0) {
-			// Passes [chunkFirst, chunkLast] run chunk by chunk over the batch so that the scratch written by one pass
-			// is still resident in the 256 MiB Infinity Cache when the next pass reads it.  Chunks are independent
-			// (own batch range, own scratch slice) and alternate between the caller's stream and helper streams, so
-			// that the tail of one chunk's kernels overlaps the head of the next chunk's.
-			const int nStreams = (xs && xs->nAux > 0) ? std::min<int>((int)plan.chunkStreams, xs->nAux + 1) : 1;
-			if (nStreams > 1) {
-				if (hipEventRecord(xs->fork, stream) != hipSuccess) return 4040;
-				for (int s = 1; s < nStreams; s++) if (hipStreamWaitEvent(xs->aux[s - 1], xs->fork, 0) != hipSuccess) return 4040;
-			}
-			uint64_t ci = 0;
-			for (uint64_t b0 = 0; b0 < plan.totalBatch; b0 += plan.chunkBatch, ci++) {
-				const uint64_t nb = std::min<uint64_t>(plan.chunkBatch, plan.totalBatch - b0);
-				const int sidx = (int)(ci % (uint64_t)nStreams);
-				hipStream_t st = sidx == 0 ? stream : xs->aux[sidx - 1];
-				for (int k = plan.chunkFirst; k <= plan.chunkLast; k++) {
-					const PassPlan& pp = plan.passes[k];
-					PassParams prm = pp.prm;
-					bind(plan, pp, bufs, prm);
-					BatchDim& bd = prm.dim[pp.chunkDim];
-					if (pp.inRole != ROLE_TEMP) prm.in = (const char*)prm.in + (int64_t)b0 * bd.inStride * pp.inElemBytes;
-					else prm.in = (const char*)prm.in + (int64_t)sidx * plan.chunkTempStrideBytes;
-					if (pp.outRole != ROLE_TEMP) prm.out = (char*)prm.out + (int64_t)b0 * bd.outStride * pp.outElemBytes;
-					else prm.out = (char*)prm.out + (int64_t)sidx * plan.chunkTempStrideBytes;
-					bd.count = (uint32_t)nb;
-					int r = launch_with_hostloop(pp, prm, st, 0);
-					if (r) return r;
-				}
-			}
-			if (nStreams > 1) {
-				for (int s = 1; s < nStreams; s++) {
-					if (hipEventRecord(xs->join[s - 1], xs->aux[s - 1]) != hipSuccess) return 4040;
-					if (hipStreamWaitEvent(stream, xs->join[s - 1], 0) != hipSuccess) return 4040;
-				}
-			}
-			i = plan.chunkLast;
+		const PassPlan& pp = plan.passes[i];
+		if (pp.kernel == KERNEL_POW2_FUSED) {
+			FusedParams f = pp.fused;
+			const char* ar = (const char*)plan.dArena;
+			f.in = (const char*)bufs.base[pp.inRole] + pp.inOffset * pp.inElemBytes;
+			f.out = (char*)bufs.base[pp.outRole] + pp.outOffset * pp.outElemBytes;
+			f.scratch = bufs.base[ROLE_TEMP];
+			f.lutA = ar + pp.lutOff; f.lutB = ar + pp.fusedLutBOff; f.tw4 = ar + pp.auxOff;
+			f.ctr = (uint32_t*)((char*)plan.dArena + pp.fusedCtrOff);
+			if (sweep) { f.reverse = *sweep & 1u; *sweep ^= 1u; }
+			int r = launch_pow2_fused(pp, f, stream);
+			if (r) return r;
 			continue;
 		}
-		const PassPlan& pp = plan.passes[i];
 		PassParams prm = pp.prm;
 		bind(plan, pp, bufs, prm);
 		if (sweep) { prm.reverseTiles = *sweep & 1u; *sweep ^= 1u; } // zig-zag: opposite to the previous launch of this application

@@ -1,0 +1,98 @@
+// Instantiations and registry of the fused Four-Step kernels (kernel_pow2_fused.h): own translation unit (build time).
+#include "engine.h"
+#include "kernel_pow2_fused.h"
+#include <cstdlib>
+#include <cstdio>
+#include <vector>
+
+namespace vkfft_mi355x {
+
+#define VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, mode) \
+	{ (a0) + (a1) + (a2) + (b0) + (b1) + (b2), dp, mode, (a0) + (a1) + (a2), (b0) + (b1) + (b2), {a0, a1, a2, 0}, {b0, b1, b2, 0}, tca, tcb, \
+	  ((1 << ((a0) + (a1) + (a2))) >> Pow2Sched<a0, a1, a2, 0>::LOGE) * (tca), pow2_fused_wg_per_cu<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb>(), \
+	  &pow2_fused_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode>, \
+	  (const void*)&pow2_fused_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode> }
+#define VKFFT_FU(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) \
+	VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 0), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 7)
+
+// first entry of each (log2 N, dp, mode) is the default; VKFFT_MI355X_FUV<log2n>=k selects the k-th shape (tuning)
+static const Pow2FusedVariant kPow2FusedVariants[] = {
+	// 2^15 = 128 x 256
+	VKFFT_FU(float, false, 4, 3, 0, 32, 4, 4, 0, 16),
+	// 2^16 = 256 x 256
+	VKFFT_FU(float, false, 4, 4, 0, 32, 4, 4, 0, 32),
+	VKFFT_FU(float, false, 4, 4, 0, 16, 4, 4, 0, 16),
+	// 2^17 = 256 x 512
+	VKFFT_FU(float, false, 5, 3, 0, 32, 5, 4, 0, 16),
+	VKFFT_FU(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
+	// 2^18 = 512 x 512
+	VKFFT_FU(float, false, 5, 4, 0, 16, 5, 4, 0, 16),
+	VKFFT_FU(float, false, 5, 4, 0, 32, 5, 4, 0, 32),
+	// 2^19 = 512 x 1024
+	VKFFT_FU(float, false, 5, 4, 0, 32, 5, 5, 0, 16),
+	// 2^20 = 1024 x 1024
+	VKFFT_FU(float, false, 5, 5, 0, 16, 5, 5, 0, 16),
+};
+constexpr int kNumPow2FusedVariants = (int)(sizeof(kPow2FusedVariants) / sizeof(kPow2FusedVariants[0]));
+
+bool pow2_fused_lookup(uint32_t log2n, bool dp, int mode, int* variant, int* la, int* lb, int bitsA[4], int bitsB[4], int* tca, int* tcb, int* threads, int* wgPerCu) {
+	int want = 0;
+	char name[64];
+	snprintf(name, sizeof(name), "VKFFT_MI355X_FUV%u", log2n);
+	if (const char* e = getenv(name)) want = atoi(e);
+	int seen = 0, found = -1;
+	for (int i = 0; i < kNumPow2FusedVariants; i++) {
+		const Pow2FusedVariant& v = kPow2FusedVariants[i];
+		if (v.log2n != (int)log2n || v.dp != dp || v.mode != mode) continue;
+		if (found < 0) found = i;
+		if (seen == want) { found = i; break; }
+		seen++;
+	}
+	if (found < 0) return false;
+	const Pow2FusedVariant& v = kPow2FusedVariants[found];
+	*variant = found; *la = v.la; *lb = v.lb; *tca = v.tca; *tcb = v.tcb; *threads = v.threads; *wgPerCu = v.wgPerCu;
+	for (int k = 0; k < 4; k++) { bitsA[k] = v.bitsA[k]; bitsB[k] = v.bitsB[k]; }
+	return true;
+}
+
+int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t stream) {
+	if (pp.variant < 0 || pp.variant >= kNumPow2FusedVariants) return 4039;
+	const Pow2FusedVariant& v = kPow2FusedVariants[pp.variant];
+	// persistent grid: what the chip holds at once (the ticket queue needs no co-residency: any grid is correct)
+	static int occ[kNumPow2FusedVariants] = {};
+	if (!occ[pp.variant]) {
+		int n = 0;
+#if defined(VKFFT_HOSTEMU)
+		n = 1;
+#else
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, v.fn, v.threads, 0) != hipSuccess || n < 1) n = 1;
+#endif
+		occ[pp.variant] = n;
+	}
+	const uint64_t tickets = (uint64_t)(prm.C + prm.D * prm.Q) << (prm.logG + prm.logTiles);
+	uint64_t grid = (uint64_t)pow2_num_cus() * (pp.fusedWgPerCu > 0 ? (uint32_t)pp.fusedWgPerCu : (uint32_t)occ[pp.variant]);
+	if (grid > tickets) grid = tickets;
+	if (grid == 0) return 0;
+#if !defined(VKFFT_HOSTEMU)
+	if ((v.mode & 4) && getenv("VKFFT_MI355X_FUSED_PROFILE")) { // development: per-phase cycle sums (blocking)
+		static unsigned long long* dbuf = nullptr;
+		if (!dbuf) (void)hipMalloc(&dbuf, 8192 * 12 * sizeof(unsigned long long));
+		FusedParams q = prm; q.prof = dbuf;
+		if (grid > 8192) grid = 8192;
+		v.launch(q, dim3((uint32_t)grid), stream);
+		(void)hipStreamSynchronize(stream);
+		std::vector<unsigned long long> h(grid * 12);
+		(void)hipMemcpy(h.data(), dbuf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+		double sum[12] = {};
+		for (uint64_t w = 0; w < grid; w++) for (int i = 0; i < 12; i++) sum[i] += (double)h[w * 12 + i];
+		const double nt = sum[7] > 0 ? sum[7] : 1;
+		fprintf(stderr, "[fused profile] grid %llu tickets/wg %.1f | cycles per ticket: S1 %.0f  A-load %.0f  A-stages %.0f A-twiddle %.0f A-transpose %.0f A-stores %.0f  B-load %.0f  B-compute %.0f  waitA %.0f waitB %.0f | total %.0f\n",
+		        (unsigned long long)grid, nt / grid, sum[0] / nt, sum[1] / nt, sum[8] / nt, sum[9] / nt, sum[10] / nt, sum[2] / nt, sum[3] / nt, sum[4] / nt, sum[5] / nt, sum[6] / nt, (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6] + sum[8] + sum[9] + sum[10]) / nt);
+		return 0;
+	}
+#endif
+	v.launch(prm, dim3((uint32_t)grid), stream);
+	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
+
+} // namespace vkfft_mi355x

@@ -55,6 +55,11 @@ template <typename T> inline void gb_store_real4(GBuf b, uint32_t voff, uint32_t
 	T* q = (T*)(b.base + (uint64_t)voff + soff);
 	q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
 }
+// cache-policy variants (AUX = sc0 | nt<<1 | sc1<<4 of the buffer instructions): plain accesses on the emulator
+template <typename T, int AUX> inline cx<T> gb_load_x(GBuf b, uint32_t voff, uint32_t soff) { return gb_load<T>(b, voff, soff); }
+template <typename T, int AUX> inline void gb_store_x(GBuf b, uint32_t voff, uint32_t soff, cx<T> v) { gb_store<T>(b, voff, soff, v); }
+template <typename T, int AUX> inline void gb_store2_x(GBuf b, uint32_t voff, cx<T> v0, cx<T> v1) { gb_store<T>(b, voff, 0, v0); gb_store<T>(b, voff + (uint32_t)sizeof(cx<T>), 0, v1); }
+template <typename T, int E> inline void gb_landed(cx<T>*) { }
 #else
 typedef unsigned int vk_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int vk_u32x4 __attribute__((ext_vector_type(4)));
@@ -127,6 +132,39 @@ template <> __device__ inline void gb_store_real4<float>(GBuf b, uint32_t voff, 
 template <> __device__ inline void gb_store_real4<double>(GBuf b, uint32_t voff, uint32_t soff, Real4<double> v) {
 	gb_store<double>(b, voff, soff, cx<double>{v.x, v.y});
 	gb_store<double>(b, voff + 16u, soff, cx<double>{v.z, v.w});
+}
+// cache-policy variants: AUX = sc0 | nt<<1 | sc1<<4 of the buffer instructions (sc1 = agent scope: write-through stores,
+// loads served from the memory side; nt = streaming hint).  Used by the fused Four-Step kernel for its on-die scratch ring.
+template <typename T, int AUX> __device__ inline cx<T> gb_load_x(GBuf b, uint32_t voff, uint32_t soff) {
+	if constexpr (sizeof(T) == 4) {
+		vk_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, AUX);
+		return cx<T>{__uint_as_float(t.x), __uint_as_float(t.y)};
+	} else {
+		vk_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, soff, AUX);
+		return cx<T>{__hiloint2double((int)t.y, (int)t.x), __hiloint2double((int)t.w, (int)t.z)};
+	}
+}
+template <typename T, int AUX> __device__ inline void gb_store_x(GBuf b, uint32_t voff, uint32_t soff, cx<T> v) {
+	if constexpr (sizeof(T) == 4) {
+		vk_u32x2 t; t.x = __float_as_uint(v.x); t.y = __float_as_uint(v.y);
+		__builtin_amdgcn_raw_buffer_store_b64(t, b.r, voff, soff, AUX);
+	} else {
+		vk_u32x4 t;
+		t.x = (unsigned)__double2loint(v.x); t.y = (unsigned)__double2hiint(v.x);
+		t.z = (unsigned)__double2loint(v.y); t.w = (unsigned)__double2hiint(v.y);
+		__builtin_amdgcn_raw_buffer_store_b128(t, b.r, voff + soff, 0, AUX); // soffset folded: see gb_store<double>
+	}
+}
+// makes the compiler wait (counted s_waitcnt) until the loads that produce v[0..E) have returned, nothing more
+template <typename T, int E> __device__ inline void gb_landed(cx<T>* v) {
+#pragma unroll
+	for (int m = 0; m < E; m++) asm volatile("" : "+v"(v[m].x), "+v"(v[m].y));
+}
+// two consecutive fp32 complex values in one 128-bit store
+template <typename T, int AUX> __device__ inline void gb_store2_x(GBuf b, uint32_t voff, cx<T> v0, cx<T> v1) {
+	static_assert(sizeof(T) == 4, "pairs of fp32 complex only");
+	vk_u32x4 t; t.x = __float_as_uint(v0.x); t.y = __float_as_uint(v0.y); t.z = __float_as_uint(v1.x); t.w = __float_as_uint(v1.y);
+	__builtin_amdgcn_raw_buffer_store_b128(t, b.r, voff, 0, AUX);
 }
 #endif
 

@@ -4,7 +4,7 @@
 // VkFFTSplitAxisBlock (vkFFT_AxisBlockSplitter.h:26: workgroup shape), VkFFTPlanAxis
 // (vkFFT_Plan_FFT.h:33: strides, batch folding) and VkFFT_AllocateLUT (vkFFT_ManageLUT.h:28: tables
 // computed in extended precision on the CPU).  The decisions themselves are re-derived for MI355X:
-// 160 KiB LDS per workgroup, 256-byte coalescing segments for strided tiles, Infinity-Cache chunking.
+// 160 KiB LDS per workgroup, 256-byte coalescing segments for strided tiles, fused Four-Step through the Infinity Cache.
 #include "engine.h"
 #include <cmath>
 #include <cstdlib>
@@ -124,7 +124,6 @@ struct PassBuild {
 	bool allowFast = true;
 	bool allowOp = false;   // op-FFT family (kernel_opfft.h): fused pre/post map kernels
 	bool noCollapse = false;
-	int chunkDim = -1;
 	uint64_t maxLds = 160 * 1024;
 	// tables prepared by the caller (arena offsets)
 	size_t auxOff = (size_t)-1, aux2Off = (size_t)-1;
@@ -359,7 +358,6 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	pp.inElemBytes = (int)((b.realIn ? 1 : 2) * (dp ? 8 : 4));
 	pp.outElemBytes = (int)((b.realOut ? 1 : 2) * (dp ? 8 : 4));
 	pp.label = b.label;
-	pp.chunkDim = b.chunkDim;
 	if (b.fastKernel != KERNEL_GENERIC) { // hand-specialised kernel: fixed tile, static LDS
 		pp.kernel = b.fastKernel; pp.variant = b.fastVariant; pp.threads = (uint32_t)b.fastThreads; pp.ldsBytes = 0;
 	}
@@ -463,7 +461,6 @@ struct AxisJob {
 	double scale = 1.0;
 	int inRole = ROLE_BUFFER, outRole = ROLE_BUFFER;
 	int axisIndex = 0;
-	uint64_t batchOuter = 1; // count of the outermost "others" entry (chunking candidate)
 };
 
 static uint32_t direct_max(const TransformDesc& d) { return (uint32_t)std::min<uint64_t>(d.raderMultMax, 61); }
@@ -545,7 +542,6 @@ struct MultiPassIO {
 	int64_t inOffset = 0, outOffset = 0, t1Offset = 0; // element offsets (T1 lives in ROLE_TEMP)
 	bool swapIn = false, swapOut = false;
 	double scale = 1.0;
-	bool chunkable = false;
 	// hooks for Bluestein: operation on the very first load / the very last store, indexed by the natural position
 	uint32_t firstPre = OP_NONE, lastPost = OP_NONE;
 	size_t firstAux = (size_t)-1, lastAux = (size_t)-1, lastAux2 = (size_t)-1;
@@ -573,7 +569,6 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 		}
 		return r;
 	};
-	const int chunkBase = io.chunkable ? (int)nOthers : -1;
 	const uint64_t n0 = sp[0];
 	const uint64_t M = N / n0;
 	// pass A: x[n0][M] columns, FFT over n0, twiddle, store transposed Y^T[m][k0] into T1
@@ -583,7 +578,7 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 	a.dims = dimsFor({M, 1, (int64_t)n0}, {}, 0, 1);
 	a.swapIn = io.swapIn; a.postOp = OP_TWIDDLE_4STEP; a.fsN = N; a.fsColDiv = 1;
 	a.inRole = io.inRole; a.inOffset = io.inOffset; a.outRole = ROLE_TEMP; a.outOffset = io.t1Offset;
-	a.label = "4step-A"; a.noCollapse = true; a.chunkDim = chunkBase;
+	a.label = "4step-A"; a.noCollapse = true;
 	if (io.firstPre != OP_NONE) {
 		a.preOp = io.firstPre; a.auxOff2ForPre = io.firstAux; a.bsSwapIn = io.bsSwapIn; a.opN = io.opN;
 		a.opStrideJ = (uint32_t)M; a.opStride0 = 1; a.opStride1 = 0;
@@ -599,7 +594,7 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 		c.dims = dimsFor({n0, 1, 1}, {}, 1, 0);
 		c.swapOut = io.swapOut; c.scale = io.scale;
 		c.inRole = ROLE_TEMP; c.inOffset = io.t1Offset; c.outRole = io.outRole; c.outOffset = io.outOffset;
-		c.label = "4step-B"; c.noCollapse = true; c.chunkDim = chunkBase;
+		c.label = "4step-B"; c.noCollapse = true;
 		if (io.lastPost != OP_NONE) {
 			c.postOp = io.lastPost; c.auxOff = io.lastAux; c.aux2Off = io.lastAux2; c.bsSwapOut = io.bsSwapOut; c.opN = io.opN;
 			c.opStrideJ = (uint32_t)n0; c.opStride0 = 1; c.opStride1 = 0;
@@ -616,7 +611,7 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 		bb.dims = dimsFor({n2 * n0, 1, 1}, {}, 1, 1);
 		bb.postOp = OP_TWIDDLE_4STEP; bb.fsN = M; bb.fsColDiv = (uint32_t)n0;
 		bb.inRole = bb.outRole = ROLE_TEMP; bb.inOffset = bb.outOffset = io.t1Offset;
-		bb.label = "4step3-B"; bb.noCollapse = true; bb.chunkDim = chunkBase;
+		bb.label = "4step3-B"; bb.noCollapse = true;
 		PassPlan pb; r = finish_pass(bb, ar, pb); if (r) return r;
 		// pass C: T1 [k1][i2][k0]: FFT over i2 (stride n0); out X[k0 + n0*(k1 + n1*k2)]
 		PassBuild c = proto;
@@ -625,7 +620,7 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 		c.dims = dimsFor({n0, 1, 1}, {{n1, (int64_t)(n2 * n0), (int64_t)n0}}, 1, 0);
 		c.swapOut = io.swapOut; c.scale = io.scale;
 		c.inRole = ROLE_TEMP; c.inOffset = io.t1Offset; c.outRole = io.outRole; c.outOffset = io.outOffset;
-		c.label = "4step3-C"; c.noCollapse = true; c.chunkDim = io.chunkable ? chunkBase + 1 : -1;
+		c.label = "4step3-C"; c.noCollapse = true;
 		if (io.lastPost != OP_NONE) {
 			c.postOp = io.lastPost; c.auxOff = io.lastAux; c.aux2Off = io.lastAux2; c.bsSwapOut = io.bsSwapOut; c.opN = io.opN;
 			c.opStrideJ = (uint32_t)(n0 * n1); c.opStride0 = 1; c.opStride1 = (uint32_t)n0;
@@ -635,6 +630,101 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 		passes.push_back(pb); passes.push_back(pc);
 	}
 	return 0;
+}
+
+// stage twiddles of a register-resident power-of-two schedule, laid out [(i-1)*S + s] per stage (kernel_pow2_core.h, Pow2Sched::lutOff)
+static size_t build_pow2_stage_lut(Arena& ar, const int bits[4], bool dp) {
+	uint64_t elems = 0, S = 1;
+	for (int k = 0; k < 4; k++) if (bits[k]) { const uint64_t R = 1ull << bits[k]; if (S > 1) elems += (R - 1) * S; S *= R; }
+	const size_t off = ar.alloc((elems + 1) * (dp ? 16 : 8));
+	uint64_t cur = 0; S = 1;
+	for (int k = 0; k < 4; k++) if (bits[k]) {
+		const uint64_t R = 1ull << bits[k];
+		if (S > 1) {
+			for (uint64_t i = 1; i < R; i++) for (uint64_t sidx = 0; sidx < S; sidx++) ar.putc(off, cur + (i - 1) * S + sidx, unit_root(i * sidx, R * S), dp);
+			cur += (R - 1) * S;
+		}
+		S *= R;
+	}
+	return off;
+}
+
+// Fused Four-Step (kernel_pow2_fused.h): a two-factor power-of-two transform on a unit-stride axis as ONE persistent launch whose
+// intermediate lives in a small scratch ring (Infinity-Cache resident) instead of a full-size temp buffer.  The other dimensions must
+// collapse into one batch progression on both sides.  Returns false when the plan does not qualify (the caller emits separate passes).
+static bool emit_fused(const TransformDesc& d, const AxisJob& j, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
+	if (!d.fused || d.disableFastKernels || (j.N & (j.N - 1)) != 0 || j.inStrideJ != 1 || j.outStrideJ != 1) return false;
+	const bool dp = j.dp;
+	const uint64_t es = dp ? 16 : 8;
+	int variant, la, lb, bitsA[4], bitsB[4], tca, tcb, thr, wgPerCu;
+	if (!pow2_fused_lookup(ilog2(j.N), dp, d.fusedMode, &variant, &la, &lb, bitsA, bitsB, &tca, &tcb, &thr, &wgPerCu)) return false;
+	// one batch progression
+	uint64_t batch = 1; int64_t inS = (int64_t)j.N, outS = (int64_t)j.N; bool first = true;
+	for (const HostDim& o : j.others) {
+		if (o.count <= 1) continue;
+		if (first) { inS = o.inStride; outS = o.outStride; batch = o.count; first = false; }
+		else { if (o.inStride != inS * (int64_t)batch || o.outStride != outS * (int64_t)batch) return false; batch *= o.count; }
+	}
+	if (inS < (int64_t)j.N || outS < (int64_t)j.N || batch >= (1ull << 31)) return false;
+	const uint64_t n0 = 1ull << la, n1 = 1ull << lb;
+	const uint64_t tileBytes = n0 * (uint64_t)tca * es, fftBytes = j.N * es;
+	const uint32_t logTiles = ilog2(fftBytes / tileBytes);
+	// chunk: about a MiB of transforms, dealt round-robin to Q queues (one per XCD when there are enough chunks).  Tickets of a queue
+	// are handed out in order, so at any moment its Wq workgroups hold a window of about Wq consecutive tickets.  A wait is avoided
+	// when the producer tiles of a dependency left that window before the consumer enters it: lag D = 1 + X slots between a chunk's A
+	// and B tiles, ring NS = D + 1 + X slots before a slot is rewritten, X slots ~ margin * Wq tickets.
+	const uint64_t chunkTarget = d.fusedChunkBytes ? d.fusedChunkBytes : (1ull << 20);
+	uint32_t logG = 0;
+	while ((fftBytes << (logG + 1)) <= chunkTarget && (1ull << (logG + 1)) <= batch) logG++;
+	const uint64_t G = 1ull << logG;
+	const uint64_t C = (batch + G - 1) / G;
+	const uint64_t tpc = G << logTiles; // tickets per slot (= tiles per chunk and phase)
+	uint64_t Q = d.fusedQueues ? d.fusedQueues : (C >= 4 * kFusedMaxQueues ? kFusedMaxQueues : 1);
+	if (Q > kFusedMaxQueues) Q = kFusedMaxQueues;
+	if (Q > C) Q = 1;
+	const uint64_t Wq = 256ull * (uint64_t)(d.fusedWgPerCu ? d.fusedWgPerCu : wgPerCu) / Q;
+	const uint64_t marginPct = d.fusedMarginPct ? d.fusedMarginPct : 125;
+	const uint64_t X = (Wq * marginPct / 100 + tpc - 1) / tpc;
+	const uint64_t Cq = (C + Q - 1) / Q;
+	uint64_t D = d.fusedLag ? d.fusedLag : 1 + X;
+	if (D < 1) D = 1;
+	uint64_t NS = d.fusedRing ? d.fusedRing : D + 1 + X;
+	if (NS <= D) NS = D + 1;
+	if (NS > Cq) NS = Cq; // fewer chunks than ring slots: no slot is ever reused
+	if (D > Cq) D = Cq;   // (then every A tile of the queue precedes its first B tile)
+	if (NS < 1) NS = 1;
+	const uint64_t scratch = Q * NS * G * fftBytes;
+	if (d.userTempBytes && scratch > d.userTempBytes) return false;
+	if (((Cq + D) << (logG + logTiles)) >= (1ull << 31)) return false; // 32-bit tickets
+	PassPlan pp;
+	memset(&pp.prm, 0, sizeof(pp.prm));
+	pp.prm.L = (uint32_t)std::min<uint64_t>(j.N, 0xffffffffu);
+	pp.kernel = KERNEL_POW2_FUSED; pp.variant = variant; pp.threads = (uint32_t)thr; pp.dp = dp;
+	pp.inRole = j.inRole; pp.outRole = j.outRole; pp.inElemBytes = pp.outElemBytes = (int)es;
+	pp.label = "4step-fused";
+	pp.lutOff = build_pow2_stage_lut(ar, bitsA, dp);
+	pp.fusedLutBOff = build_pow2_stage_lut(ar, bitsB, dp);
+	{ // two-level Four-Step table w_N^e = lo[e & mask] * hi[e >> bits]  (vkFFT_4step.h:31 computes the same factor per element)
+		const uint32_t lo = (ceil_log2(j.N) + 1) / 2;
+		const uint64_t nlo = 1ull << lo, nhi = (j.N + nlo - 1) / nlo;
+		const size_t off = ar.alloc((nlo + nhi) * es);
+		for (uint64_t i = 0; i < nlo; i++) ar.putc(off, i, unit_root(i, j.N), dp);
+		for (uint64_t i = 0; i < nhi; i++) ar.putc(off, nlo + i, unit_root(i * nlo, j.N), dp);
+		pp.auxOff = off; pp.fused.fsLoBits = lo;
+	}
+	pp.fusedCtrOff = ar.alloc((kFusedCtrDone + 2 * C) * sizeof(uint32_t)); // zero in the host image; the kernel leaves it zeroed
+	memset(ar.b.data() + pp.fusedCtrOff, 0, (kFusedCtrDone + 2 * C) * sizeof(uint32_t));
+	FusedParams& f = pp.fused;
+	f.inBatchStride = inS; f.outBatchStride = outS;
+	f.n0 = (uint32_t)n0; f.n1 = (uint32_t)n1; f.batch = (uint32_t)batch;
+	f.logG = logG; f.logTiles = logTiles; f.C = (uint32_t)C; f.NS = (uint32_t)NS; f.D = (uint32_t)D; f.Q = (uint32_t)Q;
+	f.swapIn = f.swapOut = j.inverse ? 1 : 0; f.reverse = 0; f.scale = j.scale;
+	pp.fusedWgPerCu = (int)d.fusedWgPerCu;
+	passes.push_back(pp);
+	out.uploadsPerAxis[j.axisIndex] = 2;
+	out.axisSplit[j.axisIndex][0] = n1; out.axisSplit[j.axisIndex][1] = n0;
+	out.tempBytes = std::max<uint64_t>(out.tempBytes, scratch);
+	return true;
 }
 
 // Four-Step along a NON-unit-stride axis (element stride W, a unit-stride dimension x of extent nx beside it):
@@ -970,6 +1060,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	}
 
 	// ---- Four-Step on a unit-stride axis: N = n0 * M, recursively M = n1 * n2 -------------------------
+	if (emit_fused(d, j, ar, out, passes)) return 0;
 	std::vector<uint64_t> sp;
 	if (!choose_split(j.N, dp, d.maxLds, dmax, !d.disableFastKernels, sp)) return 3002;
 	out.uploadsPerAxis[j.axisIndex] = (uint32_t)sp.size();
@@ -980,7 +1071,6 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	for (auto& o : io.othersOut) o.inStride = o.outStride;
 	io.inRole = j.inRole; io.outRole = j.outRole;
 	io.swapIn = io.swapOut = j.inverse; io.scale = j.scale;
-	io.chunkable = true;
 	int r = emit_multipass(b, j.N, sp, io, ar, passes);
 	if (r) return r;
 	uint64_t nsub = 1;
@@ -1382,19 +1472,6 @@ int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
 		}
 	}
 
-	// Infinity-Cache chunking of a multi-pass 1D plan over the batch
-	if (nd == 1 && out.passes.size() >= 2 && d.chunkTargetBytes && out.tempBytes) {
-		const uint64_t perFFT = d.size[0] * (dp ? 16 : 8);
-		uint64_t cb = std::max<uint64_t>(1, d.chunkTargetBytes / (2 * perFFT));
-		if (cb < d.batch) {
-			out.chunkFirst = 0; out.chunkLast = (int)out.passes.size() - 1;
-			out.chunkBatch = cb; out.totalBatch = d.batch;
-			out.chunkStreams = std::max<uint32_t>(1, std::min<uint32_t>(d.chunkStreams, 4));
-			out.chunkTempStrideBytes = cb * perFFT;
-			if (!d.userTempBytes) out.tempBytes = out.chunkStreams * cb * perFFT;
-			else if (d.userTempBytes < out.chunkStreams * cb * perFFT) out.chunkStreams = 1;
-		}
-	}
 	if (d.userTempBytes && out.tempBytes > d.userTempBytes) return 2016;
 	return 0;
 }
