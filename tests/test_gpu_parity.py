@@ -40,6 +40,52 @@ def test_pow2_multi_pass(run, oracle, k, passes):
     assert up == [passes]
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("k,batch", [(15, 37), (16, 65), (17, 19), (18, 9), (19, 5), (20, 3)])
+def test_fused_fourstep_equals_separate_passes(run, oracle, monkeypatch, k, batch):
+    """2^15..2^20 run as ONE persistent launch (kernel_pow2_fused.h) whose intermediate lives in an Infinity-Cache resident ring; the same
+    plan with the fusion switched off runs the two Four-Step passes as separate launches through a full-size temp buffer.  Odd batches:
+    partial last chunk, queues of unequal length."""
+    N = 1 << k
+    x = parity.seeded_complex(N * batch, False, 77 + k)
+    yf, zf, up = run.transform(x, (N,), batch, both=True)
+    monkeypatch.setenv("VKFFT_MI355X_FUSED", "0")
+    ys, zs, up2 = run.transform(x, (N,), batch, both=True)
+    assert up == [2] and up2 == [2]
+    assert rel_l2(yf, ys) < 1e-6 and rel_l2(zf, zs) < 2e-6
+    truth = oracle.truth_c2c(x[: 2 * N], (N,), 2)
+    assert rel_l2(yf[: 2 * N], truth) < 1e-6
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("k,env", [(15, dict(LAG=1, RING=2, QUEUES=8)), (16, dict(LAG=1, RING=2, QUEUES=1)), (16, dict(LAG=2, RING=3, CHUNK_KIB=512)),
+                                   (17, dict(LAG=1, RING=2, WGS=8)), (18, dict(LAG=1, RING=2, QUEUES=3)), (20, dict(LAG=1, RING=2))])
+def test_fused_fourstep_under_dependency_pressure(product_lib, monkeypatch, k, env):
+    """the smallest legal ring and lag: almost every tile finds its dependency unsatisfied and takes the polling path, ring slots are
+    reused immediately, the grid is oversubscribed — results must not change and the launch must terminate (1 GiB, 12 launches)"""
+    import torch
+    for a, b in env.items():
+        monkeypatch.setenv("VKFFT_MI355X_FUSED_" + a, str(b))
+    N = 1 << k; B = (1 << 27) // N
+    g = torch.Generator(device="cuda"); g.manual_seed(99 + k)
+    x = torch.empty(2 * N * B, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    buf = x.clone()
+    app = api.App([N], B, buffer_ptr=buf.data_ptr(), normalize=True, lib=product_lib)
+    app.forward(); torch.cuda.synchronize()
+    X = torch.view_as_complex(buf.view(-1, 2)).view(B, N)
+    xc = torch.view_as_complex(x.view(-1, 2)).view(B, N)
+    for b in (0, B // 2, B - 1):
+        ref = torch.fft.fft(xc[b].to(torch.complex128))
+        assert (torch.linalg.norm(X[b].to(torch.complex128) - ref) / torch.linalg.norm(ref)).item() < 1e-6
+    app.inverse()
+    for _ in range(5):
+        app.forward(); app.inverse()
+    torch.cuda.synchronize()
+    rt = (torch.linalg.norm(buf.double() - x.double()) / torch.linalg.norm(x.double())).item()
+    assert rt < 6e-6, (k, rt)
+    app.delete()
+
+
 def test_config1_vkfft_sample0_plumbing(run, oracle):
     """BASELINE config 1: N=4096, batch 1, forward+inverse, data = the reference's unseeded rand() stream."""
     v = oracle.rand_sample(2 * 4096)

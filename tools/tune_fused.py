@@ -35,19 +35,10 @@ def run(k, env, iters=6, check=False):
 
 if __name__ == "__main__":
     kmin, kmax = int(sys.argv[1]), int(sys.argv[2])
-    quick = len(sys.argv) > 3
+    specs = [{"FUSED": 0}, {}]
+    for arg in sys.argv[3:]:
+        specs.append(dict(kv.split("=") for kv in arg.split(",")))
     for k in range(kmin, kmax + 1):
-        print(json.dumps(run(k, {"VKFFT_MI355X_FUSED": 0}, check=True)), flush=True)
-        print(json.dumps(run(k, {"VKFFT_MI355X_FUSED": 1}, check=True)), flush=True)
-        if quick:
-            continue
-        print(json.dumps(run(k, {"VKFFT_MI355X_FUSED_MODE": 2}, check=True)), flush=True)
-        print(json.dumps(run(k, {"VKFFT_MI355X_FUSED_QUEUES": 1}, check=True)), flush=True)
-        for chunk in (256, 512, 2048, 4096):
-            print(json.dumps(run(k, {"VKFFT_MI355X_FUSED_CHUNK_KIB": chunk})), flush=True)
-        for m in (50, 75, 100, 200, 300):
-            print(json.dumps(run(k, {"VKFFT_MI355X_FUSED_MARGIN": m})), flush=True)
-        for wgs in (1, 2, 3, 4):
-            print(json.dumps(run(k, {"VKFFT_MI355X_FUSED_WGS": wgs})), flush=True)
-        for v in (1,):
-            print(json.dumps(run(k, {"VKFFT_MI355X_FUV%d" % k: v}, check=True)), flush=True)
+        for sp in specs:
+            env = {"VKFFT_MI355X_" + a.replace("KK", str(k)): b for a, b in sp.items()}
+            print(json.dumps(run(k, env, check=True)), flush=True)

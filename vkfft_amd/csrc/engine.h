@@ -74,7 +74,7 @@ struct TransformDesc {
 	bool disableFastKernels = false;
 	// fused Four-Step (kernel_pow2_fused.h); the numeric fields are tuning knobs, 0 = planner default
 	bool fused = true;
-	int fusedMode = 0;
+	int fusedMode = 2;
 	uint64_t fusedChunkBytes = 0;
 	uint32_t fusedLag = 0, fusedRing = 0, fusedWgPerCu = 0, fusedQueues = 0, fusedMarginPct = 0;
 };

@@ -80,28 +80,15 @@ template <typename T, typename SA, int TCA, typename SB, int TCB> constexpr int 
 	return w > 4 ? 4 : w < 1 ? 1 : w;
 }
 
-// Publishing an A tile's completion (thread 0, at a point where every wave's vector-memory operations have drained).
-// MODE bit 0 clear: the ring stores were write-through, the counter is bumped right away.  MODE bit 0 set: the ring stores were
-// ordinary write-back stores (they do not hold load/store-unit entries until the memory side answers); the XCD's L2 is told to
-// write its dirty lines back now (asynchronously) and the counter is bumped at the NEXT such point, when that write-back has drained too.
+// Publishing an A tile's completion (thread 0, at a point where every wave's vector-memory operations have drained: the ring stores
+// are write-through, so "acknowledged" means "at the memory side").  Write-back stores + an L2 write-back before the signal were tried
+// and are wrong: the writer's L2 keeps the lines, and a later tenant of the ring slot written by another XCD is then read stale.
 template <int MODE> __device__ inline void fused_publish(uint32_t* ctr, uint32_t& pending, uint32_t& flushing) {
 	constexpr uint32_t kNone = 0xffffffffu;
-	if constexpr ((MODE & 1) == 0) {
-		if (pending != kNone) { (void)VKFFT_ATOMIC_ADD_U32(ctr + pending, 1u); pending = kNone; }
-	} else {
-		if (flushing != kNone) { (void)VKFFT_ATOMIC_ADD_U32(ctr + flushing, 1u); flushing = kNone; }
-		if (pending != kNone) {
-#if !defined(VKFFT_HOSTEMU)
-			asm volatile("buffer_wbl2 sc1" ::: "memory");
-#endif
-			flushing = pending; pending = kNone;
-		}
-	}
+	(void)flushing;
+	if (pending != kNone) { (void)VKFFT_ATOMIC_ADD_U32(ctr + pending, 1u); pending = kNone; }
 }
-template <int MODE> __device__ inline void fused_publish_all(uint32_t* ctr, uint32_t& pending, uint32_t& flushing) {
-	fused_publish<MODE>(ctr, pending, flushing);
-	if constexpr ((MODE & 1) != 0) { VKFFT_VMEM_DRAIN(); fused_publish<MODE>(ctr, pending, flushing); }
-}
+template <int MODE> __device__ inline void fused_publish_all(uint32_t* ctr, uint32_t& pending, uint32_t& flushing) { fused_publish<MODE>(ctr, pending, flushing); }
 
 __device__ inline uint32_t fused_xcc_id() {
 #if defined(VKFFT_HOSTEMU)
@@ -122,7 +109,7 @@ pow2_fused_kernel(const FusedParams p) {
 	static_assert(LA * TCA == LB * TCB, "both phases move the same number of points per tile");
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	constexpr int AUX_SC = 16;                   // ring loads: agent scope, served from the memory side
-	constexpr int AUX_ST = (MODE & 1) ? 0 : 16;  // ring stores: write-through, or write-back + an explicit L2 write-back before the signal
+	constexpr int AUX_ST = 16;                   // ring stores: write-through (no XCD's L2 ever holds a ring line)
 	constexpr int AUX_HBM = (MODE & 2) ? 2 : 0;
 	constexpr int LDSN = LA * TCPA > LB * TCPB ? LA * TCPA : LB * TCPB;
 	constexpr int LUTA = SA::lutTotal(), LUTB = SB::lutTotal();
@@ -235,9 +222,9 @@ pow2_fused_kernel(const FusedParams p) {
 #pragma unroll
 						for (int m = 0; m < EA; m++) v[m] = cswap(v[m]);
 					}
-					pow2_stages<T, SA, 0, TPFA, TCPA, TwLds<T>>(v, lds + c, TwLds<T>{twA}, tau, false);
+					if constexpr ((MODE & 8) == 0) pow2_stages<T, SA, 0, TPFA, TCPA, TwLds<T>>(v, lds + c, TwLds<T>{twA}, tau, false);
 					VKFFT_PROF(8);
-					pow2_fs_twiddle<T, SA::LOGE, TPFA>(v, gtw, p.fsLoBits, tau, col0 + c);
+					if constexpr ((MODE & 8) == 0) pow2_fs_twiddle<T, SA::LOGE, TPFA>(v, gtw, p.fsLoBits, tau, col0 + c);
 					VKFFT_PROF(9);
 					if constexpr (SA::NS > 1) __syncthreads(); // the last exchange's reads are complete
 #pragma unroll
@@ -246,7 +233,7 @@ pow2_fused_kernel(const FusedParams p) {
 					VKFFT_PROF(10);
 				}
 			}
-			if (live) {
+			if (live && (MODE & 16) == 0) {
 				const GBuf gs = make_gbuf(sbase + (uint64_t)col0 * LA * ES);
 				if constexpr (sizeof(T) == 4) {
 					// two consecutive k per lane: 16-byte write-through stores (8-byte sc1 stores cost 2.7x per byte)
@@ -273,7 +260,7 @@ pow2_fused_kernel(const FusedParams p) {
 			const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)(liveB ? bB : 0u) * p.outBatchStride + k00));
 			if (!okB) { fused_wait(p.ctr + depB(s), TPC); VKFFT_PROF(6); } // rare (okB was sampled one ticket ago: ordered before the loads by S1)
 #pragma unroll
-			for (int m = 0; m < EB; m++) vB[m] = gb_load_x<T, AUX_SC>(gsB, laneB, m * stepB);
+			for (int m = 0; m < EB; m++) vB[m] = gb_load_x<T, AUX_SC>(gsB, (MODE & 16) ? kGbInvalid : laneB, m * stepB);
 			VKFFT_VMEM_DRAIN(); // the tile is in registers; the A part's ring stores are acknowledged
 			__syncthreads();    // S3: ... in every wave
 			VKFFT_PROF(3);
@@ -282,7 +269,7 @@ pow2_fused_kernel(const FusedParams p) {
 				fused_publish<MODE>(p.ctr, pending, flushing);
 			}
 			if (liveB) {
-				pow2_stages<T, SB, 0, TPFB, TCPB, TwLds<T>>(vB, lds + cBl, TwLds<T>{twB}, tauB, false);
+				if constexpr ((MODE & 8) == 0) pow2_stages<T, SB, 0, TPFB, TCPB, TwLds<T>>(vB, lds + cBl, TwLds<T>{twB}, tauB, false);
 				if (p.swapOut) {
 #pragma unroll
 					for (int m = 0; m < EB; m++) vB[m] = cswap(vB[m]);

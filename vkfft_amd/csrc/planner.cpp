@@ -683,7 +683,9 @@ static bool emit_fused(const TransformDesc& d, const AxisJob& j, Arena& ar, Dire
 	if (Q > kFusedMaxQueues) Q = kFusedMaxQueues;
 	if (Q > C) Q = 1;
 	const uint64_t Wq = 256ull * (uint64_t)(d.fusedWgPerCu ? d.fusedWgPerCu : wgPerCu) / Q;
-	const uint64_t marginPct = d.fusedMarginPct ? d.fusedMarginPct : 125;
+	// measured (tools/tune_fused.py): completions are published up to a ticket late and the ticket rate rises with the speed of the
+	// kernel, so the window is taken generously: 3 windows where two or more workgroups share a CU, 2 with one workgroup per CU
+	const uint64_t marginPct = d.fusedMarginPct ? d.fusedMarginPct : (wgPerCu >= 2 ? 300 : 200);
 	const uint64_t X = (Wq * marginPct / 100 + tpc - 1) / tpc;
 	const uint64_t Cq = (C + Q - 1) / Q;
 	uint64_t D = d.fusedLag ? d.fusedLag : 1 + X;
