@@ -35,13 +35,39 @@ def flops_pair(k):
     return 2 * 5.0 * N * k * ((1 << TOTAL_LOG2) // N)
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` run directly (no torchrun): start one process per GPU on this node, let rank 0's JSON line through."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: this node exposes {have} GPU(s)")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c2c-sweep", choices=["c2c-sweep", "slab3d"])
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])
+    if args.workload == "slab3d":
+        return slab3d_main(args)
 
     import numpy as np
     import torch
@@ -50,6 +76,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -101,48 +129,59 @@ def main():
     value = total_flops / (ms_per_step * 1e-3) / 1e9
 
     # ---- per-size table + dominant kernel, HIP events on the launch stream (outside the contract-timed region) ----
+    GIB2 = 2.0 * (8 << TOTAL_LOG2)  # algorithmic bytes of one transform of the buffer: one read + one write
     per_size = {}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 6
-    for k in range(KMIN, KMAX + 1):
+
+    def timed(fn, n):
         e0.record()
-        for _ in range(reps):
-            apps[k].forward(); apps[k].inverse()
+        for _ in range(n):
+            fn()
         e1.record(); e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        passes = apps[k].uploads()[0]
-        per_size[k] = dict(pair_ms=round(ms, 4), passes=passes, alg_GBps=round(2 * 2 * (8 << TOTAL_LOG2) / (ms * 1e-3) / 1e9, 1),
+        return e0.elapsed_time(e1) / n
+
+    # what a plain device-to-device copy of the same 1 GiB reaches on this box, same clock (the practical HBM ceiling)
+    other = torch.empty_like(buf)
+    other.copy_(buf)
+    copy_ms = min(timed(lambda: other.copy_(buf), 10) for _ in range(2))
+    copy_GBps = GIB2 / (copy_ms * 1e-3) / 1e9
+    del other
+    for k in range(KMIN, KMAX + 1):
+        ms = timed(lambda: (apps[k].forward(), apps[k].inverse()), reps)
+        launches, kern = apps[k].launch_info()
+        # forward transforms only, every launch sweeping front to back: no pairing with the inverse, no zig-zag reuse of what the
+        # previous launch left in the Infinity Cache
+        os.environ["VKFFT_MI355X_NO_REVERSE"] = "1"
+        fwd = api.App([1 << k], (1 << TOTAL_LOG2) >> k, device_index=dev, buffer_ptr=buf.data_ptr(), stream=stream if stream else None)
+        del os.environ["VKFFT_MI355X_NO_REVERSE"]
+        fwd.forward()
+        fms = timed(fwd.forward, 2 * reps)
+        fwd.delete()
+        buf.uniform_(-1, 1, generator=gen)  # (unnormalised forwards grow the data)
+        per_size[k] = dict(pair_ms=round(ms, 4), passes=apps[k].uploads()[0], launches=launches, kernel=kern,
+                           alg_GBps=round(2 * GIB2 / (ms * 1e-3) / 1e9, 1), fwd_only_alg_GBps=round(GIB2 / (fms * 1e-3) / 1e9, 1),
                            GFLOPs=round(flops_pair(k) / (ms * 1e-3) / 1e9, 1))
-    # dominant kernel = the kernel the sweep spends most time in.  Multi-pass sizes (2^15..2^22) run the strided-tile
-    # kernel pow2_col_kernel twice or three times per transform and account for most of the step; its launches are
-    # timed here directly: a two-pass plan of the size with the largest time share = 2 launches per transform.
-    multi = [k for k in per_size if per_size[k]["passes"] > 1]
-    single = [k for k in per_size if per_size[k]["passes"] == 1]
-    t_multi = sum(per_size[k]["pair_ms"] for k in multi)
-    t_single = sum(per_size[k]["pair_ms"] for k in single)
-    if t_multi >= t_single and multi:
-        kd = max((k for k in multi if per_size[k]["passes"] == 2), key=lambda k: per_size[k]["pair_ms"], default=multi[0])
-        kname = "pow2_col_kernel<float> (strided-tile Four-Step pass)"
-    else:
-        kd = max(single, key=lambda k: per_size[k]["pair_ms"])
-        kname = "pow2_row_kernel<float> (single-pass unit-stride)"
-    launches_per_pair = 2 * per_size[kd]["passes"]
-    e0.record()
-    for _ in range(reps):
-        apps[kd].forward(); apps[kd].inverse()
-    e1.record(); e1.synchronize()
-    launch_ms = e0.elapsed_time(e1) / (reps * launches_per_pair)
-    # algorithmic bytes of one launch: SURVEY §8(d): 16 B per point per *transform*; a P-pass plan spreads one
-    # transform over P launches, so one launch accounts for 16*N*B/P bytes of algorithmic traffic.
-    alg_bytes_launch = 16.0 * (1 << TOTAL_LOG2) / per_size[kd]["passes"]
+    # dominant kernel = the kernel family the sweep spends most time in, at its slowest size
+    fam_time = {}
+    for k, v in per_size.items():
+        fam_time[v["kernel"]] = fam_time.get(v["kernel"], 0.0) + v["pair_ms"]
+    dom = max(fam_time, key=fam_time.get)
+    kd = max((k for k in per_size if per_size[k]["kernel"] == dom), key=lambda k: per_size[k]["pair_ms"])
+    launches_per_pair = 2 * per_size[kd]["launches"]
+    launch_ms = timed(lambda: (apps[kd].forward(), apps[kd].inverse()), reps) / launches_per_pair
+    # algorithmic bytes of one launch (16 B per point per transform): a plan of P launches spreads them over P launches
+    alg_bytes_launch = GIB2 / per_size[kd]["launches"]
     achieved = alg_bytes_launch / (launch_ms * 1e-3) / 1e9
-    roofline = dict(bound="hbm", kernel=kname, size_log2N=kd, passes=per_size[kd]["passes"], launch_ms=round(launch_ms, 5),
+    roofline = dict(bound="hbm", kernel=dom, time_share=round(fam_time[dom] / sum(fam_time.values()), 3), size_log2N=kd,
+                    launches_per_transform=per_size[kd]["launches"], launch_ms=round(launch_ms, 5),
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                    physical_GBps_per_launch=round(16.0 * (1 << TOTAL_LOG2) / (launch_ms * 1e-3) / 1e9, 1), traffic=None)
-    prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+                    copy_GBps_same_box=round(copy_GBps, 1), frac_of_copy=round(achieved / copy_GBps, 4), traffic=None)
+    prof = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if os.path.exists(prof):
         try:
-            roofline["traffic"] = json.load(open(prof)).get("hbm_bytes_per_launch")
+            roofline["traffic"] = json.load(open(prof)).get(dom.split("<")[0], {}).get("bytes_per_launch")
+            roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, separate passes; L2<->fabric requests: Infinity-Cache hits included)"
         except Exception:
             pass
 
@@ -165,6 +204,51 @@ def main():
         dist.destroy_process_group()
 
 
+def slab3d_main(args):
+    """BASELINE config 5, second half: ONE slab-decomposed 3-D C2C fp32 transform (default 1024^3) over all ranks, one all-to-all
+    between the (y,x) sweep and the z sweep (vkfft_amd/distributed.py).  A step = forward + inverse of the volume."""
+    import torch
+    from vkfft_amd import api
+    from vkfft_amd.distributed import SlabFFT3D
+    n = int(os.environ.get("VKFFT_BENCH_SLAB_N", "1024"))
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    api.load()
+    plan = SlabFFT3D(n, n, n, device_index=local_rank, normalize=True)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1 + rank)
+    x = torch.view_as_complex(torch.empty((n // world, n, n, 2), dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=gen))
+
+    def step(v):
+        return plan.inverse(plan.forward(v))
+
+    for _ in range(args.warmup):
+        x = step(x)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = step(x)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = 1e3 * float(t.item()) / args.steps
+    import math
+    flops = 2 * 5.0 * n ** 3 * math.log2(n ** 3)
+    xb = plan.exchange_bytes_per_rank()
+    if rank == 0:
+        print(json.dumps(dict(metric="GFLOP/s (5N log2 N), slab-decomposed 3D C2C fp32, one all-to-all per transform", value=round(flops / (ms * 1e-3) / 1e9, 1), unit="GFLOP/s",
+                              n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 4), higher_is_better=True, scaling="strong", vs_baseline=None,
+                              dtype="f32", data="synthetic",
+                              config=dict(workload=f"3D C2C {n}^3 fp32, z-slabs over {world} rank(s), forward + inverse per step", plane_groups=plan.G,
+                                          exchange_bytes_per_rank_per_transform=xb,
+                                          exchange_GBps_per_rank_if_exchange_were_the_whole_step=round(2 * xb / (ms * 1e-3) / 1e9, 1) if world > 1 else None))))
+    plan.delete()
+    dist.destroy_process_group()
+
+
 def cpu_baseline():
     """FFTW3 API (the reference's CPU ground-truth path, sample_11_precision_VkFFT_single.cpp:116-132) served by MKL,
     all host cores, on a bounded sample: sizes 2^8, 2^12, 2^16, 2^20 with 2^24 points each, forward+inverse."""
@@ -183,13 +267,14 @@ def cpu_baseline():
     flops = 0.0; secs = 0.0
     ks = [8, 12, 16, 20]
     if O.fftw_available():
+        threaded = O.fftw_set_threads(cores)  # fftwf_init_threads + fftwf_plan_with_nthreads(all cores); each timing has an untimed warm-up
         for k in ks:
             N = 1 << k; B = (1 << pts_log2) // N
             _, tf = O.fftw_c2c(x, N, B, inverse=False, reps=3)
             _, ti = O.fftw_c2c(x, N, B, inverse=True, reps=3)
             secs += tf + ti; flops += 2 * 5.0 * N * k * B
         return dict(value=round(flops / secs / 1e9, 1), unit="GFLOP/s", cores=cores, kind="reference",
-                    sample=f"FFTW3 API via MKL libmkl_rt (FFTW proper is not installed), fftwf_plan_many_dft in-place, N=2^{ks}, 2^{pts_log2} points each, fwd+inv, MKL_NUM_THREADS={os.environ['MKL_NUM_THREADS']}",
+                    sample=f"FFTW3 API via MKL libmkl_rt (FFTW proper is not installed), fftwf_plan_many_dft in-place, N=2^{ks}, 2^{pts_log2} points each, fwd+inv, warm, MKL_NUM_THREADS={os.environ['MKL_NUM_THREADS']}, fftwf_plan_with_nthreads={'yes' if threaded else 'not exported'}",
                     alg_GBps=round(len(ks) * 2 * 16.0 * (1 << pts_log2) / secs / 1e9, 1))
     # fallback: the C restatement of the reference's algorithm (oracle/vkfft_oracle.c), one core
     pts_log2 = 18

@@ -389,6 +389,11 @@ VKFFT_API const char* getVkFFTErrorString(VkFFTResult result);
  * out[1]=sizeof(VkFFTLaunchParams), out[2]=sizeof(VkFFTPlan), out[3]=sizeof(VkFFTApplication). */
 VKFFT_API void vkfftMI355XStructSizes(pfUINT out[4]);
 
+/* Extension (not in the reference, which only prints such information under printMemoryLayout): what one VkFFTAppend of this
+ * application enqueues.  Returns the number of kernel launches of the forward (inverse != 1) or inverse plan and writes their
+ * kernel families, comma separated, into names[0..cap) (NUL terminated, truncated if cap is too small; names may be NULL). */
+VKFFT_API int vkfftMI355XDescribePlan(const VkFFTApplication* app, int inverse, char* names, pfUINT cap);
+
 #ifdef __cplusplus
 }
 #endif

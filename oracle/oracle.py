@@ -124,6 +124,14 @@ def fftw_available():
     return bool(mkl().fftw_mkl_available())
 
 
+def fftw_set_threads(n):
+    """FFTW threading API (fftw_init_threads / fftw_plan_with_nthreads) for plans created afterwards; False if not exported."""
+    l = mkl()
+    l.fftw_mkl_set_threads.restype = C.c_int
+    l.fftw_mkl_set_threads.argtypes = [C.c_int]
+    return bool(l.fftw_mkl_set_threads(int(n)))
+
+
 def fftw_c2c(x, N, batch, inverse=False, reps=1):
     """in-place batched 1D C2C via the FFTW3 API (MKL); returns (result, seconds per execute)."""
     x = np.ascontiguousarray(x).copy()

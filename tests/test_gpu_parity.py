@@ -428,12 +428,14 @@ def test_multi_gpu_drivers_on_one_device(product_lib):
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     nx, ny, nz = 96, 64, 40
     x = torch.view_as_complex(torch.empty(nz, ny, nx, 2, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g))
-    plan = SlabFFT3D(nx, ny, nz, lib=product_lib)
-    y = plan.forward(x.clone())
     ref = torch.fft.fftn(x.to(torch.complex128), dim=(0, 1, 2))
-    assert (torch.linalg.norm(y.to(torch.complex128) - ref) / torch.linalg.norm(ref)).item() < 2e-6
-    z = plan.inverse(y)
-    assert (torch.linalg.norm(z.to(torch.complex128) - x.to(torch.complex128) * (nx * ny * nz)) / torch.linalg.norm(x.to(torch.complex128) * (nx * ny * nz))).item() < 4e-6
+    for groups in (1, 4):  # 4: plane groups pipelined over the compute stream and the caller's stream
+        plan = SlabFFT3D(nx, ny, nz, lib=product_lib, groups=groups)
+        y = plan.forward(x.clone())
+        assert (torch.linalg.norm(y.to(torch.complex128) - ref) / torch.linalg.norm(ref)).item() < 2e-6
+        z = plan.inverse(y)
+        assert (torch.linalg.norm(z.to(torch.complex128) - x.to(torch.complex128) * (nx * ny * nz)) / torch.linalg.norm(x.to(torch.complex128) * (nx * ny * nz))).item() < 4e-6
+        plan.delete()
     # batch sharding: rank 1 of 3 transforms rows [lo, hi) of a 100-row batch exactly as the unsharded plan does
     N, B = 1080, 100
     a = torch.empty(B, 2 * N, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)

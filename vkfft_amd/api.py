@@ -86,7 +86,7 @@ class VkFFTApplication(C.Structure):
 
 
 EXPORTS = ["initializeVkFFT", "VkFFTAppend", "deleteVkFFT", "VkFFTGetVersion", "getVkFFTErrorString",
-           "vkfftMI355XStructSizes"]
+           "vkfftMI355XStructSizes", "vkfftMI355XDescribePlan"]
 VKFFT_SUCCESS = 0
 _lib = None
 
@@ -114,6 +114,8 @@ def _bind(p):
     lib.getVkFFTErrorString.argtypes = [C.c_int]
     lib.vkfftMI355XStructSizes.restype = None
     lib.vkfftMI355XStructSizes.argtypes = [C.POINTER(u64)]
+    lib.vkfftMI355XDescribePlan.restype = C.c_int
+    lib.vkfftMI355XDescribePlan.argtypes = [C.POINTER(VkFFTApplication), C.c_int, C.c_char_p, u64]
     sizes = (u64 * 4)()
     lib.vkfftMI355XStructSizes(sizes)
     mine = [C.sizeof(VkFFTConfiguration), C.sizeof(VkFFTLaunchParams), C.sizeof(VkFFTPlan), C.sizeof(VkFFTApplication)]
@@ -135,7 +137,9 @@ def load():
 
 def load_test_double(path):
     """tests only: bind the CPU-emulated build of the same sources (tests/hostemu).  Never used by the product."""
-    return _bind(path)
+    lib = _bind(path)
+    lib._vkfft_test_double = True
+    return lib
 
 
 class VkFFTError(RuntimeError):
@@ -194,6 +198,14 @@ class App:
     def uploads(self, inverse=False):
         pl = self.app.localFFTPlan_inverse if inverse else self.app.localFFTPlan
         return [int(pl.contents.numAxisUploads[i]) for i in range(int(self.app.configuration.FFTdim))]
+
+    def launch_info(self, inverse=False):
+        """(kernel launches per VkFFTAppend, kernel family that accounts for most of them) — extension vkfftMI355XDescribePlan"""
+        buf = C.create_string_buffer(1024)
+        n = self.lib.vkfftMI355XDescribePlan(C.byref(self.app), 1 if inverse else 0, buf, 1024)
+        names = [x for x in buf.value.decode().split(",") if x]
+        dom = max(set(names), key=names.count) if names else "?"
+        return int(n), dom
 
     def append(self, inverse, buffer_ptr=None, input_ptr=None, output_ptr=None):
         lp = VkFFTLaunchParams()

@@ -77,6 +77,28 @@ VKFFT_API void vkfftMI355XStructSizes(pfUINT out[4]) {
 	out[3] = sizeof(VkFFTApplication);
 }
 
+VKFFT_API int vkfftMI355XDescribePlan(const VkFFTApplication* app, int inverse, char* names, pfUINT cap) {
+	static const char* kname[] = {"generic_pass_kernel", "pow2_row_kernel", "pow2_col_kernel", "r2c_even_pair_kernel", "?", "mixed_row_kernel", "opfft_kernel", "pow2_blue_kernel",
+	                              "pow2_col_blue_kernel", "pow2_blue_r2r_kernel", "pow2_fused_kernel"};
+	if (names && cap) names[0] = 0;
+	if (!app) return 0;
+	const VkFFTPlan* pl = inverse == 1 ? app->localFFTPlan_inverse : app->localFFTPlan;
+	if (!pl || !pl->impl) return 0;
+	const DirectionPlan* dp = (const DirectionPlan*)pl->impl;
+	size_t pos = 0;
+	int launches = 0;
+	for (const PassPlan& q : dp->passes) {
+		uint64_t rep = 1;
+		for (const HostDim& h : q.hostLoop) rep *= h.count;
+		launches += (int)rep;
+		if (!names || !cap) continue;
+		const char* nm = kname[q.kernel >= 0 && q.kernel < 11 ? q.kernel : 4];
+		int w = snprintf(names + pos, pos < cap ? (size_t)cap - pos : 0, "%s%s<%s>", pos ? "," : "", nm, q.dp ? "double" : "float");
+		if (w > 0) pos = std::min<size_t>(pos + (size_t)w, (size_t)cap - 1);
+	}
+	return launches;
+}
+
 VKFFT_API void deleteVkFFT(VkFFTApplication* app) {
 	if (!app) return;
 	AppState* st = (AppState*)app->impl;

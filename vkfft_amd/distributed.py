@@ -3,12 +3,20 @@
 One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
   * batch sharding  — embarrassingly parallel: every rank plans and runs its own contiguous block of the batch,
                       no collective on the data path (SURVEY.md §8e row 1);
-  * slab 3D C2C     — z-slabs: local 2D transforms over (x,y), ONE all-to-all that re-partitions z<->y, local 1D
+  * slab 3D C2C     — z-slabs: local transforms along y and x, ONE all-to-all that re-partitions z<->y, local 1D
                       transforms along z.  The result is left in y-slab layout
                       [nz][ny/P][nx] (no second exchange); `inverse()` takes that layout back to z-slabs.
-The local transforms always go through the C-ABI (`lib` = the HIP library, or the CPU test double in tests)."""
-import numpy as np
 
+Slab exchange without pack/unpack passes.  Rank r must receive, from every rank s, the block
+[z in slab s][y in block r][x].  The library's own strided output does the packing: the y transform runs in place on the
+natural [z][y][x] slab, then the x transform (unit-stride rows) is planned as a 4-D problem (nx, ny/P, P, planes) of which
+only axis 0 is transformed, reading the natural layout and WRITING rows straight into the send layout
+[y-block][z][y in block][x] (VkFFTConfiguration::isInputFormatted + bufferStride, vkFFT_Structs.h:93-379), so every
+message is one contiguous run and what arrives is already the [nz][ny/P][nx] volume of the z transform.  The planes are
+processed in groups: while group g is on the wire (point-to-point sends of the group's P-1 runs, one RCCL group call), the
+transforms of group g+1 run on the compute stream.  The inverse mirrors it (contiguous sends of the z-blocks, the x
+transform gathers rows from the receive layout back into the natural slab).
+The local transforms always go through the C-ABI (`lib` = the HIP library, or the CPU test double in tests)."""
 from . import api
 
 
@@ -19,13 +27,21 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _check_device(device_index):
+    """the library allocates its tables and scratch on the CURRENT HIP device: it must be the one the plan is made for"""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.current_device() != device_index:
+        raise RuntimeError(f"current device {torch.cuda.current_device()} != plan device {device_index}: call torch.cuda.set_device first")
+
+
 class BatchShardedFFT:
     """Batched nD transform whose batch axis is split across the ranks of `group`; each rank holds only its shard."""
 
-    def __init__(self, shape, total_batch, rank, world, *, dp=False, device_index=0, lib=None, **kw):
+    def __init__(self, shape, total_batch, rank, world, *, dp=False, device_index=0, lib=None, stream=None, **kw):
+        _check_device(device_index)
         self.lo, self.hi = shard_range(total_batch, rank, world)
         self.local_batch = self.hi - self.lo
-        self.app = api.App(list(shape), max(self.local_batch, 1), dp=dp, device_index=device_index, lib=lib, **kw) if self.local_batch else None
+        self.app = api.App(list(shape), max(self.local_batch, 1), dp=dp, device_index=device_index, lib=lib, stream=stream, **kw) if self.local_batch else None
 
     def forward(self, ptr):
         if self.app:
@@ -40,84 +56,129 @@ class BatchShardedFFT:
             self.app.delete()
 
 
-def _ptr(t):
-    return t.data_ptr()
-
-
 class SlabFFT3D:
-    """3D C2C of an (nx, ny, nz) volume distributed as z-slabs over `world` ranks (nz % world == 0, ny % world == 0).
+    """3D C2C of an (nx, ny, nz) volume distributed as z-slabs over the ranks of `group` (nz and ny divisible by their number).
 
-    forward(x): x = local z-slab, torch complex tensor [nz/P, ny, nx] (contiguous)  ->  y-slab [nz, ny/P, nx]
-    inverse(y): y-slab -> z-slab (unnormalised unless normalize=True)."""
+    forward(x): x = local z-slab, torch complex tensor [nz/P, ny, nx] (contiguous; overwritten)  ->  y-slab [nz, ny/P, nx]
+    inverse(y): y-slab (overwritten) -> z-slab; unnormalised unless normalize=True.
+    `groups`: number of plane groups the exchange is pipelined over (must divide nz/P)."""
 
-    def __init__(self, nx, ny, nz, group=None, *, dp=False, device_index=0, lib=None, normalize=False):
+    def __init__(self, nx, ny, nz, group=None, *, dp=False, device_index=0, lib=None, normalize=False, groups=None):
+        import torch
         import torch.distributed as dist
-        self.dist = dist
-        self.group = group
+        self.torch, self.dist, self.group = torch, dist, group
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        assert nz % self.P == 0 and ny % self.P == 0, "slab decomposition needs nz and ny divisible by the number of ranks"
+        P = self.P
+        assert nz % P == 0 and ny % P == 0, "slab decomposition needs nz and ny divisible by the number of ranks"
         self.nx, self.ny, self.nz = nx, ny, nz
-        self.nzl, self.nyl = nz // self.P, ny // self.P
-        self.dp = dp
-        # (x,y) sweep: nzl independent 2D transforms
-        self.xy = api.App([nx, ny], self.nzl, dp=dp, device_index=device_index, lib=lib)
-        # z sweep: 1D transforms along the slowest axis of [nz][nyl][nx], unit-stride axes omitted
-        self.z = api.App([nx, self.nyl, nz], 1, dp=dp, device_index=device_index, lib=lib, omitDimension=[1, 1, 0, 0], normalize=int(normalize))
-        self.normalize = normalize
+        self.nzl, self.nyl = nz // P, ny // P
+        nzl, nyl = self.nzl, self.nyl
+        if groups is None:
+            groups = 1
+            while groups < 8 and nzl % (2 * groups) == 0 and (nzl // (2 * groups)) * nyl * nx >= (1 << 16):
+                groups *= 2  # messages of at least 2^16 points
+        assert nzl % groups == 0
+        self.G, self.zg = groups, nzl // groups
+        self.dp, self.normalize = dp, normalize
+        self.cuda = torch.cuda.is_available() and not getattr(lib, "_vkfft_test_double", False)  # the CPU test double works on host tensors
+        self.compute = None
+        stream = None
+        if self.cuda:
+            _check_device(device_index)
+            self.compute = torch.cuda.Stream()
+            stream = self.compute.cuda_stream
+        zg = self.zg
+        # y transform of a group of planes, in place on the natural slab: 2-D plan (nx, ny) with axis 0 omitted
+        self.fy = api.App([nx, ny], zg, dp=dp, device_index=device_index, lib=lib, stream=stream, omitDimension=[1, 0, 0, 0])
+        # x transform of a group of planes: rows of the natural slab (input side) <-> rows of the exchange layout (buffer side)
+        #   point (x, yl, yb, z):  natural  x + nx*(yl + nyl*yb) + nx*ny*z      exchange  x + nx*yl + nx*nyl*z + nx*nyl*nzl*yb
+        self.fx = api.App([nx, nyl, P, zg], 1, dp=dp, device_index=device_index, lib=lib, stream=stream, omitDimension=[0, 1, 1, 1],
+                          isInputFormatted=1, inverseReturnToInputBuffer=1,
+                          inputBufferStride=[nx, nx * nyl, nx * ny, nx * ny * zg],
+                          bufferStride=[nx, nx * nyl * nzl, nx * nyl, nx * nyl * nzl * P])
+        # z transform: 1-D along the slowest axis of [nz][nyl][nx]
+        self.fz = api.App([nx, nyl, nz], 1, dp=dp, device_index=device_index, lib=lib, stream=stream, omitDimension=[1, 1, 0, 0], normalize=int(normalize))
+        self.es = 16 if dp else 8
 
-    def _all_to_all(self, send):
-        """send: [P, ...] chunks (chunk r goes to rank r); returns [P, ...] (chunk s came from rank s)."""
-        import torch
+    # ---- exchange of one plane group: P-1 contiguous runs each way, one grouped point-to-point call ----
+    def _exchange(self, send, recv, g):
+        """send / recv: [P, nzl, nyl, nx]; moves planes [g*zg, (g+1)*zg) of every chunk: send[r] -> rank r's recv[me]"""
+        dist, torch = self.dist, self.torch
+        lo, hi = g * self.zg, (g + 1) * self.zg
+        recv[self.rank, lo:hi].copy_(send[self.rank, lo:hi])
         if self.P == 1:
-            return send
-        recv = torch.empty_like(send)
-        real_s, real_r = torch.view_as_real(send), torch.view_as_real(recv)  # collectives on the underlying real storage
-        try:
-            self.dist.all_to_all_single(real_r, real_s, group=self.group)
-        except Exception:
-            ops = []
-            for r in range(self.P):
-                ops.append(self.dist.P2POp(self.dist.isend, real_s[r], r, self.group))
-                ops.append(self.dist.P2POp(self.dist.irecv, real_r[r], r, self.group))
-            for w in self.dist.batch_isend_irecv(ops):
-                w.wait()
-        return recv
+            return []
+        ops = []
+        for d in range(1, self.P):
+            to, frm = (self.rank + d) % self.P, (self.rank - d) % self.P
+            ops.append(dist.P2POp(dist.isend, torch.view_as_real(send[to, lo:hi]), to, self.group))
+            ops.append(dist.P2POp(dist.irecv, torch.view_as_real(recv[frm, lo:hi]), frm, self.group))
+        return dist.batch_isend_irecv(ops)
 
     def forward(self, x):
-        import torch
-        P, nzl, nyl, nx = self.P, self.nzl, self.nyl, self.nx
-        assert tuple(x.shape) == (nzl, self.ny, nx) and x.is_contiguous()
-        self.xy.forward(buffer_ptr=_ptr(x))
-        _sync(x)
-        # chunk r = y-range of rank r: [nzl, P, nyl, nx] -> [P, nzl, nyl, nx]
-        send = x.view(nzl, P, nyl, nx).permute(1, 0, 2, 3).contiguous()
-        recv = self._all_to_all(send)  # [P(src = z-block), nzl, nyl, nx] == [nz, nyl, nx]
+        torch = self.torch
+        P, nzl, nyl, nx, ny, zg = self.P, self.nzl, self.nyl, self.nx, self.ny, self.zg
+        assert tuple(x.shape) == (nzl, ny, nx) and x.is_contiguous()
+        send = torch.empty((P, nzl, nyl, nx), dtype=x.dtype, device=x.device)
+        recv = torch.empty((P, nzl, nyl, nx), dtype=x.dtype, device=x.device)
+        caller = torch.cuda.current_stream() if self.cuda else None
+        if self.cuda:
+            self.compute.wait_stream(caller)  # x, send and recv are ready for the compute stream
+        pending = []
+        for g in range(self.G):
+            off_nat = g * zg * ny * nx * self.es
+            off_ex = g * zg * nyl * nx * self.es
+            self.fy.forward(buffer_ptr=x.data_ptr() + off_nat)
+            self.fx.forward(buffer_ptr=send.data_ptr() + off_ex, input_ptr=x.data_ptr() + off_nat)
+            if self.cuda:
+                ev = torch.cuda.Event(); ev.record(self.compute)
+                caller.wait_event(ev)  # the group's sends are enqueued behind its transforms; the next group's transforms overlap them
+            pending += self._exchange(send, recv, g)
+        for w in pending:
+            w.wait()
         y = recv.view(self.nz, nyl, nx)
-        self.z.forward(buffer_ptr=_ptr(y))
-        _sync(y)
+        if self.cuda:
+            self.compute.wait_stream(caller)
+        self.fz.forward(buffer_ptr=y.data_ptr())
+        if self.cuda:
+            caller.wait_stream(self.compute)
+            y.record_stream(self.compute); send.record_stream(self.compute); x.record_stream(self.compute)
         return y
 
     def inverse(self, y):
-        import torch
-        P, nzl, nyl, nx = self.P, self.nzl, self.nyl, self.nx
+        torch = self.torch
+        P, nzl, nyl, nx, ny, zg = self.P, self.nzl, self.nyl, self.nx, self.ny, self.zg
         assert tuple(y.shape) == (self.nz, nyl, nx) and y.is_contiguous()
-        self.z.inverse(buffer_ptr=_ptr(y))
-        _sync(y)
-        send = y.view(P, nzl, nyl, nx)  # chunk r = z-block of rank r
-        recv = self._all_to_all(send.contiguous())  # [P(src = y-block), nzl, nyl, nx]
-        x = recv.permute(1, 0, 2, 3).contiguous().view(nzl, self.ny, nx)
-        self.xy.inverse(buffer_ptr=_ptr(x))
-        _sync(x)
+        caller = torch.cuda.current_stream() if self.cuda else None
+        x = torch.empty((nzl, ny, nx), dtype=y.dtype, device=y.device)
+        recv = torch.empty((P, nzl, nyl, nx), dtype=y.dtype, device=y.device)
+        if self.cuda:
+            self.compute.wait_stream(caller)
+        self.fz.inverse(buffer_ptr=y.data_ptr())
+        if self.cuda:
+            caller.wait_stream(self.compute)
+        send = y.view(P, nzl, nyl, nx)  # chunk r = the z-block of rank r: already contiguous
+        works = [self._exchange(send, recv, g) for g in range(self.G)]
+        for g in range(self.G):
+            for w in works[g]:
+                w.wait()
+            if self.cuda:
+                self.compute.wait_stream(caller)  # group g has arrived (its local copy and receives are on the caller's stream)
+            off_nat = g * zg * ny * nx * self.es
+            off_ex = g * zg * nyl * nx * self.es
+            self.fx.inverse(buffer_ptr=recv.data_ptr() + off_ex, input_ptr=x.data_ptr() + off_nat)
+            self.fy.inverse(buffer_ptr=x.data_ptr() + off_nat)
+        if self.cuda:
+            caller.wait_stream(self.compute)
+            x.record_stream(self.compute); recv.record_stream(self.compute); y.record_stream(self.compute)
         if self.normalize:
             x /= (self.nx * self.ny)
         return x
 
+    def exchange_bytes_per_rank(self):
+        """bytes this rank puts on the wire per exchange (everything but its own chunk)"""
+        return (self.P - 1) * self.nzl * self.nyl * self.nx * self.es
+
     def delete(self):
-        self.xy.delete(); self.z.delete()
-
-
-def _sync(t):
-    if t.is_cuda:
-        import torch
-        torch.cuda.current_stream().synchronize()
+        self.fy.delete(); self.fx.delete(); self.fz.delete()
