@@ -63,6 +63,12 @@ __device__ inline void pow2_fs_twiddle(cx<T>* v, const GBuf gtab, const uint32_t
 	for (int m = 0; m < E; m++) v[m] = cmul(v[m], (m & ((1 << LOB) - 1)) ? cmul(A[m >> LOB], B[m & ((1 << LOB) - 1)]) : A[m >> LOB]);
 }
 
+template <typename T, typename SCH, int TPF, int TCP, int TWL>
+__device__ inline void fused_stages(cx<T>* v, cx<T>* ldsf, const cx<T>* twLds, const void* twGlobal, uint32_t oz, uint32_t tau) {
+	if constexpr (TWL) pow2_stages<T, SCH, 0, TPF, TCP, TwLds<T>>(v, ldsf, TwLds<T>{twLds}, tau, false);
+	else pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, ldsf, TwGlobal<T>{make_gbuf((const char*)twGlobal + oz)}, tau, false);
+}
+
 __device__ inline void fused_wait(uint32_t* ctr, uint32_t target) {
 	if (threadIdx.x == 0) {
 		while (VKFFT_ATOMIC_LOAD_U32(ctr) < target) VKFFT_SLEEP();
@@ -71,9 +77,9 @@ __device__ inline void fused_wait(uint32_t* ctr, uint32_t target) {
 }
 
 // workgroups of a fused kernel that fit one CU (LDS and wave slots), at most 4: fixes the register budget through __launch_bounds__
-template <typename T, typename SA, int TCA, typename SB, int TCB> constexpr int pow2_fused_wg_per_cu() {
+template <typename T, typename SA, int TCA, typename SB, int TCB, int TWL> constexpr int pow2_fused_wg_per_cu() {
 	constexpr int la = (1 << SA::LOGN) * (TCA + 1), lb = (1 << SB::LOGN) * (TCB + 1);
-	constexpr int ldsBytes = ((la > lb ? la : lb) + SA::lutTotal() + SB::lutTotal()) * (int)sizeof(cx<T>) + 64;
+	constexpr int ldsBytes = ((la > lb ? la : lb) + (TWL ? SA::lutTotal() + SB::lutTotal() : 0)) * (int)sizeof(cx<T>) + 64;
 	constexpr int nt = ((1 << SA::LOGN) >> SA::LOGE) * TCA;
 	int w = 163840 / ldsBytes;
 	if (w > 2048 / nt) w = 2048 / nt;
@@ -99,8 +105,9 @@ __device__ inline uint32_t fused_xcc_id() {
 }
 
 // MODE bit 1: non-temporal hint on the HBM side
-template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE>
-__global__ void __launch_bounds__(((1 << SA::LOGN) >> SA::LOGE) * TCA, (pow2_fused_wg_per_cu<T, SA, TCA, SB, TCB>() * (((1 << SA::LOGN) >> SA::LOGE) * TCA)) / 256)
+// TWL: stage twiddles staged in LDS (1) or read through the buffer path from L2 (0: where the LDS copy would cost a workgroup per CU)
+template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE, int TWL>
+__global__ void __launch_bounds__(((1 << SA::LOGN) >> SA::LOGE) * TCA, (pow2_fused_wg_per_cu<T, SA, TCA, SB, TCB, TWL>() * (((1 << SA::LOGN) >> SA::LOGE) * TCA)) / 256)
 pow2_fused_kernel(const FusedParams p) {
 	constexpr int LA = 1 << SA::LOGN, EA = 1 << SA::LOGE, TPFA = LA / EA, TCPA = TCA + 1;
 	constexpr int LB = 1 << SB::LOGN, EB = 1 << SB::LOGE, TPFB = LB / EB, TCPB = TCB + 1;
@@ -112,7 +119,7 @@ pow2_fused_kernel(const FusedParams p) {
 	constexpr int AUX_ST = 16;                   // ring stores: write-through (no XCD's L2 ever holds a ring line)
 	constexpr int AUX_HBM = (MODE & 2) ? 2 : 0;
 	constexpr int LDSN = LA * TCPA > LB * TCPB ? LA * TCPA : LB * TCPB;
-	constexpr int LUTA = SA::lutTotal(), LUTB = SB::lutTotal();
+	constexpr int LUTA = TWL ? SA::lutTotal() : 0, LUTB = TWL ? SB::lutTotal() : 0;
 	__shared__ cx<T> lds[LDSN + LUTA + LUTB];
 	__shared__ uint32_t sTicket[2], sOkA[2], sOkB[2];
 	const uint32_t tid = threadIdx.x;
@@ -222,7 +229,7 @@ pow2_fused_kernel(const FusedParams p) {
 #pragma unroll
 						for (int m = 0; m < EA; m++) v[m] = cswap(v[m]);
 					}
-					if constexpr ((MODE & 8) == 0) pow2_stages<T, SA, 0, TPFA, TCPA, TwLds<T>>(v, lds + c, TwLds<T>{twA}, tau, false);
+					if constexpr ((MODE & 8) == 0) fused_stages<T, SA, TPFA, TCPA, TWL>(v, lds + c, twA, p.lutA, oz, tau);
 					VKFFT_PROF(8);
 					if constexpr ((MODE & 8) == 0) pow2_fs_twiddle<T, SA::LOGE, TPFA>(v, gtw, p.fsLoBits, tau, col0 + c);
 					VKFFT_PROF(9);
@@ -269,7 +276,7 @@ pow2_fused_kernel(const FusedParams p) {
 				fused_publish<MODE>(p.ctr, pending, flushing);
 			}
 			if (liveB) {
-				if constexpr ((MODE & 8) == 0) pow2_stages<T, SB, 0, TPFB, TCPB, TwLds<T>>(vB, lds + cBl, TwLds<T>{twB}, tauB, false);
+				if constexpr ((MODE & 8) == 0) fused_stages<T, SB, TPFB, TCPB, TWL>(vB, lds + cBl, twB, p.lutB, oz, tauB);
 				if (p.swapOut) {
 #pragma unroll
 					for (int m = 0; m < EB; m++) vB[m] = cswap(vB[m]);
@@ -312,9 +319,9 @@ struct Pow2FusedVariant {
 	const void* fn;
 };
 
-template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE> void pow2_fused_launch(const FusedParams& prm, dim3 grid, hipStream_t s) {
+template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE, int TWL> void pow2_fused_launch(const FusedParams& prm, dim3 grid, hipStream_t s) {
 	constexpr int threads = ((1 << SA::LOGN) >> SA::LOGE) * TCA;
-	hipLaunchKernelGGL((pow2_fused_kernel<T, SA, TCA, SB, TCB, MODE>), grid, dim3(threads), 0, s, prm);
+	hipLaunchKernelGGL((pow2_fused_kernel<T, SA, TCA, SB, TCB, MODE, TWL>), grid, dim3(threads), 0, s, prm);
 }
 
 } // namespace vkfft_mi355x

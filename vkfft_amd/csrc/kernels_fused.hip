@@ -7,19 +7,20 @@
 
 namespace vkfft_mi355x {
 
-#define VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, mode) \
+#define VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, mode, twl) \
 	{ (a0) + (a1) + (a2) + (b0) + (b1) + (b2), dp, mode, (a0) + (a1) + (a2), (b0) + (b1) + (b2), {a0, a1, a2, 0}, {b0, b1, b2, 0}, tca, tcb, \
-	  ((1 << ((a0) + (a1) + (a2))) >> Pow2Sched<a0, a1, a2, 0>::LOGE) * (tca), pow2_fused_wg_per_cu<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb>(), \
-	  &pow2_fused_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode>, \
-	  (const void*)&pow2_fused_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode> }
+	  ((1 << ((a0) + (a1) + (a2))) >> Pow2Sched<a0, a1, a2, 0>::LOGE) * (tca), pow2_fused_wg_per_cu<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, twl>(), \
+	  &pow2_fused_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl>, \
+	  (const void*)&pow2_fused_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl> }
 // mode 2 = product (non-temporal hint on the streamed side); the others exist only in development builds (-DVKFFT_MI355X_DEV):
 // 0 = no hint, 6 = per-phase cycle profile, 8 / 16 / 24 = without the FFT arithmetic / without the ring traffic / without both
 #if defined(VKFFT_MI355X_DEV)
-#define VKFFT_FU(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) \
-	VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 0), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 8), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 16), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 24)
+#define VKFFT_FUT(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl) \
+	VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 0, twl), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, twl), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 8, twl), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 16, twl), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 24, twl)
 #else
-#define VKFFT_FU(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2)
+#define VKFFT_FUT(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl) VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl)
 #endif
+#define VKFFT_FU(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUT(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1)
 
 // first entry of each (log2 N, dp, mode) is the default; VKFFT_MI355X_FUV<log2n>=k selects the k-th shape (tuning)
 static const Pow2FusedVariant kPow2FusedVariants[] = {
@@ -31,7 +32,8 @@ static const Pow2FusedVariant kPow2FusedVariants[] = {
 	VKFFT_FU(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
 	// 2^18 = 512 x 512 (32 points per thread, 256 threads, two workgroups per CU: 3.1 TB/s; 16 points per thread: 2.4)
 	VKFFT_FU(float, false, 5, 4, 0, 16, 5, 4, 0, 16),
-	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: one workgroup per CU (the 1024-point column tile needs 139 KiB of LDS)
+	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: one workgroup per CU (the 1024-point column tile needs 139 KiB of LDS); 8-column tiles
+	// (two workgroups per CU, 64-byte segments on the HBM side) measured 12 % slower
 	VKFFT_FU(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
 	VKFFT_FU(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
 };
