@@ -391,6 +391,38 @@ def test_stream_and_launch_params(product_lib):
     app.delete()
 
 
+def test_several_caller_streams(product_lib, oracle):
+    """num_streams = 3: passes the host splits into independent sub-launches (here: a 4-D transform with padded strides, whose outer
+    dimensions do not collapse) are dealt round-robin over the streams and joined back into stream 0 (vkFFT_DispatchPlan.h:288-295);
+    the result must equal the one-stream result bit for bit and synchronising stream 0 must be enough."""
+    import torch
+    shape, B = (8, 6, 5, 4), 3
+    pitch = [10, 10 * 7, 10 * 7 * 6, 10 * 7 * 6 * 5]  # padded: nothing collapses
+    n = pitch[3] * B
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    x = torch.empty(2 * n, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    outs = []
+    for ns in (1, 3):
+        ss = [torch.cuda.Stream() for _ in range(ns)]
+        buf = x.clone()
+        torch.cuda.synchronize()
+        app = api.App(list(shape), B, buffer_ptr=buf.data_ptr(), streams=[s.cuda_stream for s in ss], bufferStride=pitch, lib=product_lib)
+        for _ in range(3):
+            app.forward(); app.inverse()
+        app.forward()
+        ss[0].synchronize()
+        outs.append(buf.clone())
+        app.delete()
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0].cpu().numpy().view(np.complex64).reshape(B, 5, 6, 7, 10)[:, :4, :5, :6, :8]
+    ref = x.cpu().numpy().view(np.complex64).reshape(B, 5, 6, 7, 10)[:, :4, :5, :6, :8].astype(np.complex128)
+    want = np.fft.fftn(ref, axes=(1, 2, 3, 4))
+    for _ in range(3):
+        want = np.fft.fftn(np.fft.ifftn(want, axes=(1, 2, 3, 4)) , axes=(1, 2, 3, 4))
+    scale = float(8 * 6 * 5 * 4) ** 3  # three unnormalised round trips
+    assert rel_l2(got, want * scale) < 4e-6
+
+
 def test_out_of_place_and_offsets(product_lib):
     import torch
     N, B = 100, 7
@@ -403,6 +435,154 @@ def test_out_of_place_and_offsets(product_lib):
     assert rel_l2(out, np.fft.fft(x.astype(np.complex128).reshape(B, N), axis=1)) < 1e-6
     assert np.array_equal(src.cpu().numpy().view(np.complex64), x)
     app.delete()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_padded_strides_out_of_place_formatted_output_on_device(product_lib, seed):
+    """(f3) on the GPU: random 1-D..3-D C2C plans on padded bufferStride, with isInputFormatted (separate source, source untouched),
+    isOutputFormatted (separate destination) and inverseReturnToInputBuffer, both precisions — the device twin of
+    tests/test_emu_fuzz.py::test_random_padded_strides_and_out_of_place."""
+    import random, torch
+    rnd = random.Random(4000 + seed)
+
+    def smooth(maxn):
+        while True:
+            n = 1
+            for p, emax in ((2, 12), (3, 5), (5, 4), (7, 3), (11, 2), (13, 2)):
+                n *= p ** rnd.randint(0, emax)
+            if 2 <= n <= maxn:
+                return n
+    for it in range(20):
+        dp = rnd.random() < 0.3
+        ct = np.complex128 if dp else np.complex64
+        nd = rnd.choice([1, 1, 2, 3])
+        shape = [rnd.choice([smooth(70000 if nd == 1 else 300), rnd.randint(2, 500 if nd == 1 else 60)]) for _ in range(nd)]
+        B = rnd.randint(1, 4)
+        pitches, acc = [], 1
+        for sz in shape:
+            acc = acc * sz + rnd.choice([0, 0, 1, 3, 8])
+            pitches.append(acc)
+        total = pitches[-1] * B
+        rng = np.random.default_rng(seed * 100 + it)
+        host = (rng.uniform(-1, 1, total) + 1j * rng.uniform(-1, 1, total)).astype(ct)
+        strides = [pitches[-1]] + [pitches[i - 1] if i > 0 else 1 for i in range(nd - 1, -1, -1)]
+        idx = np.indices([B] + shape[::-1]).reshape(nd + 1, -1)
+        off = sum(idx[d] * strides[d] for d in range(nd + 1))
+        view = lambda a: a[off].reshape([B] + shape[::-1]).astype(np.complex128)
+        truth = np.fft.fftn(view(host), axes=tuple(range(1, nd + 1)))
+        tol = 3e-14 if dp else 5e-6
+        dev = lambda a: torch.from_numpy(a.view(np.float64 if dp else np.float32).copy()).cuda()
+        back = lambda t: t.cpu().numpy().view(ct)
+        pad = pitches + [0] * (4 - nd)
+        mode = rnd.choice(["inplace", "in", "out", "in+return"])
+        try:
+            if mode == "inplace":
+                buf = dev(host)
+                app = api.App(shape, B, dp=dp, buffer_ptr=buf.data_ptr(), bufferStride=pad, lib=product_lib)
+                app.forward(); torch.cuda.synchronize()
+                assert rel_l2(view(back(buf)), truth) < tol, (mode, shape, B, dp, pitches)
+            elif mode == "in":
+                src, dst = dev(host), dev(np.zeros(total, ct))
+                app = api.App(shape, B, dp=dp, buffer_ptr=dst.data_ptr(), isInputFormatted=1, inputBuffer=src.data_ptr(), inputBufferStride=pad, bufferStride=pad, lib=product_lib)
+                app.forward(); torch.cuda.synchronize()
+                assert rel_l2(view(back(dst)), truth) < tol, (mode, shape, B, dp, pitches)
+                assert np.array_equal(back(src), host)
+            elif mode == "out":
+                buf, dst = dev(host), dev(np.zeros(total, ct))
+                app = api.App(shape, B, dp=dp, buffer_ptr=buf.data_ptr(), isOutputFormatted=1, outputBuffer=dst.data_ptr(), outputBufferStride=pad, bufferStride=pad, lib=product_lib)
+                app.forward(); torch.cuda.synchronize()
+                assert rel_l2(view(back(dst)), truth) < tol, (mode, shape, B, dp, pitches)
+            else:
+                src, dst = dev(host), dev(np.zeros(total, ct))
+                app = api.App(shape, B, dp=dp, buffer_ptr=dst.data_ptr(), isInputFormatted=1, inverseReturnToInputBuffer=1, inputBuffer=src.data_ptr(), inputBufferStride=pad,
+                              bufferStride=pad, lib=product_lib)
+                app.forward(); torch.cuda.synchronize()
+                assert rel_l2(view(back(dst)), truth) < tol, (mode, shape, B, dp, pitches)
+                app.inverse(); torch.cuda.synchronize()  # inverse: buffer (scratch for all but the last axis) -> inputBuffer
+                n = float(np.prod(shape))
+                assert rel_l2(view(back(src)), view(host) * n) < 2 * tol, (mode, shape, B, dp, pitches)
+        except api.VkFFTError as e:
+            assert e.code in (3002, 3003, 3004, 3005), e
+            continue
+        app.delete()
+
+
+def test_r2c_2d_offsets_at_launch(product_lib):
+    """the launch-parameter pattern of the reference's sample 15 (sample_15_precision_VkFFT_single_r2c.cpp:238-240, 346-351): one R2C 2-D
+    plan with specifyOffsetsAtLaunch, run on two different sub-buffers of one allocation by passing byte... element offsets at VkFFTAppend"""
+    import torch
+    nx, ny = 96, 40
+    rowc = nx // 2 + 1
+    per = 2 * rowc * ny  # reals per padded in-place image
+    rng = np.random.default_rng(7)
+    imgs = rng.uniform(-1, 1, (2, ny, nx)).astype(np.float32)
+    host = np.zeros(3 * per, np.float32)
+    for i, base in enumerate((0, 2 * per)):  # image 0 at the start, image 1 in the third slot
+        host[base:base + per].reshape(ny, 2 * rowc)[:, :nx] = imgs[i]
+    buf = torch.from_numpy(host.copy()).cuda()
+    app = api.App([nx, ny], 1, r2c=True, buffer_ptr=buf.data_ptr(), specifyOffsetsAtLaunch=1, lib=product_lib)
+    lp = api.VkFFTLaunchParams()
+    for base in (0, 2 * per):
+        lp.bufferOffset = base * 4  # bytes (vkFFT_Structs.h: offsets are in bytes)
+        r = product_lib.VkFFTAppend(C.byref(app.app), -1, C.byref(lp))
+        assert r == 0
+    torch.cuda.synchronize()
+    out = buf.cpu().numpy()
+    for i, base in enumerate((0, 2 * per)):
+        got = out[base:base + per].view(np.complex64).reshape(ny, rowc)
+        assert rel_l2(got, np.fft.rfft2(imgs[i].astype(np.float64))) < 2e-6
+    assert np.array_equal(out[per:2 * per], host[per:2 * per])  # the slot in between is untouched
+    app.delete()
+
+
+def test_fp64_three_pass_and_512cubed_random_lines(product_lib, oracle):
+    """fp64 on a three-pass plan (2^21), and the 512^3 volume of BASELINE config 4 checked on random (ky,kz) lines and random points against
+    direct evaluations of the 3-D sum in double precision"""
+    import torch
+    N = 1 << 21
+    x = parity.seeded_complex(N * 2, True, 5)
+    t = torch.from_numpy(x.view(np.float64).copy()).cuda()
+    app = api.App([N], 2, dp=True, buffer_ptr=t.data_ptr(), lib=product_lib)
+    assert app.uploads() == [3]
+    app.forward(); torch.cuda.synchronize()
+    y = t.cpu().numpy().view(np.complex128)
+    assert rel_l2(y, oracle.truth_c2c(x, (N,), 2, longdouble=True)) < 4e-15
+    app.inverse(); torch.cuda.synchronize(); app.delete()
+    assert rel_l2(t.cpu().numpy().view(np.complex128), x * N) < 6e-15
+    n = 512
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    v = torch.empty(2 * n ** 3, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    buf = v.clone()
+    app = api.App([n, n, n], 1, buffer_ptr=buf.data_ptr(), lib=product_lib)
+    app.forward(); torch.cuda.synchronize(); app.delete()
+    X = torch.view_as_complex(buf.view(-1, 2)).view(n, n, n)          # [kz][ky][kx]
+    xc = torch.view_as_complex(v.view(-1, 2)).view(n, n, n).to(torch.complex128)
+    rng = np.random.default_rng(12)
+    w = lambda k: torch.exp(-2j * np.pi * k * torch.arange(n, device="cuda", dtype=torch.float64) / n)
+    for _ in range(6):
+        ky, kz = int(rng.integers(n)), int(rng.integers(n))
+        # line X[kz, ky, :] = FFT_x( sum_{z,y} x[z,y,:] w_z^{kz z} w_y^{ky y} )
+        plane = torch.einsum("zyx,z,y->x", xc, w(kz), w(ky))
+        line = torch.fft.fft(plane)
+        err = (torch.linalg.norm(X[kz, ky].to(torch.complex128) - line) / torch.linalg.norm(line)).item()
+        assert err < 2e-6, (ky, kz, err)
+
+
+@pytest.mark.timeout(600)
+def test_reference_sample0_caller_unchanged(product_lib, tmp_path):
+    """Drop-in proof: the reference's own sample-0 benchmark (sample_0_benchmark_VkFFT_single.cpp + utils_VkFFT.cpp), compiled UNCHANGED
+    against include/vkFFT.h and linked with libvkfft_mi355x.so (oracle/build_ref.sh, built where /root/reference exists), runs all its
+    sizes (2^3 .. 2^27, 1 GiB each) incl. its save/load-application round trip and ends with VKFFT_SUCCESS."""
+    import os, subprocess, re
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "dropin_sample0")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/dropin_sample0 not built (needs the reference sources at build time)")
+    r = subprocess.run([exe, "0"], cwd=tmp_path, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "dropin sample_0 result: 0" in r.stdout
+    rows = re.findall(r"VkFFT System: (\d+) .*?bandwidth: ([0-9.]+)", r.stdout)
+    assert len(rows) >= 25, r.stdout[-1500:]  # sizes 2^3 .. 2^27 (the 4096 warm-up configuration prints no row)
+    assert re.search(r"Benchmark score VkFFT: \d+", r.stdout)
 
 
 def test_cli_driver_on_device(product_lib):

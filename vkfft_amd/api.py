@@ -152,7 +152,7 @@ class App:
     """Plan object mirroring the reference call sequence: configure -> initializeVkFFT -> VkFFTAppend -> deleteVkFFT."""
 
     def __init__(self, size, batch=1, *, dp=False, r2c=False, dct=0, dst=0, normalize=False, device_index=0,
-                 buffer_ptr=0, stream=None, lib=None, **extra):
+                 buffer_ptr=0, stream=None, streams=None, lib=None, **extra):
         self.lib = lib if lib is not None else load()
         self.cfg = VkFFTConfiguration()
         self.app = VkFFTApplication()
@@ -171,7 +171,11 @@ class App:
         self._buf = C.c_void_p(buffer_ptr)
         self.cfg.buffer = C.pointer(self._buf)
         self._keep = []
-        if stream is not None:
+        if streams is not None:  # several caller streams (VkFFTConfiguration::stream / num_streams)
+            self._streams = (C.c_void_p * len(streams))(*streams)
+            self.cfg.stream = C.cast(self._streams, type(self.cfg.stream))
+            self.cfg.num_streams = len(streams)
+        elif stream is not None:
             self._stream = C.c_void_p(stream)
             self.cfg.stream = C.pointer(self._stream)
             self.cfg.num_streams = 1

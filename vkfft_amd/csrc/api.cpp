@@ -104,6 +104,7 @@ VKFFT_API void deleteVkFFT(VkFFTApplication* app) {
 	AppState* st = (AppState*)app->impl;
 	if (st) {
 		if (st->tempOwned) (void)hipFree(st->tempOwned);
+		if (app->saveApplicationString) free(app->saveApplicationString);
 		if (st->events) {
 			for (uint32_t i = 0; i < st->numEvents; i++) if (st->events[i]) (void)hipEventDestroy(st->events[i]);
 			free(st->events);
@@ -135,6 +136,7 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 		return VKFFT_ERROR_PLAN_NOT_INITIALIZED;
 	};
 	if (in.performConvolution || in.kernelConvolution || in.matrixConvolution) return unsupported("convolution");
+	if (in.bufferNum > 1 || in.inputBufferNum > 1 || in.outputBufferNum > 1 || in.tempBufferNum > 1 || in.kernelNum > 1) return unsupported("a buffer split over several allocations (bufferNum > 1)");
 	for (int i = 0; i < VKFFT_MAX_FFT_DIMENSIONS; i++) if (in.performZeropadding[i]) return unsupported("zero-padding");
 	if (in.halfPrecision || in.halfPrecisionMemoryOnly) return unsupported("half precision");
 	if (in.quadDoubleDoublePrecision || in.quadDoubleDoublePrecisionDoubleMemory) return unsupported("double-double precision");
@@ -143,6 +145,7 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 	if ((in.performDCT && in.performDST) || ((in.performDCT || in.performDST) && in.performR2C)) return VKFFT_ERROR_UNSUPPORTED_FFT_LENGTH_R2R;
 
 	c = in;
+	bool ldsCapped = false;
 	// ---- device ----------------------------------------------------------------------------------------
 	{
 		int v = 0;
@@ -158,7 +161,9 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 		(void)hipDeviceGetAttribute(&g[2], hipDeviceAttributeMaxGridDimZ, dev);
 		for (int i = 0; i < 3; i++) c.maxComputeWorkGroupCount[i] = (pfUINT)g[i];
 		if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_FAILED_TO_GET_ATTRIBUTE; }
-		c.sharedMemorySize = in.sharedMemorySize ? in.sharedMemorySize : (pfUINT)v;
+		// caller's cap on LDS per workgroup (a reference knob): clamped to what the device has and to a floor the planner's tiles need
+		c.sharedMemorySize = in.sharedMemorySize ? std::min<pfUINT>(std::max<pfUINT>(in.sharedMemorySize, 16384), (pfUINT)v) : (pfUINT)v;
+		ldsCapped = c.sharedMemorySize < (pfUINT)v;
 		c.sharedMemorySizeStatic = c.sharedMemorySize;
 		pfUINT p2 = 1; while (p2 * 2 <= c.sharedMemorySize) p2 *= 2;
 		c.sharedMemorySizePow2 = p2;
@@ -234,6 +239,7 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 	if (const char* e = getenv("VKFFT_MI355X_FUSED_QUEUES")) d.fusedQueues = (uint32_t)atoi(e);
 	if (const char* e = getenv("VKFFT_MI355X_FUSED_MARGIN")) d.fusedMarginPct = (uint32_t)atoi(e);
 	if (const char* e = getenv("VKFFT_MI355X_GENERIC_ONLY")) d.disableFastKernels = atoi(e) != 0;
+	if (ldsCapped) d.disableFastKernels = true; // the hand-specialised kernels have fixed LDS footprints (up to 155 KiB): under a cap the generic kernel, which sizes its tiles from maxLds, serves the plan
 
 	AppState* st = new (std::nothrow) AppState();
 	if (!st) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_MALLOC_FAILED; }
@@ -276,6 +282,17 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 		if (hipMalloc(&st->tempOwned, need) != hipSuccess) { deleteVkFFT(app); return VKFFT_ERROR_FAILED_TO_ALLOCATE; }
 		st->tempOwnedBytes = need;
 		c.allocateTempBuffer = 1;
+	}
+	// ---- saveApplicationToString: the reference serialises its run-time compiled kernels (vkFFT_InitializeApp.h:1468-1530) so that a later
+	// initializeVkFFT can skip hiprtc.  Nothing is compiled at run time here; callers that write the blob to a file and hand it back
+	// through loadApplicationString (sample_0_benchmark_VkFFT_single.cpp:169-199) get a small self-describing record.
+	if (c.saveApplicationToString) {
+		const size_t n = 64;
+		char* blob = (char*)calloc(1, n);
+		if (!blob) { deleteVkFFT(app); return VKFFT_ERROR_MALLOC_FAILED; }
+		snprintf(blob, n, "vkfft_mi355x ahead-of-time kernels, API %d", VkFFTGetVersion());
+		app->saveApplicationString = blob;
+		app->applicationStringSize = n;
 	}
 	// ---- multi-stream events ------------------------------------------------------------------------------
 	if (c.num_streams > 1 && c.stream) {
@@ -327,9 +344,13 @@ VKFFT_API VkFFTResult VkFFTAppend(VkFFTApplication* app, int inverse, VkFFTLaunc
 			lb.base[ROLE_TEMP] = (char*)c.tempBuffer[0] + c.tempBufferOffset;
 		} else lb.base[ROLE_TEMP] = st->tempOwned;
 	}
-	hipStream_t stream = 0;
-	if (c.stream && c.num_streams >= 1) stream = c.stream[0];
-	int r = execute_direction(*dp, lb, stream, st->sweepEnabled ? &st->sweep : nullptr);
+	StreamSet ss;
+	if (c.stream && c.num_streams >= 1) {
+		ss.n = (uint32_t)std::min<pfUINT>(c.num_streams, 8);
+		for (uint32_t i = 0; i < ss.n; i++) ss.s[i] = c.stream[i];
+		if (ss.n > 1) { for (uint32_t i = 0; i < ss.n; i++) ss.ev[i] = st->events[i]; }
+	}
+	int r = execute_direction(*dp, lb, ss, st->sweepEnabled ? &st->sweep : nullptr);
 	if (r) { fprintf(stderr, "vkfft_mi355x: kernel launch failed\n"); return (VkFFTResult)r; }
 	return VKFFT_SUCCESS;
 }

@@ -87,8 +87,16 @@ struct LaunchBuffers {
 	void* base[4] = {nullptr, nullptr, nullptr, nullptr}; // by BufRole
 };
 int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
+// The caller's streams (VkFFTConfiguration::stream / num_streams).  Everything is ordered on s[0]; a pass that the host has to split
+// into independent sub-launches deals them round-robin over all streams (reference: vkFFT_DispatchPlan.h:288-295 does the same with
+// the blocks of an oversized dispatch) and joins them back into s[0] through the events (stream-side waits, no host synchronisation).
+struct StreamSet {
+	uint32_t n = 1;
+	hipStream_t s[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
 // sweep: the application's zig-zag state: every launch walks the buffer opposite to the previous one; nullptr = always front to back
-int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream, uint32_t* sweep = nullptr);
+int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, const StreamSet& streams, uint32_t* sweep = nullptr);
 
 // fast-kernel registry queries used by the planner
 bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads);

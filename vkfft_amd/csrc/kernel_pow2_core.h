@@ -108,22 +108,16 @@ __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const TW lut, const ui
 	}
 }
 
-inline unsigned pow2_num_cus() {
-	static unsigned n = 0;
-	if (!n) {
+inline unsigned pow2_num_cus() { // CUs of the CURRENT device (plans are made and launched with their device current)
 #if defined(VKFFT_HOSTEMU)
-		n = 4;
+	return 4;
 #else
-		int dev = 0, v = 0;
-		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = (unsigned)v; else n = 256;
+	static unsigned cache[64] = {};
+	int dev = 0, v = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+	if (!cache[dev]) cache[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? (unsigned)v : 256u;
+	return cache[dev];
 #endif
-	}
-	return n;
-}
-inline unsigned pow2_persist_mult() { // tuning knob: resident-grid multiplier (1 = exactly resident)
-	static int m = 0;
-	if (!m) { const char* e = getenv("VKFFT_MI355X_PERSIST_MULT"); m = e ? atoi(e) : 1; if (m < 1) m = 1; }
-	return (unsigned)m;
 }
 
 struct Pow2Variant {

@@ -178,14 +178,14 @@ bool pow2_blue_lookup(uint32_t log2m, bool dp, int* variant, int bits[4], int* f
 	return pow2_lookup(kPow2BlueVariants, kNumPow2BlueVariants, "VKFFT_MI355X_P2B", log2m, dp, variant, bits, fpw, threads);
 }
 
-static int launch_with_hostloop(const PassPlan& pp, PassParams prm, hipStream_t stream, size_t level) {
-	if (level == pp.hostLoop.size()) return launch_pass(pp, prm, stream);
+static int launch_with_hostloop(const PassPlan& pp, PassParams prm, const StreamSet& ss, uint32_t& rr, size_t level) {
+	if (level == pp.hostLoop.size()) return launch_pass(pp, prm, ss.s[pp.hostLoop.empty() ? 0 : (rr++ % ss.n)]);
 	const HostDim& h = pp.hostLoop[level];
 	for (uint64_t i = 0; i < h.count; i++) {
 		PassParams q = prm;
 		q.in = (const char*)prm.in + (int64_t)i * h.inStride * pp.inElemBytes;
 		q.out = (char*)prm.out + (int64_t)i * h.outStride * pp.outElemBytes;
-		int r = launch_with_hostloop(pp, q, stream, level + 1);
+		int r = launch_with_hostloop(pp, q, ss, rr, level + 1);
 		if (r) return r;
 	}
 	return 0;
@@ -202,7 +202,8 @@ static void bind(const DirectionPlan& plan, const PassPlan& pp, const LaunchBuff
 	prm.rader = pp.raderOff != (size_t)-1 ? ar + pp.raderOff : nullptr;
 }
 
-int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipStream_t stream, uint32_t* sweep) {
+int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, const StreamSet& ss, uint32_t* sweep) {
+	hipStream_t stream = ss.s[0];
 	const int np = (int)plan.passes.size();
 	for (int i = 0; i < np; i++) {
 		const PassPlan& pp = plan.passes[i];
@@ -222,8 +223,20 @@ int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, hipS
 		PassParams prm = pp.prm;
 		bind(plan, pp, bufs, prm);
 		if (sweep) { prm.reverseTiles = *sweep & 1u; *sweep ^= 1u; } // zig-zag: opposite to the previous launch of this application
-		int r = launch_with_hostloop(pp, prm, stream, 0);
+		const bool fan = ss.n > 1 && !pp.hostLoop.empty(); // independent sub-launches: fan out over the caller's streams, join into s[0]
+		if (fan) {
+			if (hipEventRecord(ss.ev[0], ss.s[0]) != hipSuccess) return 4040;
+			for (uint32_t k = 1; k < ss.n; k++) if (hipStreamWaitEvent(ss.s[k], ss.ev[0], 0) != hipSuccess) return 4040;
+		}
+		uint32_t rr = 0;
+		int r = launch_with_hostloop(pp, prm, ss, rr, 0);
 		if (r) return r;
+		if (fan) {
+			for (uint32_t k = 1; k < ss.n; k++) {
+				if (hipEventRecord(ss.ev[k], ss.s[k]) != hipSuccess) return 4040;
+				if (hipStreamWaitEvent(ss.s[0], ss.ev[k], 0) != hipSuccess) return 4040;
+			}
+		}
 	}
 	return 0;
 }

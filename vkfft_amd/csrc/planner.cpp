@@ -384,7 +384,8 @@ static uint64_t max_row_len(bool dp, uint64_t maxLds) { // unit-stride, T = 1
 }
 static uint64_t max_col_len(bool dp, uint64_t maxLds, uint32_t T) {
 	uint64_t es = dp ? 16 : 8;
-	return maxLds / ((uint64_t)(T + 1) * 2 * es) - 2;
+	const uint64_t c = maxLds / ((uint64_t)(T + 1) * 2 * es);
+	return c > 2 ? c - 2 : 0;
 }
 
 static bool is_supported_len(uint64_t L, uint32_t directMax) {
@@ -815,6 +816,9 @@ static void make_bluestein_tables(uint64_t N, uint64_t M, bool dp, Arena& ar, si
 	}
 	for (uint64_t n = 0; n < N; n++) ar.putc(chirpOff, n, cChirp[n], dp);
 	for (uint64_t k = 0; k < M; k++) ar.putc(bhatOff, k, cBhat[k] / (ld)M, dp);
+	// the cache exists for the second direction of the same application; long rows would pin (N + M) * 32 bytes of host memory
+	// for the life of the process: keep it only while it is small
+	if ((N + M) * sizeof(cld) > (64ull << 20)) { std::vector<cld>().swap(cChirp); std::vector<cld>().swap(cBhat); cN = cM = 0; }
 }
 
 // ---- C2C along one axis -------------------------------------------------------------------------------
