@@ -1,5 +1,5 @@
-"""Workload for the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE): a calibration copy of known size followed by
-single launches of the headline kernels on the 1 GiB buffer."""
+"""Workload for the rocprofv3 PMC passes (one counter set per pass): a calibration copy of known size, then a few launches of the
+headline kernels on the 1 GiB buffer — single-pass row kernels, the fused Four-Step kernel, and the same sizes with the fusion off."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,10 +9,13 @@ dst = torch.empty_like(buf)
 for _ in range(2):
     dst.copy_(buf)          # calibration: reads 1 GiB, writes 1 GiB
 torch.cuda.synchronize()
-for k in (10, 12, 14, 16, 20, 22):
-    N = 1 << k
-    app = api.App([N], (1 << 27) // N, buffer_ptr=buf.data_ptr(), normalize=True)
-    for _ in range(2):
-        app.forward(); app.inverse()
-    torch.cuda.synchronize()
-    app.delete()
+del dst
+for fused in ("1", "0"):
+    os.environ["VKFFT_MI355X_FUSED"] = fused
+    for k in ((10, 12, 14, 15, 16, 18, 20, 22) if fused == "1" else (16, 20)):
+        N = 1 << k
+        app = api.App([N], (1 << 27) // N, buffer_ptr=buf.data_ptr(), normalize=True)
+        for _ in range(2):
+            app.forward(); app.inverse()
+        torch.cuda.synchronize()
+        app.delete()
