@@ -841,8 +841,15 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	}
 	// lengths with a prime factor above 13 on unit-stride rows: the fused Bluestein kernel on a compile-time schedule of the
 	// padded length beats the interpreter's Rader stages (measured), so it also takes the Rader-capable lengths
+	// ... and the 13-smooth lengths between 1024 and 4096 that have no ahead-of-time mixed-radix instance (the interpreter runs them at
+	// 1.1-1.3 TB/s, the fused chirp-z kernel at 1.5-2 TB/s)
 	uint64_t fusedM = 0;
-	if (unit && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N)) {
+	bool smoothNoInstance = false;
+	if (unit && !d.disableFastKernels && smooth13(j.N) && (j.N & (j.N - 1)) != 0 && j.N > 1024 && j.N <= 4096) {
+		int v, r5[5], f, t;
+		smoothNoInstance = !mixed_row_lookup(j.N, dp, &v, r5, &f, &t);
+	}
+	if (unit && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && (!smooth13(j.N) || smoothNoInstance)) {
 		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
 		uint64_t Mp = 64; while (Mp < 2 * j.N - 1) Mp *= 2; // measured: the power-of-two padded length wins even at 1.6x the {1,3,5}*2^k one
 		int v, bits[4], fpw, thr;
