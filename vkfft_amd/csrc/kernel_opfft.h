@@ -107,6 +107,35 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 			}
 		}
 		if constexpr (!last) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); } // V is consumed before stage 0 overwrites the buffer
+	} else if constexpr (first && PRE == OP_C2R_EVEN_PRE && ROW) {
+		// C2R even fold on unit-stride rows, pairs (k, H-k) together (H = N): X_k and X_{H-k} are loaded ONCE, one table entry, and give
+		// both z_k = s + i d and z_{H-k} = conj(s - i d), s = X_k + conj(X_{H-k}), d = conj(w_k)(X_k - conj(X_{H-k})); the packed sequence z
+		// is laid down in LDS and the first stage gathers its inputs from there.  (pre_gather computes every z_n on its own: each X loaded
+		// twice, twice the arithmetic.)  Reference: vkFFT_R2C_even_decomposition.h:40-180.
+		constexpr int HP = N / 2 + 1, PH = (HP + TPF - 1) / TPF;
+		const GBuf gw = make_gbuf(p.aux);
+#pragma unroll
+		for (int b = 0; b < PH; b++) {
+			const uint32_t k = tau + b * TPF;
+			if ((b + 1) * TPF <= HP || k < (uint32_t)HP) {
+				const cx<T> a = io.ldc(k), bq = cconj(io.ldc((uint32_t)N - k));
+				const cx<T> w = cconj(gb_load<T>(gw, k * (uint32_t)sizeof(cx<T>), 0));
+				const cx<T> sS = cadd(a, bq), d = cmul(w, csub(a, bq));
+				const cx<T> zk = {sS.x - d.y, sS.y + d.x}, zm = {sS.x + d.y, d.x - sS.y};
+				ldsf[k] = p.swapIn ? cswap(zk) : zk;
+				if (k != 0 && 2 * k != (uint32_t)N) ldsf[(uint32_t)N - k] = p.swapIn ? cswap(zm) : zm;
+			}
+		}
+		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+#pragma unroll
+		for (int b = 0; b < P; b++) {
+			const uint32_t t = opfft_bfly<NB, TPF, P, PAIR>(tau, b);
+			if (PAIR || (b + 1) * TPF <= NB || t < (uint32_t)NB) {
+#pragma unroll
+				for (int i = 0; i < R; i++) x[b][i] = ldsf[t + i * NB];
+			}
+		}
+		if constexpr (!last) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); } // z is consumed before stage 0 overwrites the buffer
 	} else {
 #pragma unroll
 		for (int b = 0; b < P; b++) {
@@ -167,6 +196,26 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 	if constexpr (!last) {
 		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
 		op_stage<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, PRE, POST, ROW, TRANS>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
+	} else if constexpr (staged && !TRANS && POST == OP_R2C_EVEN_POST && ROW) {
+		// R2C even split on unit-stride rows, pairs (k, H-k) together (H = N: complex length): one pair of LDS reads and ONE table entry give
+		// both X[k] = (s - i d)/2 and X[H-k] = conj(s + i d)/2, s = Z_k + conj(Z_{H-k}), d = w_k (Z_k - conj(Z_{H-k})), w_{H-k} = -conj(w_k)
+		// (reference: vkFFT_R2C_even_decomposition.h:181-230 computes every output on its own).  k = 0 yields X[0] and X[H].
+		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		constexpr int HP = N / 2 + 1, PH = (HP + TPF - 1) / TPF; // pairs k = 0 .. N/2
+		const T hs = (T)0.5 * (T)p.scale;
+		const GBuf gw = make_gbuf(p.aux);
+#pragma unroll
+		for (int b = 0; b < PH; b++) {
+			const uint32_t k = tau + b * TPF;
+			if ((b + 1) * TPF <= HP || k < (uint32_t)HP) {
+				const uint32_t km = k == 0 ? 0u : (uint32_t)N - k;
+				const cx<T> zk = ldsf[k], zm = cconj(ldsf[km]);
+				const cx<T> w = gb_load<T>(gw, k * (uint32_t)sizeof(cx<T>), 0);
+				const cx<T> sS = cadd(zk, zm), d = cmul(w, csub(zk, zm));
+				io.stc(k, cx<T>{hs * (sS.x + d.y), hs * (sS.y - d.x)});
+				if (2 * k != (uint32_t)N) io.stc((uint32_t)N - k, cx<T>{hs * (sS.x - d.y), -hs * (sS.y + d.x)});
+			}
+		}
 	} else if constexpr (staged && !TRANS) {
 		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
 		constexpr int PO = (N + 1 + TPF - 1) / TPF; // R2C even split: N + 1 outputs from the length-N complex FFT
@@ -193,7 +242,7 @@ template <typename T, typename SCH, int TPF, int FPW, bool COL, int PRE, int POS
 __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	constexpr int N = SCH::N;
 	static_assert(!TRANS || (COL && (POST == OP_NONE || POST == OP_TWIDDLE_4STEP)), "transposed store: first Four-Step pass of a column tile");
-	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || TRANS || PRE == OP_DCT3H_PRE || POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST), MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems()>();
+	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || TRANS || PRE == OP_DCT3H_PRE || (PRE == OP_C2R_EVEN_PRE && !COL) || POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST), MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems()>();
 	constexpr bool waveOnly = !COL && (TPF <= 64) && (64 % TPF == 0); // a row FFT that never straddles wavefronts
 	__shared__ cx<T> lds[FPW * LDSPF];
 	const uint32_t tid = threadIdx.x;
