@@ -77,6 +77,41 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 				x[bm][R - 1 - i] = p.swapIn ? cswap(m) : m;
 			}
 		}
+	} else if constexpr (first && PRE == OP_DCT3H_PRE && ROW) {
+		// half-length DCT/DST-III on unit-stride rows, pairs (k, H-k) together (H = N, Nr = 2H reals): the Hermitian spectrum entries
+		// V_k = conj(c_k)(x_k - i x_{Nr-k}) and V_{H-k} come from four reals each read ONCE, and fold (as in the C2R path above) into both
+		// z_k = s + i d and z_{H-k} = conj(s - i d), s = V_k + conj(V_{H-k}), d = conj(w_k)(V_k - conj(V_{H-k})); z is laid down in LDS and the
+		// first stage gathers its inputs from there.  (Round 1 built V in LDS first and folded every z_n on its own: two LDS reads and one
+		// table entry per point.)  Reference vkFFT_R2R.h:193 runs a full-length complex FFT instead.
+		constexpr int HP = N / 2 + 1, PH = (HP + TPF - 1) / TPF;
+		constexpr uint32_t Hc = (uint32_t)N, Nr = 2u * (uint32_t)N;
+		const bool dst = p.preOp == OP_DST3H_PRE;
+		auto X = [&](uint32_t k) -> T { return k >= Nr ? (T)0 : io.ldr(dst ? Nr - 1u - k : k); };
+		const GBuf gc = make_gbuf(p.aux), gw = make_gbuf(p.aux2);
+#pragma unroll
+		for (int b = 0; b < PH; b++) {
+			const uint32_t k = tau + b * TPF;
+			if ((b + 1) * TPF <= HP || k < (uint32_t)HP) {
+				const uint32_t km = Hc - k;
+				const cx<T> vk = cmul(cconj(gb_load<T>(gc, k * (uint32_t)sizeof(cx<T>), 0)), cx<T>{X(k), -X(Nr - k)});
+				const cx<T> vm = cmul(cconj(gb_load<T>(gc, km * (uint32_t)sizeof(cx<T>), 0)), cx<T>{X(km), -X(Nr - km)});
+				const cx<T> bq = cconj(vm);
+				const cx<T> d = cmul(cconj(gb_load<T>(gw, k * (uint32_t)sizeof(cx<T>), 0)), csub(vk, bq)), s2 = cadd(vk, bq);
+				const cx<T> zk = {s2.x - d.y, s2.y + d.x}, zm = {s2.x + d.y, d.x - s2.y};
+				ldsf[k] = p.swapIn ? cswap(zk) : zk;
+				if (k != 0 && 2 * k != Hc) ldsf[km] = p.swapIn ? cswap(zm) : zm;
+			}
+		}
+		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+#pragma unroll
+		for (int b = 0; b < P; b++) {
+			const uint32_t t = opfft_bfly<NB, TPF, P, PAIR>(tau, b);
+			if (PAIR || (b + 1) * TPF <= NB || t < (uint32_t)NB) {
+#pragma unroll
+				for (int i = 0; i < R; i++) x[b][i] = ldsf[t + i * NB];
+			}
+		}
+		if constexpr (!last) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); } // z is consumed before stage 0 overwrites the buffer
 	} else if constexpr (first && PRE == OP_DCT3H_PRE) {
 		// half-length DCT/DST-III: the Hermitian spectrum V_k = e^{+i pi k/2N}(x_k - i x_{N-k}), k = 0..H, is built ONCE in LDS
 		// (every real read once, one table entry per k), then each FFT input is the even C2R fold of V_n and V_{H-n}.  Gathering
@@ -214,6 +249,33 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 				const cx<T> sS = cadd(zk, zm), d = cmul(w, csub(zk, zm));
 				io.stc(k, cx<T>{hs * (sS.x + d.y), hs * (sS.y - d.x)});
 				if (2 * k != (uint32_t)N) io.stc((uint32_t)N - k, cx<T>{hs * (sS.x - d.y), -hs * (sS.y + d.x)});
+			}
+		}
+	} else if constexpr (staged && !TRANS && POST == OP_DCT2H_POST && ROW) {
+		// half-length DCT/DST-II post-map on unit-stride rows, pairs (k, H-k) together (H = N): 2V_k = s - i d and 2V_{H-k} = conj(s + i d) from one
+		// pair of LDS reads and one split twiddle (see the R2C split above), then y[k] = Re(c^k 2V_k), y[Nr-k] = -Im(c^k 2V_k) and the same for H-k
+		// (reference vkFFT_R2R.h:784 runs a full-length complex FFT instead)
+		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		constexpr int HP = N / 2 + 1, PH = (HP + TPF - 1) / TPF;
+		constexpr uint32_t Hc = (uint32_t)N, Nr = 2u * (uint32_t)N;
+		const bool dst = p.postOp == OP_DST2H_POST;
+		const T sc = (T)p.scale;
+		const GBuf gw = make_gbuf(p.aux2), gc = make_gbuf(p.aux);
+		auto emit = [&](const uint32_t k, const cx<T> v2, const cx<T> c) { // k in [0, H]
+			const cx<T> t = cmul(c, v2);
+			io.str(dst ? Nr - 1u - k : k, sc * t.x);
+			if (k >= 1u && k < Hc) io.str(dst ? k - 1u : Nr - k, -sc * t.y);
+		};
+#pragma unroll
+		for (int b = 0; b < PH; b++) {
+			const uint32_t k = tau + b * TPF;
+			if ((b + 1) * TPF <= HP || k < (uint32_t)HP) {
+				const uint32_t km = k == 0 ? 0u : Hc - k;
+				const cx<T> zk = ldsf[k], zm = cconj(ldsf[km]);
+				const cx<T> w = gb_load<T>(gw, k * (uint32_t)sizeof(cx<T>), 0);
+				const cx<T> sS = cadd(zk, zm), d = cmul(w, csub(zk, zm));
+				emit(k, cx<T>{sS.x + d.y, sS.y - d.x}, gb_load<T>(gc, k * (uint32_t)sizeof(cx<T>), 0));
+				if (2 * k != Hc) emit(Hc - k, cx<T>{sS.x - d.y, -(sS.y + d.x)}, gb_load<T>(gc, (Hc - k) * (uint32_t)sizeof(cx<T>), 0));
 			}
 		}
 	} else if constexpr (staged && !TRANS) {
