@@ -261,3 +261,17 @@ def test_fused_fourstep_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag
     assert up == [2]
     assert rel_l2(y, oracle.truth_c2c(x, (N,), batch)) < 1e-6
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
+
+
+@pytest.mark.parametrize("k,batch", [(14, 5), (15, 3), (16, 3), (17, 2)])
+def test_fused_fourstep_fp64(run, oracle, monkeypatch, k, batch):
+    """fp64 members of the fused Four-Step family (16-byte elements, 16-column tiles), several chunks"""
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_CHUNK_KIB", str((16 << k) >> 10))
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_LAG", "1")
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_RING", "2")
+    N = 1 << k
+    x = parity.seeded_complex(N * batch, True, 5 + k)
+    y, z, up = run.transform(x, (N,), batch, both=True)
+    assert up == [2]
+    assert rel_l2(y, oracle.truth_c2c(x, (N,), batch, longdouble=True)) < 3e-15
+    assert rel_l2(z, x * N) < 5e-15

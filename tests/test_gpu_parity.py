@@ -58,6 +58,20 @@ def test_fused_fourstep_equals_separate_passes(run, oracle, monkeypatch, k, batc
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("k,batch", [(14, 33), (15, 17), (16, 9), (17, 5)])
+def test_fused_fourstep_fp64_equals_separate_passes(run, oracle, monkeypatch, k, batch):
+    """fp64 members of the fused Four-Step family (2^14..2^17) against the separate-pass plan and the long-double truth"""
+    N = 1 << k
+    x = parity.seeded_complex(N * batch, True, 177 + k)
+    yf, zf, up = run.transform(x, (N,), batch, both=True)
+    monkeypatch.setenv("VKFFT_MI355X_FUSED", "0")
+    ys, zs, up2 = run.transform(x, (N,), batch, both=True)
+    assert up == [2] and up2 == [2]
+    assert rel_l2(yf, ys) < 2e-15 and rel_l2(zf, zs) < 4e-15
+    assert rel_l2(yf[: 2 * N], oracle.truth_c2c(x[: 2 * N], (N,), 2, longdouble=True)) < 3e-15
+
+
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("k,env", [(15, dict(LAG=1, RING=2, QUEUES=8)), (16, dict(LAG=1, RING=2, QUEUES=1)), (16, dict(LAG=2, RING=3, CHUNK_KIB=512)),
                                    (17, dict(LAG=1, RING=2, WGS=8)), (18, dict(LAG=1, RING=2, QUEUES=3)), (20, dict(LAG=1, RING=2))])
 def test_fused_fourstep_under_dependency_pressure(product_lib, monkeypatch, k, env):

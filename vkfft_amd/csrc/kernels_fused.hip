@@ -36,6 +36,11 @@ static const Pow2FusedVariant kPow2FusedVariants[] = {
 	// (two workgroups per CU, 64-byte segments on the HBM side) measured 12 % slower
 	VKFFT_FU(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
 	VKFFT_FU(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
+	// fp64: 16-byte elements, 16 columns = 256-byte segments.  2^14 = 128 x 128, 2^15 = 128 x 256, 2^16 = 256 x 256, 2^17 = 256 x 512
+	VKFFT_FU(double, true, 4, 3, 0, 16, 4, 3, 0, 16),
+	VKFFT_FU(double, true, 4, 3, 0, 16, 4, 4, 0, 8),
+	VKFFT_FU(double, true, 4, 4, 0, 16, 4, 4, 0, 16),
+	VKFFT_FUT(double, true, 4, 4, 0, 16, 4, 3, 2, 8, 0), // (stage twiddles through L2: the LDS copy would cost the second workgroup per CU)
 };
 constexpr int kNumPow2FusedVariants = (int)(sizeof(kPow2FusedVariants) / sizeof(kPow2FusedVariants[0]));
 
