@@ -63,34 +63,52 @@ template <typename T> struct TwLds {
 	__device__ inline cx<T> get(uint32_t s, uint32_t constOff) const { return tab[constOff + s]; }
 };
 
-template <typename T, typename SCH, int SI, int TPF, int TCP, typename TW>
+// two neighbouring complex values as one 16-byte LDS access (column kernels that keep two adjacent columns per thread)
+template <typename T> struct alignas(4 * sizeof(T)) cx2 { cx<T> a, b; };
+
+// CPT = columns per thread (column kernels only): 1, or 2 adjacent columns kept in v[0..E) and v[E..2E) — 16-byte global and LDS
+// accesses for fp32 data, one twiddle read serves both columns (needs an even column pitch TCP and ldsf at an even column)
+template <typename T, typename SCH, int SI, int TPF, int TCP, typename TW, int CPT = 1>
 __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const TW lut, const uint32_t tau, const bool waveOnly) {
 	constexpr int LOGE = SCH::LOGE, E = 1 << LOGE;
 	constexpr int LOGR = SCH::bits[SI], R = 1 << LOGR, NB = E / R;
 	constexpr int LOGS = SCH::logS(SI), S = 1 << LOGS;
 	constexpr bool last = (SI == SCH::NS - 1);
+	static_assert(CPT == 1 || (CPT == 2 && TCP > 0 && TCP % 2 == 0), "two columns per thread: column kernels with an even pitch");
 #pragma unroll
 	for (int b = 0; b < NB; b++) {
-		cx<T> x[R];
+		cx<T> x[CPT][R];
 #pragma unroll
-		for (int i = 0; i < R; i++) x[i] = v[b + i * NB];
+		for (int cc = 0; cc < CPT; cc++) {
+#pragma unroll
+			for (int i = 0; i < R; i++) x[cc][i] = v[cc * E + b + i * NB];
+		}
 		const uint32_t t = tau + b * TPF;
 		const uint32_t s = t & (S - 1);
 		if constexpr (SI > 0) {
 			constexpr int LO = SCH::lutOff(SI);
 #pragma unroll
-			for (int i = 1; i < R; i++) x[i] = cmul(x[i], lut.get(s, (uint32_t)(LO + (i - 1) * S)));
+			for (int i = 1; i < R; i++) {
+				const cx<T> w = lut.get(s, (uint32_t)(LO + (i - 1) * S));
+#pragma unroll
+				for (int cc = 0; cc < CPT; cc++) x[cc][i] = cmul(x[cc][i], w);
+			}
 		}
-		dft<R, T>(x);
+#pragma unroll
+		for (int cc = 0; cc < CPT; cc++) dft<R, T>(x[cc]);
 		if constexpr (last) {
 #pragma unroll
-			for (int k = 0; k < R; k++) v[b + k * NB] = x[k];
+			for (int cc = 0; cc < CPT; cc++) {
+#pragma unroll
+				for (int k = 0; k < R; k++) v[cc * E + b + k * NB] = x[cc][k];
+			}
 		} else {
 			const uint32_t ob = ((t - s) << LOGR) + s;
 #pragma unroll
 			for (int k = 0; k < R; k++) {
 				const uint32_t a = ob + k * S;
-				ldsf[pow2_slot<TCP, LOGE>(a)] = x[k];
+				if constexpr (CPT == 1) ldsf[pow2_slot<TCP, LOGE>(a)] = x[0][k];
+				else *(cx2<T>*)(ldsf + pow2_slot<TCP, LOGE>(a)) = cx2<T>{x[0][k], x[1][k]};
 			}
 		}
 	}
@@ -99,12 +117,13 @@ __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const TW lut, const ui
 #pragma unroll
 		for (int m = 0; m < E; m++) {
 			const uint32_t a = tau + m * TPF;
-			v[m] = ldsf[pow2_slot<TCP, LOGE>(a)];
+			if constexpr (CPT == 1) v[m] = ldsf[pow2_slot<TCP, LOGE>(a)];
+			else { const cx2<T> q = *(const cx2<T>*)(ldsf + pow2_slot<TCP, LOGE>(a)); v[m] = q.a; v[E + m] = q.b; }
 		}
 		if constexpr (SI + 2 < SCH::NS) { // another exchange will overwrite the buffer: all reads must be done first
 			if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
 		}
-		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, TCP, TW>(v, ldsf, lut, tau, waveOnly);
+		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, TCP, TW, CPT>(v, ldsf, lut, tau, waveOnly);
 	}
 }
 

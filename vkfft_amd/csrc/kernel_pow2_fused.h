@@ -63,10 +63,10 @@ __device__ inline void pow2_fs_twiddle(cx<T>* v, const GBuf gtab, const uint32_t
 	for (int m = 0; m < E; m++) v[m] = cmul(v[m], (m & ((1 << LOB) - 1)) ? cmul(A[m >> LOB], B[m & ((1 << LOB) - 1)]) : A[m >> LOB]);
 }
 
-template <typename T, typename SCH, int TPF, int TCP, int TWL>
+template <typename T, typename SCH, int TPF, int TCP, int TWL, int CPT>
 __device__ inline void fused_stages(cx<T>* v, cx<T>* ldsf, const cx<T>* twLds, const void* twGlobal, uint32_t oz, uint32_t tau) {
-	if constexpr (TWL) pow2_stages<T, SCH, 0, TPF, TCP, TwLds<T>>(v, ldsf, TwLds<T>{twLds}, tau, false);
-	else pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, ldsf, TwGlobal<T>{make_gbuf((const char*)twGlobal + oz)}, tau, false);
+	if constexpr (TWL) pow2_stages<T, SCH, 0, TPF, TCP, TwLds<T>, CPT>(v, ldsf, TwLds<T>{twLds}, tau, false);
+	else pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>, CPT>(v, ldsf, TwGlobal<T>{make_gbuf((const char*)twGlobal + oz)}, tau, false);
 }
 
 __device__ inline void fused_wait(uint32_t* ctr, uint32_t target) {
@@ -77,10 +77,10 @@ __device__ inline void fused_wait(uint32_t* ctr, uint32_t target) {
 }
 
 // workgroups of a fused kernel that fit one CU (LDS and wave slots), at most 4: fixes the register budget through __launch_bounds__
-template <typename T, typename SA, int TCA, typename SB, int TCB, int TWL> constexpr int pow2_fused_wg_per_cu() {
-	constexpr int la = (1 << SA::LOGN) * (TCA + 1), lb = (1 << SB::LOGN) * (TCB + 1);
+template <typename T, typename SA, int TCA, typename SB, int TCB, int TWL, int CPT> constexpr int pow2_fused_wg_per_cu() {
+	constexpr int la = (1 << SA::LOGN) * (TCA + (CPT == 2 ? 2 : 1)), lb = (1 << SB::LOGN) * (TCB + (CPT == 2 ? 2 : 1));
 	constexpr int ldsBytes = ((la > lb ? la : lb) + (TWL ? SA::lutTotal() + SB::lutTotal() : 0)) * (int)sizeof(cx<T>) + 64;
-	constexpr int nt = ((1 << SA::LOGN) >> SA::LOGE) * TCA;
+	constexpr int nt = ((1 << SA::LOGN) >> SA::LOGE) * TCA / CPT;
 	int w = 163840 / ldsBytes;
 	if (w > 2048 / nt) w = 2048 / nt;
 	return w > 4 ? 4 : w < 1 ? 1 : w;
@@ -106,13 +106,16 @@ __device__ inline uint32_t fused_xcc_id() {
 
 // MODE bit 1: non-temporal hint on the HBM side
 // TWL: stage twiddles staged in LDS (1) or read through the buffer path from L2 (0: where the LDS copy would cost a workgroup per CU)
-template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE, int TWL>
-__global__ void __launch_bounds__(((1 << SA::LOGN) >> SA::LOGE) * TCA, (pow2_fused_wg_per_cu<T, SA, TCA, SB, TCB, TWL>() * (((1 << SA::LOGN) >> SA::LOGE) * TCA)) / 256)
+// CPT: columns per thread.  2 (fp32 only): a thread keeps two adjacent columns, so that every global and ring access is 16 bytes per lane and
+// every LDS exchange access 16 bytes (the fp64 kernels, whose elements are 16 bytes, measured 10-15 % above the 8-byte fp32 ones)
+template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE, int TWL, int CPT>
+__global__ void __launch_bounds__(((1 << SA::LOGN) >> SA::LOGE) * TCA / CPT, (pow2_fused_wg_per_cu<T, SA, TCA, SB, TCB, TWL, CPT>() * (((1 << SA::LOGN) >> SA::LOGE) * TCA / CPT) + 255) / 256)
 pow2_fused_kernel(const FusedParams p) {
-	constexpr int LA = 1 << SA::LOGN, EA = 1 << SA::LOGE, TPFA = LA / EA, TCPA = TCA + 1;
-	constexpr int LB = 1 << SB::LOGN, EB = 1 << SB::LOGE, TPFB = LB / EB, TCPB = TCB + 1;
-	constexpr int NT = TPFA * TCA;
-	static_assert(NT == TPFB * TCB, "both phases run on the same workgroup shape");
+	static_assert(CPT == 1 || (CPT == 2 && sizeof(T) == 4), "two columns per thread: fp32 only");
+	constexpr int LA = 1 << SA::LOGN, EA = 1 << SA::LOGE, TPFA = LA / EA, TCPA = TCA + (CPT == 2 ? 2 : 1);
+	constexpr int LB = 1 << SB::LOGN, EB = 1 << SB::LOGE, TPFB = LB / EB, TCPB = TCB + (CPT == 2 ? 2 : 1);
+	constexpr int NT = TPFA * TCA / CPT;
+	static_assert(NT == TPFB * TCB / CPT, "both phases run on the same workgroup shape");
 	static_assert(LA * TCA == LB * TCB, "both phases move the same number of points per tile");
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	constexpr int AUX_SC = 16;                   // ring loads: agent scope, served from the memory side
@@ -193,26 +196,29 @@ pow2_fused_kernel(const FusedParams p) {
 		const uint32_t sB = s - p.D, cB = q + Q * sB;
 		const uint32_t bB = ((p.reverse ? p.C - 1u - cB : cB) << p.logG) + f;
 		const bool liveB = hasB && bB < p.batch;
-		const uint32_t cBl = tid % TCB, tauB = tid / TCB;
+		const uint32_t cBl = (tid % (TCB / CPT)) * CPT, tauB = tid / (TCB / CPT); // first of this thread's CPT adjacent columns
 		const uint32_t k00 = ti * TCB;
 		const char* const sbaseB = (const char*)p.scratch + ((uint64_t)(((q * p.NS + (hasB ? sB % p.NS : 0u)) << p.logG) + f) * nPts) * ES;
 		const GBuf gsB = make_gbuf(sbaseB + (uint64_t)k00 * ES);
 		const uint32_t laneB = liveB ? (tauB * p.n0 + cBl) * ES : kGbInvalid, stepB = (uint32_t)TPFB * p.n0 * ES;
-		cx<T> vB[EB];
+		cx<T> vB[CPT * EB];
 		{
 			// ---- A: FFT over n0 of TCA neighbouring columns (stride n1), twiddle, per-column contiguous store into the ring
 			const uint32_t cA = q + Q * s;                          // chunk in processing order (counters, ring slot)
 			const uint32_t b = ((p.reverse ? p.C - 1u - cA : cA) << p.logG) + f;
 			const bool live = hasA && b < p.batch; // the last chunk may be partial: its empty tiles only keep the counters uniform
 			const char* const sbase = (const char*)p.scratch + ((uint64_t)(((q * p.NS + s % p.NS) << p.logG) + f) * nPts) * ES;
-			const uint32_t c = tid % TCA, tau = tid / TCA;
+			const uint32_t c = (tid % (TCA / CPT)) * CPT, tau = tid / (TCA / CPT); // first of this thread's CPT adjacent columns
 			const uint32_t col0 = ti * TCA;
 			const GBuf gin = make_gbuf((const cx<T>*)p.in + ((int64_t)(live ? b : 0u) * p.inBatchStride + col0));
 			const uint32_t laneIn = live ? (tau * p.n1 + c) * ES : kGbInvalid, stepIn = (uint32_t)TPFA * p.n1 * ES;
 			{
-				cx<T> v[EA];
+				cx<T> v[CPT * EA];
 #pragma unroll
-				for (int m = 0; m < EA; m++) v[m] = gb_load_x<T, AUX_HBM>(gin, laneIn, m * stepIn);
+				for (int m = 0; m < EA; m++) {
+					if constexpr (CPT == 1) v[m] = gb_load_x<T, AUX_HBM>(gin, laneIn, m * stepIn);
+					else gb_load2_x<T, AUX_HBM>(gin, laneIn, m * stepIn, v[m], v[EA + m]);
+				}
 				VKFFT_VMEM_DRAIN(); // this tile's loads have landed, the previous ticket's stores are acknowledged, the next ticket is here
 				if (tid == 0) {
 					sTicket[it] = nextT;
@@ -227,15 +233,21 @@ pow2_fused_kernel(const FusedParams p) {
 				if (live) {
 					if (p.swapIn) {
 #pragma unroll
-						for (int m = 0; m < EA; m++) v[m] = cswap(v[m]);
+						for (int m = 0; m < CPT * EA; m++) v[m] = cswap(v[m]);
 					}
-					if constexpr ((MODE & 8) == 0) fused_stages<T, SA, TPFA, TCPA, TWL>(v, lds + c, twA, p.lutA, oz, tau);
+					if constexpr ((MODE & 8) == 0) fused_stages<T, SA, TPFA, TCPA, TWL, CPT>(v, lds + c, twA, p.lutA, oz, tau);
 					VKFFT_PROF(8);
-					if constexpr ((MODE & 8) == 0) pow2_fs_twiddle<T, SA::LOGE, TPFA>(v, gtw, p.fsLoBits, tau, col0 + c);
+					if constexpr ((MODE & 8) == 0) {
+#pragma unroll
+						for (int cc = 0; cc < CPT; cc++) pow2_fs_twiddle<T, SA::LOGE, TPFA>(v + cc * EA, gtw, p.fsLoBits, tau, col0 + c + cc);
+					}
 					VKFFT_PROF(9);
 					if constexpr (SA::NS > 1) __syncthreads(); // the last exchange's reads are complete
 #pragma unroll
-					for (int m = 0; m < EA; m++) lds[(tau + m * TPFA) * TCPA + c] = v[m];
+					for (int m = 0; m < EA; m++) {
+						if constexpr (CPT == 1) lds[(tau + m * TPFA) * TCPA + c] = v[m];
+						else *(cx2<T>*)(lds + (tau + m * TPFA) * TCPA + c) = cx2<T>{v[m], v[EA + m]};
+					}
 					__syncthreads();
 					VKFFT_PROF(10);
 				}
@@ -245,14 +257,14 @@ pow2_fused_kernel(const FusedParams p) {
 				if constexpr (sizeof(T) == 4) {
 					// two consecutive k per lane: 16-byte write-through stores (8-byte sc1 stores cost 2.7x per byte)
 #pragma unroll
-					for (int i = 0; i < EA / 2; i++) {
+					for (int i = 0; i < CPT * EA / 2; i++) {
 						const uint32_t idx = tid + i * NT;
 						const uint32_t kp = idx % (LA / 2), cc = idx / (LA / 2);
 						gb_store2_x<T, AUX_ST>(gs, (cc * LA + 2u * kp) * ES, lds[(2u * kp) * TCPA + cc], lds[(2u * kp + 1u) * TCPA + cc]);
 					}
 				} else {
 #pragma unroll
-					for (int i = 0; i < EA; i++) {
+					for (int i = 0; i < CPT * EA; i++) {
 						const uint32_t idx = tid + i * NT;
 						const uint32_t k = idx % LA, cc = idx / LA;
 						gb_store_x<T, AUX_ST>(gs, (cc * LA + k) * ES, 0, lds[k * TCPA + cc]);
@@ -267,7 +279,10 @@ pow2_fused_kernel(const FusedParams p) {
 			const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)(liveB ? bB : 0u) * p.outBatchStride + k00));
 			if (!okB) { fused_wait(p.ctr + depB(s), TPC); VKFFT_PROF(6); } // rare (okB was sampled one ticket ago: ordered before the loads by S1)
 #pragma unroll
-			for (int m = 0; m < EB; m++) vB[m] = gb_load_x<T, AUX_SC>(gsB, (MODE & 16) ? kGbInvalid : laneB, m * stepB);
+			for (int m = 0; m < EB; m++) {
+				if constexpr (CPT == 1) vB[m] = gb_load_x<T, AUX_SC>(gsB, (MODE & 16) ? kGbInvalid : laneB, m * stepB);
+				else gb_load2_x<T, AUX_SC>(gsB, (MODE & 16) ? kGbInvalid : laneB, m * stepB, vB[m], vB[EB + m]);
+			}
 			VKFFT_VMEM_DRAIN(); // the tile is in registers; the A part's ring stores are acknowledged
 			__syncthreads();    // S3: ... in every wave
 			VKFFT_PROF(3);
@@ -276,18 +291,21 @@ pow2_fused_kernel(const FusedParams p) {
 				fused_publish<MODE>(p.ctr, pending, flushing);
 			}
 			if (liveB) {
-				if constexpr ((MODE & 8) == 0) fused_stages<T, SB, TPFB, TCPB, TWL>(vB, lds + cBl, twB, p.lutB, oz, tauB);
+				if constexpr ((MODE & 8) == 0) fused_stages<T, SB, TPFB, TCPB, TWL, CPT>(vB, lds + cBl, twB, p.lutB, oz, tauB);
 				if (p.swapOut) {
 #pragma unroll
-					for (int m = 0; m < EB; m++) vB[m] = cswap(vB[m]);
+					for (int m = 0; m < CPT * EB; m++) vB[m] = cswap(vB[m]);
 				}
 				const T sc = (T)p.scale;
 				if (sc != (T)1) {
 #pragma unroll
-					for (int m = 0; m < EB; m++) vB[m] = cscale(vB[m], sc);
+					for (int m = 0; m < CPT * EB; m++) vB[m] = cscale(vB[m], sc);
 				}
 #pragma unroll
-				for (int m = 0; m < EB; m++) gb_store_x<T, AUX_HBM>(gout, laneB, m * stepB, vB[m]);
+				for (int m = 0; m < EB; m++) {
+					if constexpr (CPT == 1) gb_store_x<T, AUX_HBM>(gout, laneB, m * stepB, vB[m]);
+					else gb_store2_x<T, AUX_HBM>(gout, laneB + m * stepB, vB[m], vB[EB + m]);
+				}
 			}
 		}
 		if (tid == 0) { sOkA[it] = nfA >= TPC; sOkB[it] = nfB >= TPC; }
@@ -319,9 +337,9 @@ struct Pow2FusedVariant {
 	const void* fn;
 };
 
-template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE, int TWL> void pow2_fused_launch(const FusedParams& prm, dim3 grid, hipStream_t s) {
-	constexpr int threads = ((1 << SA::LOGN) >> SA::LOGE) * TCA;
-	hipLaunchKernelGGL((pow2_fused_kernel<T, SA, TCA, SB, TCB, MODE, TWL>), grid, dim3(threads), 0, s, prm);
+template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE, int TWL, int CPT> void pow2_fused_launch(const FusedParams& prm, dim3 grid, hipStream_t s) {
+	constexpr int threads = ((1 << SA::LOGN) >> SA::LOGE) * TCA / CPT;
+	hipLaunchKernelGGL((pow2_fused_kernel<T, SA, TCA, SB, TCB, MODE, TWL, CPT>), grid, dim3(threads), 0, s, prm);
 }
 
 } // namespace vkfft_mi355x

@@ -7,34 +7,43 @@
 
 namespace vkfft_mi355x {
 
-#define VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, mode, twl) \
+#define VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, mode, twl, cpt) \
 	{ (a0) + (a1) + (a2) + (b0) + (b1) + (b2), dp, mode, (a0) + (a1) + (a2), (b0) + (b1) + (b2), {a0, a1, a2, 0}, {b0, b1, b2, 0}, tca, tcb, \
-	  ((1 << ((a0) + (a1) + (a2))) >> Pow2Sched<a0, a1, a2, 0>::LOGE) * (tca), pow2_fused_wg_per_cu<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, twl>(), \
-	  &pow2_fused_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl>, \
-	  (const void*)&pow2_fused_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl> }
+	  ((1 << ((a0) + (a1) + (a2))) >> Pow2Sched<a0, a1, a2, 0>::LOGE) * (tca) / (cpt), pow2_fused_wg_per_cu<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, twl, cpt>(), \
+	  &pow2_fused_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt>, \
+	  (const void*)&pow2_fused_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt> }
 // mode 2 = product (non-temporal hint on the streamed side); the others exist only in development builds (-DVKFFT_MI355X_DEV):
 // 0 = no hint, 6 = per-phase cycle profile, 8 / 16 / 24 = without the FFT arithmetic / without the ring traffic / without both
 #if defined(VKFFT_MI355X_DEV)
-#define VKFFT_FUT(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl) \
-	VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 0, twl), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, twl), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 8, twl), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 16, twl), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 24, twl)
+#define VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, cpt) \
+	VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 0, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 8, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 16, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 24, twl, cpt)
 #else
-#define VKFFT_FUT(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl) VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl)
+#define VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, cpt) VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, cpt)
 #endif
-#define VKFFT_FU(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUT(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1)
+#define VKFFT_FUT(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, 1)
+#define VKFFT_FU(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 1)
+#define VKFFT_FU2(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 2) /* two columns per thread */
 
 // first entry of each (log2 N, dp, mode) is the default; VKFFT_MI355X_FUV<log2n>=k selects the k-th shape (tuning)
 static const Pow2FusedVariant kPow2FusedVariants[] = {
+	// fp32, two adjacent columns per thread (16-byte accesses): measured 3-18 % above the one-column shapes that follow them
 	// 2^15 = 128 x 256
+	VKFFT_FU2(float, false, 4, 3, 0, 32, 4, 4, 0, 16),
 	VKFFT_FU(float, false, 4, 3, 0, 32, 4, 4, 0, 16),
 	// 2^16 = 256 x 256
+	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 4, 0, 32),
 	VKFFT_FU(float, false, 4, 4, 0, 32, 4, 4, 0, 32),
-	// 2^17 = 256 x 512 (measured: 2.9 TB/s; 32 points per thread on 256 threads: 2.6)
+	// 2^17 = 256 x 512
+	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
 	VKFFT_FU(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
-	// 2^18 = 512 x 512 (32 points per thread, 256 threads, two workgroups per CU: 3.1 TB/s; 16 points per thread: 2.4)
+	// 2^18 = 512 x 512
+	VKFFT_FU2(float, false, 4, 3, 2, 16, 4, 3, 2, 16),
 	VKFFT_FU(float, false, 5, 4, 0, 16, 5, 4, 0, 16),
 	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: one workgroup per CU (the 1024-point column tile needs 139 KiB of LDS); 8-column tiles
 	// (two workgroups per CU, 64-byte segments on the HBM side) measured 12 % slower
+	VKFFT_FU2(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
 	VKFFT_FU(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
+	VKFFT_FU2(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
 	VKFFT_FU(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
 	// fp64: 16-byte elements, 16 columns = 256-byte segments.  2^14 = 128 x 128, 2^15 = 128 x 256, 2^16 = 256 x 256, 2^17 = 256 x 512
 	VKFFT_FU(double, true, 4, 3, 0, 16, 4, 3, 0, 16),

@@ -60,6 +60,7 @@ template <typename T, int AUX> inline cx<T> gb_load_x(GBuf b, uint32_t voff, uin
 template <typename T, int AUX> inline void gb_store_x(GBuf b, uint32_t voff, uint32_t soff, cx<T> v) { gb_store<T>(b, voff, soff, v); }
 template <typename T, int AUX> inline void gb_store2_x(GBuf b, uint32_t voff, cx<T> v0, cx<T> v1) { gb_store<T>(b, voff, 0, v0); gb_store<T>(b, voff + (uint32_t)sizeof(cx<T>), 0, v1); }
 template <typename T, int E> inline void gb_landed(cx<T>*) { }
+template <typename T, int AUX> inline void gb_load2_x(GBuf b, uint32_t voff, uint32_t soff, cx<T>& v0, cx<T>& v1) { v0 = gb_load<T>(b, voff, soff); v1 = gb_load<T>(b, voff + (voff >= kGbRange ? 0u : (uint32_t)sizeof(cx<T>)), soff); }
 #else
 typedef unsigned int vk_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int vk_u32x4 __attribute__((ext_vector_type(4)));
@@ -159,6 +160,12 @@ template <typename T, int AUX> __device__ inline void gb_store_x(GBuf b, uint32_
 template <typename T, int E> __device__ inline void gb_landed(cx<T>* v) {
 #pragma unroll
 	for (int m = 0; m < E; m++) asm volatile("" : "+v"(v[m].x), "+v"(v[m].y));
+}
+// two consecutive fp32 complex values in one 128-bit load
+template <typename T, int AUX> __device__ inline void gb_load2_x(GBuf b, uint32_t voff, uint32_t soff, cx<T>& v0, cx<T>& v1) {
+	static_assert(sizeof(T) == 4, "pairs of fp32 complex only");
+	const vk_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, soff, AUX);
+	v0 = cx<T>{__uint_as_float(t.x), __uint_as_float(t.y)}; v1 = cx<T>{__uint_as_float(t.z), __uint_as_float(t.w)};
 }
 // two consecutive fp32 complex values in one 128-bit store
 template <typename T, int AUX> __device__ inline void gb_store2_x(GBuf b, uint32_t voff, cx<T> v0, cx<T> v1) {
