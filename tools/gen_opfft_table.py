@@ -66,6 +66,26 @@ def plan_row(n, dp, pair=None):
             cand = nbp // 2
             if max(math.ceil((n // r) / cand) * r for r in rad) <= (32 if not dp else 24):
                 tpf = cand
+    if pair == "both" and len(rad) >= 1:
+        # half-length DCT-IV: mirrored butterfly pairs in the first AND the last stage (8-byte accesses, kernel_opfft.h pairIn4/pairOut4):
+        # even radices at both ends and a thread count that halves both butterfly counts
+        evens = sorted(r for r in rad if r % 2 == 0)
+        if len(evens) >= (2 if len(rad) > 1 else 1):
+            rest = list(rad)
+            r0 = evens[0]; rest.remove(r0)
+            if len(rad) > 1:
+                rl = min(r for r in rest if r % 2 == 0); rest.remove(rl)
+                order = [r0] + sorted(rest, reverse=True) + [rl]
+            else:
+                order = [r0]
+            nb0, nbl = n // order[0], n // order[-1]
+            import math as _m
+            g = _m.gcd(nb0 // 2 if nb0 % 2 == 0 else 0, nbl // 2 if nbl % 2 == 0 else 0)
+            cands = [t for t in range(1, g + 1) if g % t == 0 and max(_m.ceil((n // r) / t) * r for r in order) <= (32 if not dp else 24)] if g else []
+            if cands:
+                rad = order
+                tpf = min(cands)  # fewest threads that keep every stage within the register budget... smallest admissible divisor
+                tpf = max(c for c in cands if c <= max(tpf_for(n, rad, 16), min(cands)))
     if tpf > 1024:
         return None
     lds_per = pitch(n, 1, False) * es
@@ -119,7 +139,7 @@ def main():
                     if dp and n > 4096: continue
                     if fourstep and ispow2 and n <= 1024: continue  # pow2_col_kernel covers these
                     if fam in ("dct2", "dct3") and n % 2 == 0: continue  # even lengths take the half-length form
-                    r = plan_col(n, dp, real) if col else plan_row(n, dp, {"dct2h": "first", "dct3h": "last"}.get(fam))
+                    r = plan_col(n, dp, real) if col else plan_row(n, dp, {"dct2h": "first", "dct3h": "last", "dct4": "both"}.get(fam))
                     if r is None: continue
                     rad, tpf, fpw = r
                     rr = rad + [1] * (5 - len(rad))

@@ -55,7 +55,13 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 	constexpr bool staged = POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST || TRANS; // the post-map (or the transposed store) gathers from LDS
 	constexpr bool pairIn = ROW && first && PRE == OP_DCT2H_PRE && opfft_can_pair<SCH, SI, TPF>();
 	constexpr bool pairOut = ROW && last && POST == OP_DCT3H_POST && opfft_can_pair<SCH, SI, TPF>();
-	constexpr bool PAIR = pairIn || pairOut;
+	// half-length DCT/DST-IV: FFT input n is (x[2n], x[Nr-1-2n]) * twiddle and output m feeds y[2m] and y[Nr-1-2m].  The two consecutive reals
+	// x[2n], x[2n+1] belong to n and to its mirror H-1-n, which is input R-1-i of butterfly NB-1-t when n is input i of butterfly t: a thread that
+	// owns the butterfly pair (t, NB-1-t) moves its points with 8-byte accesses that are contiguous across the lanes (instead of two 4-byte
+	// accesses of stride 2 per point).  Reference: vkFFT_R2R.h:368,861.
+	constexpr bool pairIn4 = ROW && first && PRE == OP_DCT4_PRE && opfft_can_pair<SCH, SI, TPF>();
+	constexpr bool pairOut4 = ROW && last && POST == OP_DCT4_POST && opfft_can_pair<SCH, SI, TPF>();
+	constexpr bool PAIR = pairIn || pairOut || pairIn4 || pairOut4;
 	// LDS padding per exchange: rows pick it by conflict count (MixPad); column tiles need none (lanes run along the columns)
 	using PAD = MixPad<SCH, TPF, (int)sizeof(cx<T>)>;
 	constexpr int PADIN = ROW ? PAD::shift(SI - 1) : 0, PADOUT = ROW ? PAD::shift(SI) : 0;
@@ -75,6 +81,25 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 				const cx<T> a = {q.x, q.z}, m = {q.w, q.y};
 				x[b][i] = p.swapIn ? cswap(a) : a;
 				x[bm][R - 1 - i] = p.swapIn ? cswap(m) : m;
+			}
+		}
+	} else if constexpr (pairIn4) {
+		const bool dst = p.preOp == OP_DST4_PRE; // DST-IV reads the reversed row: (x[2n], x[Nr-1-2n]) swap roles
+		const GBuf gtw = make_gbuf(p.aux);
+		constexpr uint32_t RS = (uint32_t)sizeof(T);
+#pragma unroll
+		for (int b = 0; b < P / 2; b++) {
+			const uint32_t t = opfft_bfly<NB, TPF, P, true>(tau, b);
+			constexpr int mirror = P / 2;
+#pragma unroll
+			for (int i = 0; i < R; i++) {
+				const uint32_t n = t + i * NB, nm = (uint32_t)N - 1u - n; // nm = input R-1-i of butterfly NB-1-t
+				const cx<T> q = gb_load<T>(io.gin, io.inOff + n * (2 * RS), 0);   // (x[2n], x[2n+1]): T pairs are read as one cx<T>-sized access
+				const cx<T> qm = gb_load<T>(io.gin, io.inOff + nm * (2 * RS), 0); // (x[2nm], x[2nm+1])
+				const cx<T> a = dst ? cx<T>{qm.y, q.x} : cx<T>{q.x, qm.y}, am = dst ? cx<T>{q.y, qm.x} : cx<T>{qm.x, q.y};
+				const cx<T> z = cmul(a, gb_load<T>(gtw, n * ES, 0)), zm = cmul(am, gb_load<T>(gtw, nm * ES, 0));
+				x[b][i] = p.swapIn ? cswap(z) : z;
+				x[b + mirror][R - 1 - i] = p.swapIn ? cswap(zm) : zm;
 			}
 		}
 	} else if constexpr (first && PRE == OP_DCT3H_PRE && ROW) {
@@ -200,7 +225,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 				for (int i = 1; i < R; i++) x[b][i] = cmul(x[b][i], gb_load<T>(glut, s * ES, (uint32_t)(LO + (i - 1) * S) * ES));
 			}
 			dft<R, T>(x[b]);
-			if constexpr (!pairOut) {
+			if constexpr (!pairOut && !pairOut4) {
 				const uint32_t ob = (t - s) * (uint32_t)R + s;
 #pragma unroll
 				for (int k = 0; k < R; k++) {
@@ -225,6 +250,25 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 			for (int k = 0; k < R / 2; k++) {
 				const cx<T> a = p.swapOut ? cswap(x[b][k]) : x[b][k], m = p.swapOut ? cswap(x[bm][R - 1 - k]) : x[bm][R - 1 - k];
 				gb_store_real4<T>(io.gout, io.outOff + t * (2 * ES), (uint32_t)(k * NB) * (2 * ES), Real4<T>{a.x * sc, m.y * so, a.y * sc, m.x * so});
+			}
+		}
+	}
+	if constexpr (pairOut4) { // last stage: output k of butterfly t is FFT output m = t + k*NB; (y[2m], y[2m+1]) = (2 Re c_m, -2 Im c_{H-1-m})
+		const bool dst = p.postOp == OP_DST4_POST; // DST-IV: the odd outputs change sign
+		const T sc2 = (T)2 * (T)p.scale, so = dst ? sc2 : -sc2;
+		const GBuf gtw = make_gbuf(p.aux2);
+		constexpr uint32_t RS = (uint32_t)sizeof(T);
+#pragma unroll
+		for (int b = 0; b < P / 2; b++) {
+			const uint32_t t = opfft_bfly<NB, TPF, P, true>(tau, b);
+			constexpr int mirror = P / 2;
+#pragma unroll
+			for (int k = 0; k < R; k++) {
+				const uint32_t m = t + k * NB, mm = (uint32_t)N - 1u - m;
+				const cx<T> v = p.swapOut ? cswap(x[b][k]) : x[b][k], vm = p.swapOut ? cswap(x[b + mirror][R - 1 - k]) : x[b + mirror][R - 1 - k];
+				const cx<T> c = cmul(v, gb_load<T>(gtw, m * ES, 0)), cm = cmul(vm, gb_load<T>(gtw, mm * ES, 0));
+				gb_store<T>(io.gout, io.outOff + m * (2 * RS), 0, cx<T>{sc2 * c.x, so * cm.y});
+				gb_store<T>(io.gout, io.outOff + mm * (2 * RS), 0, cx<T>{sc2 * cm.x, so * c.y});
 			}
 		}
 	}
