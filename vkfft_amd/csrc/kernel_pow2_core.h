@@ -103,6 +103,14 @@ __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const TW lut, const ui
 				for (int k = 0; k < R; k++) v[cc * E + b + k * NB] = x[cc][k];
 			}
 		} else {
+#if defined(VKFFT_PROBE_NO_EXCHANGE) // tools/probe_exchange.hip only: timing of the kernel without its exchange (results meaningless)
+#pragma unroll
+			for (int cc = 0; cc < CPT; cc++) {
+#pragma unroll
+				for (int k = 0; k < R; k++) v[cc * E + b + k * NB] = x[cc][k];
+			}
+			continue;
+#endif
 			const uint32_t ob = ((t - s) << LOGR) + s;
 #pragma unroll
 			for (int k = 0; k < R; k++) {
@@ -113,6 +121,10 @@ __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const TW lut, const ui
 		}
 	}
 	if constexpr (!last) {
+#if defined(VKFFT_PROBE_NO_EXCHANGE)
+		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, TCP, TW, CPT>(v, ldsf, lut, tau, waveOnly);
+		return;
+#endif
 		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
 #pragma unroll
 		for (int m = 0; m < E; m++) {
