@@ -85,7 +85,7 @@ def test_bluestein_multi_pass_fused(run, oracle, N, dp, uploads):
     assert up == [uploads]
 
 
-@pytest.mark.parametrize("N,passes", [(1 << 15, 2), (1 << 16, 2), (1 << 18, 2), (3 ** 10, 2), (1 << 21, 3), (5 ** 9, 3)])
+@pytest.mark.parametrize("N,passes", [(1 << 15, 2), (1 << 16, 2), (1 << 18, 2), (3 ** 10, 2), (1 << 21, 2), (5 ** 9, 3)])
 def test_fourstep(run, oracle, N, passes):
     up = parity.check_c2c(run, oracle, (N,), 1, False, use_c_oracle=N <= (1 << 16))
     assert up == [passes]

@@ -33,7 +33,7 @@ def test_pow2_single_pass(run, oracle, k):
     parity.check_c2c(run, oracle, (N,), max(1, min(97, (1 << 17) // N)), False)
 
 
-@pytest.mark.parametrize("k,passes", [(15, 2), (16, 2), (17, 2), (18, 2), (19, 2), (20, 2), (21, 3), (22, 3)])
+@pytest.mark.parametrize("k,passes", [(15, 2), (16, 2), (17, 2), (18, 2), (19, 2), (20, 2), (21, 2), (22, 2)])
 def test_pow2_multi_pass(run, oracle, k, passes):
     N = 1 << k
     up = parity.check_c2c(run, oracle, (N,), 3 if k < 20 else 2, False)
@@ -41,7 +41,7 @@ def test_pow2_multi_pass(run, oracle, k, passes):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("k,batch", [(15, 37), (16, 65), (17, 19), (18, 9), (19, 5), (20, 3)])
+@pytest.mark.parametrize("k,batch", [(15, 37), (16, 65), (17, 19), (18, 9), (19, 5), (20, 3), (21, 3), (22, 2)])
 def test_fused_fourstep_equals_separate_passes(run, oracle, monkeypatch, k, batch):
     """2^15..2^20 run as ONE persistent launch (kernel_pow2_fused.h) whose intermediate lives in an Infinity-Cache resident ring; the same
     plan with the fusion switched off runs the two Four-Step passes as separate launches through a full-size temp buffer.  Odd batches:
@@ -51,7 +51,7 @@ def test_fused_fourstep_equals_separate_passes(run, oracle, monkeypatch, k, batc
     yf, zf, up = run.transform(x, (N,), batch, both=True)
     monkeypatch.setenv("VKFFT_MI355X_FUSED", "0")
     ys, zs, up2 = run.transform(x, (N,), batch, both=True)
-    assert up == [2] and up2 == [2]
+    assert up == [2] and up2 == ([2] if k <= 20 else [3])  # 2^21 / 2^22: three separate passes without the fusion
     assert rel_l2(yf, ys) < 1e-6 and rel_l2(zf, zs) < 2e-6
     truth = oracle.truth_c2c(x[: 2 * N], (N,), 2)
     assert rel_l2(yf[: 2 * N], truth) < 1e-6
@@ -73,7 +73,7 @@ def test_fused_fourstep_fp64_equals_separate_passes(run, oracle, monkeypatch, k,
 
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("k,env", [(15, dict(LAG=1, RING=2, QUEUES=8)), (16, dict(LAG=1, RING=2, QUEUES=1)), (16, dict(LAG=2, RING=3, CHUNK_KIB=512)),
-                                   (17, dict(LAG=1, RING=2, WGS=8)), (18, dict(LAG=1, RING=2, QUEUES=3)), (20, dict(LAG=1, RING=2))])
+                                   (17, dict(LAG=1, RING=2, WGS=8)), (18, dict(LAG=1, RING=2, QUEUES=3)), (20, dict(LAG=1, RING=2)), (22, dict(LAG=1, RING=2))])
 def test_fused_fourstep_under_dependency_pressure(product_lib, monkeypatch, k, env):
     """the smallest legal ring and lag: almost every tile finds its dependency unsatisfied and takes the polling path, ring slots are
     reused immediately, the grid is oversubscribed — results must not change and the launch must terminate (1 GiB, 12 launches)"""

@@ -45,6 +45,9 @@ static const Pow2FusedVariant kPow2FusedVariants[] = {
 	VKFFT_FU(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
 	VKFFT_FU2(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
 	VKFFT_FU(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
+	// 2^21 = 2048 x 1024, 2^22 = 2048 x 2048: 2048-point column tiles are 8 columns wide (147 KiB of LDS; 64-byte segments on the HBM side)
+	VKFFT_FUT(float, false, 5, 3, 3, 8, 5, 5, 0, 16, 0),
+	VKFFT_FUT(float, false, 5, 3, 3, 8, 5, 3, 3, 8, 0),
 	// fp64: 16-byte elements, 16 columns = 256-byte segments.  2^14 = 128 x 128, 2^15 = 128 x 256, 2^16 = 256 x 256, 2^17 = 256 x 512
 	VKFFT_FU(double, true, 4, 3, 0, 16, 4, 3, 0, 16),
 	VKFFT_FU(double, true, 4, 3, 0, 16, 4, 4, 0, 8),

@@ -680,22 +680,32 @@ static bool emit_fused(const TransformDesc& d, const AxisJob& j, Arena& ar, Dire
 	const uint64_t G = 1ull << logG;
 	const uint64_t C = (batch + G - 1) / G;
 	const uint64_t tpc = G << logTiles; // tickets per slot (= tiles per chunk and phase)
-	uint64_t Q = d.fusedQueues ? d.fusedQueues : (C >= 4 * kFusedMaxQueues ? kFusedMaxQueues : 1);
-	if (Q > kFusedMaxQueues) Q = kFusedMaxQueues;
-	if (Q > C) Q = 1;
-	const uint64_t Wq = 256ull * (uint64_t)(d.fusedWgPerCu ? d.fusedWgPerCu : wgPerCu) / Q;
+	// queues: one per XCD when the ring that goes with it still fits the Infinity Cache (256 MiB, shared with what streams through),
+	// else one queue; as a last resort a shorter lag (some tiles will poll)
+	const uint64_t ringBudget = 224ull << 20;
+	const uint64_t wgs = 256ull * (uint64_t)(d.fusedWgPerCu ? d.fusedWgPerCu : wgPerCu);
 	// measured (tools/tune_fused.py): completions are published up to a ticket late and the ticket rate rises with the speed of the
 	// kernel, so the window is taken generously: 3 windows where two or more workgroups share a CU, 2 with one workgroup per CU
-	const uint64_t marginPct = d.fusedMarginPct ? d.fusedMarginPct : (wgPerCu >= 2 ? 300 : 200);
-	const uint64_t X = (Wq * marginPct / 100 + tpc - 1) / tpc;
-	const uint64_t Cq = (C + Q - 1) / Q;
-	uint64_t D = d.fusedLag ? d.fusedLag : 1 + X;
-	if (D < 1) D = 1;
-	uint64_t NS = d.fusedRing ? d.fusedRing : D + 1 + X;
-	if (NS <= D) NS = D + 1;
-	if (NS > Cq) NS = Cq; // fewer chunks than ring slots: no slot is ever reused
-	if (D > Cq) D = Cq;   // (then every A tile of the queue precedes its first B tile)
-	if (NS < 1) NS = 1;
+	uint64_t marginPct = d.fusedMarginPct ? d.fusedMarginPct : (wgPerCu >= 2 ? 300 : 200);
+	uint64_t Q = 1, X = 1, D = 1, NS = 1, Cq = C;
+	auto shape = [&](uint64_t q, uint64_t pct) {
+		Q = q; Cq = (C + Q - 1) / Q;
+		X = ((wgs / Q) * pct / 100 + tpc - 1) / tpc;
+		if (X < 1) X = 1;
+		D = d.fusedLag ? d.fusedLag : 1 + X;
+		NS = d.fusedRing ? d.fusedRing : D + 1 + X;
+		if (NS <= D) NS = D + 1;
+		if (NS > Cq) NS = Cq; // fewer chunks than ring slots: no slot is ever reused
+		if (D > Cq) D = Cq;   // (then every A tile of the queue precedes its first B tile)
+		if (NS < 1) NS = 1;
+		return Q * NS * G * fftBytes;
+	};
+	if (d.fusedQueues) (void)shape(std::min<uint64_t>(std::min<uint64_t>(d.fusedQueues, kFusedMaxQueues), C), marginPct);
+	else {
+		const uint64_t q8 = C >= 4 * kFusedMaxQueues ? kFusedMaxQueues : 1;
+		if (shape(q8, marginPct) > ringBudget && q8 > 1) (void)shape(1, marginPct);
+		while (!d.fusedMarginPct && shape(Q, marginPct) > ringBudget && marginPct > 50) marginPct -= 25;
+	}
 	const uint64_t scratch = Q * NS * G * fftBytes;
 	if (d.userTempBytes && scratch > d.userTempBytes) return false;
 	if (((Cq + D) << (logG + logTiles)) >= (1ull << 31)) return false; // 32-bit tickets
