@@ -40,12 +40,14 @@ static const Pow2FusedVariant kPow2FusedVariants[] = {
 	VKFFT_FU2(float, false, 4, 3, 2, 16, 4, 3, 2, 16),
 	VKFFT_FU(float, false, 5, 4, 0, 16, 5, 4, 0, 16),
 	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: one workgroup per CU (the 1024-point column tile needs 139 KiB of LDS); 8-column tiles
-	// (two workgroups per CU, 64-byte segments on the HBM side) measured 12 % slower
+	// (two workgroups per CU, 64-byte segments on the HBM side) measured 12 % slower, 2^20 as 512 x 2048 20 % slower
 	VKFFT_FU2(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
 	VKFFT_FU(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
 	VKFFT_FU2(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
 	VKFFT_FU(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
-	// 2^21 = 2048 x 1024, 2^22 = 2048 x 2048: 2048-point column tiles are 8 columns wide (147 KiB of LDS; 64-byte segments on the HBM side)
+	// 2^21 = 1024 x 2048, 2^22 = 2048 x 2048: 2048-point column tiles are 8 columns wide (147 KiB of LDS; 64-byte segments on the HBM side)
+	// (2^21 as 1024 x 2048 — the wide 16-column tiles on the HBM read side — measured 10 % above 2048 x 1024)
+	VKFFT_FUT(float, false, 5, 5, 0, 16, 5, 3, 3, 8, 0),
 	VKFFT_FUT(float, false, 5, 3, 3, 8, 5, 5, 0, 16, 0),
 	VKFFT_FUT(float, false, 5, 3, 3, 8, 5, 3, 3, 8, 0),
 	// fp64: 16-byte elements, 16 columns = 256-byte segments.  2^14 = 128 x 128, 2^15 = 128 x 256, 2^16 = 256 x 256, 2^17 = 256 x 512
