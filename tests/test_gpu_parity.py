@@ -100,6 +100,30 @@ def test_fused_fourstep_under_dependency_pressure(product_lib, monkeypatch, k, e
     app.delete()
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("k,queues", [(18, 3), (18, 5), (15, 3), (20, 6)])
+def test_fused_fourstep_unbalanced_queues_many_launches(product_lib, monkeypatch, k, queues):
+    """queue counts that do not divide the 8 XCDs: queues drain at different times and most workgroups finish on a queue that is not
+    theirs (regression: before every workgroup barrier also waited for the wave's own LDS writes, waves occasionally read the previous
+    ticket after a queue switch — 2-29 wrong round trips in 300 launch pairs with this configuration, a few ppm of relative error each)"""
+    import torch
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_LAG", "1"); monkeypatch.setenv("VKFFT_MI355X_FUSED_RING", "4")
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_QUEUES", str(queues))
+    N = 1 << k; B = (1 << 27) // N
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    x = torch.empty(2 * N * B, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    buf = x.clone()
+    app = api.App([N], B, buffer_ptr=buf.data_ptr(), normalize=True, lib=product_lib)
+    nx = torch.linalg.norm(x)
+    worst = 0.0
+    for _ in range(120):
+        buf.copy_(x)
+        app.forward(); app.inverse()
+        worst = max(worst, (torch.linalg.norm(buf - x) / nx).item())
+    app.delete()
+    assert worst < 2e-6, (k, queues, worst)
+
+
 def test_config1_vkfft_sample0_plumbing(run, oracle):
     """BASELINE config 1: N=4096, batch 1, forward+inverse, data = the reference's unseeded rand() stream."""
     v = oracle.rand_sample(2 * 4096)

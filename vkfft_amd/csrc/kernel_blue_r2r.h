@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 		pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], bh[m]));
-		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); } // the exchange buffer is reused
+		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); } // the exchange buffer is reused
 		pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
 #pragma unroll
 		for (int m = 0; m < EH; m++) {
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 			if (p.swapOut) y = cswap(y);
 			if (pos < n) post_scatter<T>(p, io, pos, y, 0, nat, op_resolve<POST>(p.postOp), p.outLen); // applies the scale
 		}
-		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); }
+		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); }
 	}
 }
 

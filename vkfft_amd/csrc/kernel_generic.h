@@ -403,7 +403,7 @@ __device__ inline void run_subfft(const PassParams& p, cx<T>*& cur, cx<T>*& oth,
 			case 16: run_substage<16, T>(p, si, cur, oth, U, tid, nthr); break;
 			default: break;
 		}
-		__syncthreads();
+		VKFFT_SYNC();
 		cx<T>* t = cur; cur = oth; oth = t;
 	}
 }
@@ -436,7 +436,7 @@ __device__ inline cx<T>* run_stage_rader_fft(const PassParams& p, const StageDes
 		B[q * U + u] = x;
 		if (q == 0) tail[u] = A[(t + (t >> ps)) * Tp + f];
 	}
-	__syncthreads();
+	VKFFT_SYNC();
 	cx<T>* cur = B; cx<T>* oth = A;
 	run_subfft<T>(p, cur, oth, U, tid, nthr);
 	// (2) pointwise product with FFT(b)/(P-1); x_0 enters the zero bin so that every convolution output carries it;
@@ -449,7 +449,7 @@ __device__ inline cx<T>* run_stage_rader_fft(const PassParams& p, const StageDes
 		if (m == 0) { const cx<T> x0 = tail[u]; tail[u] = cadd(x0, a); c = cadd(c, x0); }
 		cur[m * U + u] = cswap(c);
 	}
-	__syncthreads();
+	VKFFT_SYNC();
 	run_subfft<T>(p, cur, oth, U, tid, nthr);
 	// (3) scatter X_{g^-m} = conv_m (+x_0 already inside) and X_0 to the Stockham output positions in the other buffer
 	for (uint32_t v = tid; v < P * U; v += nthr) {
@@ -464,7 +464,7 @@ __device__ inline cx<T>* run_stage_rader_fft(const PassParams& p, const StageDes
 		const uint32_t a = qq * S * P + s + k * S;
 		oth[(a + (a >> ps)) * Tp + f] = val;
 	}
-	__syncthreads();
+	VKFFT_SYNC();
 	return oth;
 }
 
@@ -509,7 +509,7 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 			bufA[(pos + (pos >> ps)) * Tp + f] = v;
 		}
 	}
-	__syncthreads();
+	VKFFT_SYNC();
 
 	cx<T>* src = bufA;
 	cx<T>* dst = bufB;
@@ -536,7 +536,7 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 				case 16: run_stage<16, T>(p, sd, si, src, dst, tid, nthr); break;
 				default: break;
 			}
-			__syncthreads();
+			VKFFT_SYNC();
 			cx<T>* tmp = src; src = dst; dst = tmp;
 		}
 		if (rep == 0 && reps == 2) {
@@ -551,7 +551,7 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 				const uint32_t li = (pos + (pos >> ps)) * Tp + f;
 				src[li] = cswap(cmul(src[li], bh[pos]));
 			}
-			__syncthreads();
+			VKFFT_SYNC();
 		}
 	}
 

@@ -127,7 +127,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 				if (k != 0 && 2 * k != Hc) ldsf[km] = p.swapIn ? cswap(zm) : zm;
 			}
 		}
-		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
 #pragma unroll
 		for (int b = 0; b < P; b++) {
 			const uint32_t t = opfft_bfly<NB, TPF, P, PAIR>(tau, b);
@@ -136,7 +136,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 				for (int i = 0; i < R; i++) x[b][i] = ldsf[t + i * NB];
 			}
 		}
-		if constexpr (!last) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); } // z is consumed before stage 0 overwrites the buffer
+		if constexpr (!last) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); } // z is consumed before stage 0 overwrites the buffer
 	} else if constexpr (first && PRE == OP_DCT3H_PRE) {
 		// half-length DCT/DST-III: the Hermitian spectrum V_k = e^{+i pi k/2N}(x_k - i x_{N-k}), k = 0..H, is built ONCE in LDS
 		// (every real read once, one table entry per k), then each FFT input is the even C2R fold of V_n and V_{H-n}.  Gathering
@@ -151,7 +151,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 			const uint32_t k = tau + b * TPF;
 			if (k <= H) ldsf[k] = cmul(cconj(table_load<T>(p.aux, k)), cx<T>{X(k), -X(Nr - k)});
 		}
-		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
 #pragma unroll
 		for (int b = 0; b < P; b++) {
 			const uint32_t t = opfft_bfly<NB, TPF, P, PAIR>(tau, b);
@@ -166,7 +166,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 				}
 			}
 		}
-		if constexpr (!last) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); } // V is consumed before stage 0 overwrites the buffer
+		if constexpr (!last) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); } // V is consumed before stage 0 overwrites the buffer
 	} else if constexpr (first && PRE == OP_C2R_EVEN_PRE && ROW) {
 		// C2R even fold on unit-stride rows, pairs (k, H-k) together (H = N): X_k and X_{H-k} are loaded ONCE, one table entry, and give
 		// both z_k = s + i d and z_{H-k} = conj(s - i d), s = X_k + conj(X_{H-k}), d = conj(w_k)(X_k - conj(X_{H-k})); the packed sequence z
@@ -186,7 +186,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 				if (k != 0 && 2 * k != (uint32_t)N) ldsf[(uint32_t)N - k] = p.swapIn ? cswap(zm) : zm;
 			}
 		}
-		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
 #pragma unroll
 		for (int b = 0; b < P; b++) {
 			const uint32_t t = opfft_bfly<NB, TPF, P, PAIR>(tau, b);
@@ -195,7 +195,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 				for (int i = 0; i < R; i++) x[b][i] = ldsf[t + i * NB];
 			}
 		}
-		if constexpr (!last) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); } // z is consumed before stage 0 overwrites the buffer
+		if constexpr (!last) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); } // z is consumed before stage 0 overwrites the buffer
 	} else {
 #pragma unroll
 		for (int b = 0; b < P; b++) {
@@ -212,7 +212,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 		}
 	}
 	if constexpr (!first && (!last || staged)) { // all inputs are in registers before the buffer is overwritten
-		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
 	}
 #pragma unroll
 	for (int b = 0; b < P; b++) {
@@ -273,13 +273,13 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 		}
 	}
 	if constexpr (!last) {
-		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
 		op_stage<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, PRE, POST, ROW, TRANS>(ldsf, io, glut, tau, waveOnly, p, colIdx, nat);
 	} else if constexpr (staged && !TRANS && POST == OP_R2C_EVEN_POST && ROW) {
 		// R2C even split on unit-stride rows, pairs (k, H-k) together (H = N: complex length): one pair of LDS reads and ONE table entry give
 		// both X[k] = (s - i d)/2 and X[H-k] = conj(s + i d)/2, s = Z_k + conj(Z_{H-k}), d = w_k (Z_k - conj(Z_{H-k})), w_{H-k} = -conj(w_k)
 		// (reference: vkFFT_R2C_even_decomposition.h:181-230 computes every output on its own).  k = 0 yields X[0] and X[H].
-		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
 		constexpr int HP = N / 2 + 1, PH = (HP + TPF - 1) / TPF; // pairs k = 0 .. N/2
 		const T hs = (T)0.5 * (T)p.scale;
 		const GBuf gw = make_gbuf(p.aux);
@@ -299,7 +299,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 		// half-length DCT/DST-II post-map on unit-stride rows, pairs (k, H-k) together (H = N): 2V_k = s - i d and 2V_{H-k} = conj(s + i d) from one
 		// pair of LDS reads and one split twiddle (see the R2C split above), then y[k] = Re(c^k 2V_k), y[Nr-k] = -Im(c^k 2V_k) and the same for H-k
 		// (reference vkFFT_R2R.h:784 runs a full-length complex FFT instead)
-		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
 		constexpr int HP = N / 2 + 1, PH = (HP + TPF - 1) / TPF;
 		constexpr uint32_t Hc = (uint32_t)N, Nr = 2u * (uint32_t)N;
 		const bool dst = p.postOp == OP_DST2H_POST;
@@ -323,7 +323,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 			}
 		}
 	} else if constexpr (staged && !TRANS) {
-		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
 		constexpr int PO = (N + 1 + TPF - 1) / TPF; // R2C even split: N + 1 outputs from the length-N complex FFT
 		auto rd = [&](uint32_t a) { return ldsf[a]; };
 #pragma unroll
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	if constexpr (TRANS) {
 		// first Four-Step pass: every column leaves as ONE contiguous run (Y^T[m][k0], reference vkFFT_ReadWrite.h:1405-1424);
 		// the tile is read back from LDS with lanes along the column so that the stores are contiguous, twiddle applied on the way
-		__syncthreads();
+		VKFFT_SYNC();
 		constexpr int NT = TPF * FPW, TOT = FPW * N, PT = (TOT + NT - 1) / NT;
 		constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 		const uint32_t remain = p.dim[0].count - f0, nvalid = remain < (uint32_t)FPW ? remain : (uint32_t)FPW;

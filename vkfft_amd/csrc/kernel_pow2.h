@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 		pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], bh[m]));
-		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); } // the exchange buffer is reused
+		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); } // the exchange buffer is reused
 		pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
 #pragma unroll
 		for (int m = 0; m < EH; m++) {
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 			if (sc != (T)1) x = cscale(x, sc);
 			gb_store<T>(gout, tau + m * TPF < n ? laneOut : kGbInvalid, (uint32_t)(m * TPF) * ES, x);
 		}
-		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads(); }
+		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); }
 	}
 }
 
@@ -189,10 +189,10 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 		for (int m = 0; m < E; m++) gb_store<T>(gout, laneOut, m * stepOut, v[m]);
 	} else {
 		// transposed store: column c becomes the contiguous run out[c*dim0.outStride + k*outStrideJ], lanes along k
-		if constexpr (SCH::NS > 1) __syncthreads(); // the last exchange's reads are complete
+		if constexpr (SCH::NS > 1) VKFFT_SYNC(); // the last exchange's reads are complete
 #pragma unroll
 		for (int m = 0; m < E; m++) lds[(tau + m * TPF) * TCP + c] = v[m];
-		__syncthreads();
+		VKFFT_SYNC();
 		const uint32_t nvalid = p.dim[0].count - col0 < (uint32_t)TC ? p.dim[0].count - col0 : (uint32_t)TC;
 #pragma unroll
 		for (int i = 0; i < E; i++) {
@@ -252,10 +252,10 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
 		pow2_col_twiddle<T, LOGE, TPF>(v, p, tau, col0 + c);
 		// transposed store: column c becomes the contiguous run T[col0 + c][.]
-		if constexpr (SCH::NS > 1) __syncthreads();
+		if constexpr (SCH::NS > 1) VKFFT_SYNC();
 #pragma unroll
 		for (int m = 0; m < E; m++) lds[(tau + m * TPF) * TCP + c] = v[m];
-		__syncthreads();
+		VKFFT_SYNC();
 #pragma unroll
 		for (int i = 0; i < E; i++) {
 			const uint32_t idx = tid + i * NT;
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], gb_load<T>(gbh, bhLane, m * bhStep)));
-		if constexpr (SCH::NS > 1) __syncthreads(); // the exchange buffer is reused
+		if constexpr (SCH::NS > 1) VKFFT_SYNC(); // the exchange buffer is reused
 		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
 #pragma unroll
 		for (int m = 0; m < E; m++) gb_store<T>(gout, lane, m * step, cswap(v[m]));
@@ -298,10 +298,10 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 			const uint32_t k = idx % L, cc = idx / L;
 			lds[k * TCP + cc] = gb_load<T>(gin, cc < nvalid ? (cc * (uint32_t)p.dim[0].inStride + k) * ES : kGbInvalid, 0);
 		}
-		__syncthreads();
+		VKFFT_SYNC();
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = cswap(lds[(tau + m * TPF) * TCP + c]);
-		if constexpr (SCH::NS > 1) __syncthreads(); // the tile is in registers before the exchanges overwrite it
+		if constexpr (SCH::NS > 1) VKFFT_SYNC(); // the tile is in registers before the exchanges overwrite it
 		pow2_col_twiddle<T, LOGE, TPF>(v, p, tau, col0 + c); // swap(u conj(w)) = swap(u) w: the forward table serves the inverse
 		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
 		const GBuf gch = make_gbuf(p.aux3);

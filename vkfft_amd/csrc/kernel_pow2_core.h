@@ -125,7 +125,7 @@ __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const TW lut, const ui
 		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, TCP, TW, CPT>(v, ldsf, lut, tau, waveOnly);
 		return;
 #endif
-		if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
 #pragma unroll
 		for (int m = 0; m < E; m++) {
 			const uint32_t a = tau + m * TPF;
@@ -133,7 +133,7 @@ __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const TW lut, const ui
 			else { const cx2<T> q = *(const cx2<T>*)(ldsf + pow2_slot<TCP, LOGE>(a)); v[m] = q.a; v[E + m] = q.b; }
 		}
 		if constexpr (SI + 2 < SCH::NS) { // another exchange will overwrite the buffer: all reads must be done first
-			if (waveOnly) VKFFT_WAVE_SYNC(); else __syncthreads();
+			if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
 		}
 		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, TCP, TW, CPT>(v, ldsf, lut, tau, waveOnly);
 	}

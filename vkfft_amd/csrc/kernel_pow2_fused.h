@@ -73,7 +73,7 @@ __device__ inline void fused_wait(uint32_t* ctr, uint32_t target) {
 	if (threadIdx.x == 0) {
 		while (VKFFT_ATOMIC_LOAD_U32(ctr) < target) VKFFT_SLEEP();
 	}
-	__syncthreads();
+	VKFFT_SYNC();
 }
 
 // workgroups of a fused kernel that fit one CU (LDS and wave slots), at most 4: fixes the register budget through __launch_bounds__
@@ -160,14 +160,14 @@ pow2_fused_kernel(const FusedParams p) {
 #define VKFFT_PROF(i) do { } while (0)
 #endif
 	for (;;) {
-		__syncthreads(); // S1: ticket visible; exchange buffer free again
+		VKFFT_SYNC(); // S1: ticket visible; exchange buffer free again
 		VKFFT_PROF(0);
 		const uint32_t t = sTicket[it];
 		if (t >= totq) {
 			// this queue is drained: help the next one, leave when every queue is (completion must not depend on where workgroups run)
 			if (++tried >= Q) break;
 			VKFFT_VMEM_DRAIN();
-			__syncthreads();
+			VKFFT_SYNC();
 			q = q + 1u == Q ? 0u : q + 1u;
 			Cq = (p.C + Q - 1u - q) / Q;
 			totq = Cq ? (Cq + p.D) << logTPC : 0u;
@@ -226,7 +226,7 @@ pow2_fused_kernel(const FusedParams p) {
 					if (dA != kNone) nfA = VKFFT_ATOMIC_LOAD_U32(p.ctr + dA); // consumed at the end of this iteration
 					if (dB != kNone) nfB = VKFFT_ATOMIC_LOAD_U32(p.ctr + dB);
 				}
-				__syncthreads(); // S2
+				VKFFT_SYNC(); // S2
 				VKFFT_PROF(1);
 				if (tid == 0 && pending != kNone) { (void)VKFFT_ATOMIC_ADD_U32(p.ctr + pending, 1u); pending = kNone; }
 				if (hasA && !okA) { fused_wait(p.ctr + depA(s), TPC); VKFFT_PROF(5); }
@@ -242,13 +242,13 @@ pow2_fused_kernel(const FusedParams p) {
 						for (int cc = 0; cc < CPT; cc++) pow2_fs_twiddle<T, SA::LOGE, TPFA>(v + cc * EA, gtw, p.fsLoBits, tau, col0 + c + cc);
 					}
 					VKFFT_PROF(9);
-					if constexpr (SA::NS > 1) __syncthreads(); // the last exchange's reads are complete
+					if constexpr (SA::NS > 1) VKFFT_SYNC(); // the last exchange's reads are complete
 #pragma unroll
 					for (int m = 0; m < EA; m++) {
 						if constexpr (CPT == 1) lds[(tau + m * TPFA) * TCPA + c] = v[m];
 						else *(cx2<T>*)(lds + (tau + m * TPFA) * TCPA + c) = cx2<T>{v[m], v[EA + m]};
 					}
-					__syncthreads();
+					VKFFT_SYNC();
 					VKFFT_PROF(10);
 				}
 			}
@@ -284,7 +284,7 @@ pow2_fused_kernel(const FusedParams p) {
 				else gb_load2_x<T, AUX_SC>(gsB, (MODE & 16) ? kGbInvalid : laneB, m * stepB, vB[m], vB[EB + m]);
 			}
 			VKFFT_VMEM_DRAIN(); // the tile is in registers; the A part's ring stores are acknowledged
-			__syncthreads();    // S3: ... in every wave
+			VKFFT_SYNC();    // S3: ... in every wave
 			VKFFT_PROF(3);
 			if (tid == 0) {
 				(void)VKFFT_ATOMIC_ADD_U32(p.ctr + doneB + cB, 1u); // release the ring slot
@@ -319,13 +319,13 @@ pow2_fused_kernel(const FusedParams p) {
 #endif
 	// ---- exit: publish the last A tile, then the last workgroup out resets the counters for the next launch
 	VKFFT_VMEM_DRAIN();
-	__syncthreads();
+	VKFFT_SYNC();
 	if (tid == 0) {
 		fused_publish_all<MODE>(p.ctr, pending, flushing);
 		VKFFT_VMEM_DRAIN(); // this workgroup's counter updates have been performed
 		sOkA[0] = VKFFT_ATOMIC_ADD_U32(p.ctr + kFusedCtrExit, 1u) == gridDim.x - 1u;
 	}
-	__syncthreads();
+	VKFFT_SYNC();
 	if (sOkA[0]) {
 		for (uint32_t i = tid; i < kFusedCtrDone + 2u * p.C; i += NT) p.ctr[i] = 0u;
 	}

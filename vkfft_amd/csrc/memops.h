@@ -8,6 +8,7 @@
 
 #if defined(VKFFT_HOSTEMU)
 #define VKFFT_WAVE_SYNC() hostemu::wave_sync()
+#define VKFFT_SYNC() __syncthreads()
 #define VKFFT_OPAQUE_ZERO(z) uint32_t z = 0
 #define VKFFT_SCHED_FENCE() do { } while (0)
 #else
@@ -16,6 +17,11 @@
 #define VKFFT_OPAQUE_ZERO(z) uint32_t z = 0; asm volatile("" : "+s"(z))
 // keeps the instruction scheduler from hoisting every load of an unrolled gather loop above the first use (register pressure)
 #define VKFFT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Workgroup barrier that first waits for this wave's own LDS operations.  __syncthreads() alone fences the "local" address space only,
+// for which the compiler emits no wait (it takes LDS operations of all waves as totally ordered): at the back edge of the fused kernel's
+// persistent loop the barrier then followed two ds_writes of thread 0 directly, and on MI355X other waves occasionally passed the barrier
+// and read the previous contents (a stale ticket: 2-29 wrong transforms in 300 under unbalanced queues, none with the wait).
+#define VKFFT_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 // orders this wave's LDS writes before its later LDS reads without an s_barrier
 #define VKFFT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #endif
