@@ -44,6 +44,74 @@ int ref_transform(int kind, int fftdim, const uint64_t* size, uint64_t batch, in
     return (int)r;
 }
 
+// zero padding with the reference (performZeropadding / fft_zeropad_left / fft_zeropad_right / frequencyZeroPadding): as ref_transform
+int ref_transform_zeropad(int kind, int fftdim, const uint64_t* size, uint64_t batch, int dp, int inverse, const uint64_t* flags,
+                          const uint64_t* left, const uint64_t* right, int frequency, void* data, uint64_t nbytes) {
+    hipError_t e = hipInit(0); if (e != hipSuccess) return -1;
+    hipDevice_t dev; if (hipDeviceGet(&dev, 0) != hipSuccess) return -2;
+    hipSetDevice(0);
+    void* buf = nullptr; if (hipMalloc(&buf, nbytes) != hipSuccess) return -3;
+    hipMemcpy(buf, data, nbytes, hipMemcpyHostToDevice);
+    VkFFTConfiguration cfg = {}; VkFFTApplication app = {};
+    cfg.FFTdim = fftdim; for (int i = 0; i < fftdim; i++) cfg.size[i] = size[i];
+    cfg.numberBatches = batch; cfg.device = &dev; cfg.buffer = &buf; uint64_t bs = nbytes; cfg.bufferSize = &bs;
+    cfg.doublePrecision = dp;
+    if (kind == 1) cfg.performR2C = 1;
+    if (kind >= 11 && kind <= 14) cfg.performDCT = kind - 10;
+    for (int i = 0; i < fftdim; i++) { cfg.performZeropadding[i] = flags[i]; cfg.fft_zeropad_left[i] = left[i]; cfg.fft_zeropad_right[i] = right[i]; }
+    cfg.frequencyZeroPadding = frequency;
+    VkFFTResult r = initializeVkFFT(&app, cfg);
+    if (r != VKFFT_SUCCESS) { hipFree(buf); return (int)r; }
+    VkFFTLaunchParams lp = {};
+    r = VkFFTAppend(&app, inverse ? 1 : -1, &lp);
+    hipDeviceSynchronize();
+    hipMemcpy(data, buf, nbytes, hipMemcpyDeviceToHost);
+    deleteVkFFT(&app); hipFree(buf);
+    return (int)r;
+}
+
+// convolution with the reference (sample_50/51/52 call sequence): a kernelConvolution plan transforms `kernel` (kernelSystems systems
+// per kernel, numKernels kernels), then a performConvolution plan convolves `data` in place.  Host buffers in the library's layouts.
+// ms_out (optional): average time of one convolution append over `iters` runs (the data is convolved repeatedly: timing only).
+int ref_convolution(int fftdim, const uint64_t* size, int r2c, int dp, uint64_t coordinates, uint64_t matrix, uint64_t numKernels,
+                    int symmetric, int conjugate, int crossPower, uint64_t kernelSystems, void* kernel, uint64_t kbytes,
+                    void* data, uint64_t dbytes, double* ms_out, int iters) {
+    hipError_t e = hipInit(0); if (e != hipSuccess) return -1;
+    hipDevice_t dev; if (hipDeviceGet(&dev, 0) != hipSuccess) return -2;
+    hipSetDevice(0);
+    void *kbuf = nullptr, *dbuf = nullptr;
+    if (hipMalloc(&kbuf, kbytes) != hipSuccess || hipMalloc(&dbuf, dbytes) != hipSuccess) return -3;
+    hipMemcpy(kbuf, kernel, kbytes, hipMemcpyHostToDevice);
+    hipMemcpy(dbuf, data, dbytes, hipMemcpyHostToDevice);
+    VkFFTConfiguration cfg = {}; VkFFTApplication appK = {}, appC = {};
+    cfg.FFTdim = fftdim; for (int i = 0; i < fftdim; i++) cfg.size[i] = size[i];
+    cfg.device = &dev; cfg.doublePrecision = dp; cfg.normalize = 1; cfg.performR2C = r2c;
+    cfg.kernelConvolution = 1; cfg.coordinateFeatures = kernelSystems; cfg.numberBatches = numKernels;
+    cfg.buffer = &kbuf; uint64_t kb = kbytes; cfg.bufferSize = &kb;
+    VkFFTResult r = initializeVkFFT(&appK, cfg);
+    if (r != VKFFT_SUCCESS) { hipFree(kbuf); hipFree(dbuf); return (int)r; }
+    VkFFTLaunchParams lp = {};
+    r = VkFFTAppend(&appK, -1, &lp);
+    hipDeviceSynchronize();
+    VkFFTConfiguration cc = cfg;
+    cc.kernelConvolution = 0; cc.performConvolution = 1; cc.matrixConvolution = matrix; cc.coordinateFeatures = coordinates;
+    cc.numberBatches = 1; cc.numberKernels = numKernels; cc.symmetricKernel = symmetric; cc.conjugateConvolution = conjugate;
+    cc.crossPowerSpectrumNormalization = crossPower;
+    cc.kernel = &kbuf; cc.kernelSize = &kb; cc.buffer = &dbuf; uint64_t db = dbytes; cc.bufferSize = &db;
+    if (r == VKFFT_SUCCESS) r = initializeVkFFT(&appC, cc);
+    if (r == VKFFT_SUCCESS) r = VkFFTAppend(&appC, -1, &lp);
+    hipDeviceSynchronize();
+    if (r == VKFFT_SUCCESS) hipMemcpy(data, dbuf, dbytes, hipMemcpyDeviceToHost);
+    if (r == VKFFT_SUCCESS && ms_out && iters > 0) {
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < iters; i++) VkFFTAppend(&appC, -1, &lp);
+        hipDeviceSynchronize();
+        *ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
+    }
+    deleteVkFFT(&appC); deleteVkFFT(&appK); hipFree(kbuf); hipFree(dbuf);
+    return (int)r;
+}
+
 // sample-0 protocol on a device buffer of `nbytes` (random data): returns ms per FFT+iFFT pair.
 double ref_bench_pair_ms(int fftdim, const uint64_t* size, uint64_t batch, int dp, int kind, uint64_t nbytes,
                          int num_iter, uint64_t* uploads_out) {

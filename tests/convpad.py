@@ -1,0 +1,163 @@
+"""Convolution and zero-padding cases shared by the CPU-emulator and the GPU tests: the library through the C-ABI against
+numpy.  The expected values restate the reference's definitions: element-wise product of the kernel spectra with the spectra of the input
+systems (vkFFT_Convolution.h:352-390), zero padding = the range [left, right) of an axis is taken as zero (vkFFT_Zeropad.h:28)."""
+import numpy as np
+from helpers import rel_l2
+from vkfft_amd import api
+
+
+def _kernel_index(j, l, m, symmetric):
+    if not symmetric:
+        return j * m + l
+    return l * m - l * l + j if l < j else j * m - j * j + l
+
+
+def conv_case(run, shape, *, m=1, cf=1, nk=1, nb=1, symmetric=False, conjugate=0, cross=False, r2c=False, dp=False, seed=0):
+    """kernel plan (kernelConvolution) on the kernel buffer, then a performConvolution plan on the data; returns the relative error"""
+    rng = np.random.default_rng(seed)
+    rt = np.float64 if dp else np.float32
+    ct = np.complex128 if dp else np.complex64
+    dims = tuple(reversed(shape))  # numpy order: slowest first
+    nsys = m if m > 1 else cf
+    ksys = (m * (m + 1) // 2 if symmetric else m * m) if m > 1 else cf
+    if r2c:
+        nx = shape[0]
+        pad = dims[:-1] + (nx + 2,)
+        def to_buf(a):  # real systems -> in-place padded layout
+            out = np.zeros(a.shape[:-len(dims)] + pad, rt)
+            out[..., :nx] = a
+            return out
+        kern = rng.uniform(-1, 1, (nk, ksys) + dims).astype(rt)
+        data = rng.uniform(-1, 1, (nb, nsys) + dims).astype(rt)
+        kbuf, dbuf = to_buf(kern), np.zeros((max(nb, nk), nsys) + pad, rt)
+        dbuf[:nb] = to_buf(data)
+        fwd = lambda a: np.fft.rfftn(a.astype(np.float64), axes=tuple(range(-len(dims), 0)))
+        inv = lambda a: np.fft.irfftn(a, s=dims, axes=tuple(range(-len(dims), 0)))
+    else:
+        kern = (rng.uniform(-1, 1, (nk, ksys) + dims) + 1j * rng.uniform(-1, 1, (nk, ksys) + dims)).astype(ct)
+        data = (rng.uniform(-1, 1, (nb, nsys) + dims) + 1j * rng.uniform(-1, 1, (nb, nsys) + dims)).astype(ct)
+        kbuf, dbuf = kern.copy(), np.zeros((max(nb, nk), nsys) + dims, ct)
+        dbuf[:nb] = data
+        fwd = lambda a: np.fft.fftn(a.astype(np.complex128), axes=tuple(range(-len(dims), 0)))
+        inv = lambda a: np.fft.ifftn(a, axes=tuple(range(-len(dims), 0)))
+    # expected
+    K, X = fwd(kern), fwd(data)
+    if conjugate == 1:
+        X = np.conj(X)
+    if conjugate == 2:
+        K = np.conj(K)
+    Y = np.zeros((nk, nb, nsys) + X.shape[2:], np.complex128)
+    for f in range(nk):
+        for b in range(nb):
+            if m > 1:
+                for j in range(m):
+                    for l in range(m):
+                        Y[f, b, j] += K[f, _kernel_index(j, l, m, symmetric)] * X[b, l]
+            else:
+                Y[f, b] = K[f] * X[b]
+    if cross:
+        Y = Y / np.abs(Y)
+    want = inv(Y)
+    # library
+    hk, pk = run._alloc(kbuf)
+    hd, pd = run._alloc(dbuf)
+    common = dict(dp=dp, r2c=r2c, lib=run.lib, normalize=True)
+    ka = api.App(list(shape), nk, buffer_ptr=pk, coordinateFeatures=ksys, kernelConvolution=1, **common)
+    ka.forward()
+    ca = api.App(list(shape), nb, buffer_ptr=pd, coordinateFeatures=nsys, performConvolution=1, matrixConvolution=m, numberKernels=nk,
+                 symmetricKernel=int(symmetric), conjugateConvolution=conjugate, crossPowerSpectrumNormalization=int(cross), kernel=pk, **common)
+    ca.forward()
+    got = run._fetch(hd, rt if r2c else ct).reshape(dbuf.shape)
+    ka.delete(); ca.delete()
+    if r2c:
+        got = got[..., : shape[0]]
+    got = got[: nk * nb].reshape((nk, nb, nsys) + dims) if nk > 1 or nb > 1 else got[:1].reshape((1, 1, nsys) + dims)
+    return rel_l2(got, want)
+
+
+def zeropad_case(run, shape, pads, *, frequency=False, r2c=False, dct=0, dp=False, batch=2, seed=0):
+    """pads: {axis: (left, right)}.  The padded range holds garbage on entry; the transform must behave as if it held zeros."""
+    rng = np.random.default_rng(seed)
+    rt = np.float64 if dp else np.float32
+    ct = np.complex128 if dp else np.complex64
+    dims = tuple(reversed(shape))
+    nd = len(dims)
+    ax = tuple(range(-nd, 0))
+    left = [0] * 4; right = [0] * 4; flag = [0] * 4
+    for a, (l, r) in pads.items():
+        left[a], right[a], flag[a] = l, r, 1
+    def mask(sh):  # zero the padded ranges of an array whose last nd axes are the transform axes (numpy order)
+        mk = np.ones(sh, bool)
+        for a, (l, r) in pads.items():
+            idx = [slice(None)] * len(sh)
+            idx[len(sh) - 1 - a] = slice(l, r)
+            mk[tuple(idx)] = False
+        return mk
+    kw = dict(dp=dp, lib=run.lib, performZeropadding=flag, fft_zeropad_left=left, fft_zeropad_right=right, frequencyZeroPadding=int(frequency))
+    if dct:
+        import scipy.fft as sf
+        x = rng.uniform(-1, 1, (batch,) + dims).astype(rt)
+        want = sf.dctn(np.where(mask(x.shape), x, 0).astype(np.float64), type=dct, axes=ax)
+        h, ptr = run._alloc(x)
+        app = api.App(list(shape), batch, buffer_ptr=ptr, dct=dct, **kw)
+        app.forward(); got = run._fetch(h, rt).reshape(x.shape); app.delete()
+        return rel_l2(got, want)
+    if r2c:
+        nx = shape[0]
+        if not frequency:
+            x = rng.uniform(-1, 1, (batch,) + dims).astype(rt)
+            buf = rng.uniform(-1, 1, (batch,) + dims[:-1] + (nx + 2,)).astype(rt)
+            buf[..., :nx] = x
+            want = np.fft.rfftn(np.where(mask(x.shape), x, 0).astype(np.float64), axes=ax)
+            h, ptr = run._alloc(buf)
+            app = api.App(list(shape), batch, buffer_ptr=ptr, r2c=True, **kw)
+            app.forward(); got = run._fetch(h, ct).reshape(want.shape); app.delete()
+            return rel_l2(got, want)
+        sp = np.fft.rfftn(rng.uniform(-1, 1, (batch,) + dims), axes=ax)
+        hs = sp.shape
+        def fmask():
+            mk = np.ones(hs, bool)
+            for a, (l, r) in pads.items():
+                idx = [slice(None)] * len(hs)
+                idx[len(hs) - 1 - a] = slice(l, min(r, hs[len(hs) - 1 - a]))
+                mk[tuple(idx)] = False
+            return mk
+        want = np.fft.irfftn(np.where(fmask(), sp, 0), s=dims, axes=ax) * np.prod(dims)
+        h, ptr = run._alloc(sp.astype(ct))
+        app = api.App(list(shape), batch, buffer_ptr=ptr, r2c=True, **kw)
+        app.inverse(); got = run._fetch(h, rt).reshape((batch,) + dims[:-1] + (nx + 2,))[..., :nx]; app.delete()
+        return rel_l2(got, want)
+    x = (rng.uniform(-1, 1, (batch,) + dims) + 1j * rng.uniform(-1, 1, (batch,) + dims)).astype(ct)
+    xz = np.where(mask(x.shape), x, 0).astype(np.complex128)
+    want = np.fft.ifftn(xz, axes=ax) * np.prod(dims) if frequency else np.fft.fftn(xz, axes=ax)
+    h, ptr = run._alloc(x)
+    app = api.App(list(shape), batch, buffer_ptr=ptr, **kw)
+    app.append(frequency); got = run._fetch(h, ct).reshape(x.shape); app.delete()
+    return rel_l2(got, want)
+
+
+CONV_CASES = [
+    dict(shape=(64,), m=1, cf=1),
+    dict(shape=(96,), m=1, cf=3, nb=2),
+    dict(shape=(1 << 15,), m=3, seed=3),                                # two-pass power of two (the fused kernel on the device)
+    dict(shape=(32, 16), m=2, symmetric=True),
+    dict(shape=(16, 12, 10), m=3),
+    dict(shape=(32, 32), m=1, cf=2, nk=2, r2c=True),                    # the reference's sample 52
+    dict(shape=(32, 8, 4), m=3, r2c=True),                              # sample 51 without the padding
+    dict(shape=(128,), m=2, conjugate=1),
+    dict(shape=(128,), m=2, conjugate=2, dp=True),
+    dict(shape=(60,), m=1, cf=2, cross=True),
+    dict(shape=(24, 20), m=3, symmetric=True, nk=3, dp=True),
+]
+ZEROPAD_CASES = [
+    dict(shape=(64,), pads={0: (32, 64)}),
+    dict(shape=(32, 16), pads={0: (16, 32), 1: (8, 16)}),
+    dict(shape=(16, 16, 16), pads={0: (8, 16), 1: (8, 16), 2: (8, 16)}),  # the reference's sample 4 at a small size
+    dict(shape=(30, 20), pads={1: (5, 17)}, dp=True),
+    dict(shape=(64, 8), pads={0: (32, 64)}, r2c=True),
+    dict(shape=(32, 32, 4), pads={0: (16, 32), 1: (16, 32)}, r2c=True),
+    dict(shape=(64,), pads={0: (20, 44)}, frequency=True),
+    dict(shape=(32, 16), pads={0: (9, 17), 1: (4, 13)}, frequency=True, r2c=True),  # (a range that keeps the spectrum Hermitian)
+    dict(shape=(40, 6), pads={0: (20, 40)}, dct=2),
+    dict(shape=(1 << 15,), pads={0: (1 << 14, 1 << 15)}, batch=3),
+]

@@ -52,7 +52,7 @@ def test_validation_order_matches_reference(product_lib):
     assert _init(lib, cfg)[0] == 1002                                    # INVALID_DEVICE
     dev = C.c_int(0); cfg.device = C.pointer(dev)
     assert _init(lib, cfg)[0] == 2002                                    # EMPTY_size
-    cfg.size[0] = 64; cfg.performConvolution = 1
+    cfg.size[0] = 64; cfg.halfPrecision = 1
     assert _init(lib, cfg)[0] == 4                                       # out-of-scope feature rejected
     assert lib.VkFFTAppend(None, -1, None) == 2015
 

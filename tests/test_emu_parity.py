@@ -91,7 +91,7 @@ def test_fourstep(run, oracle, N, passes):
     assert up == [passes]
 
 
-@pytest.mark.parametrize("shape,dp,passes", [((32, 32768), False, 2), ((8, 3 ** 10), True, 2), ((4, 4, 32768), False, 2)])
+@pytest.mark.parametrize("shape,dp,passes", [((32, 32768), False, 2), ((8, 3 ** 10), True, 2), ((4, 4, 32768), False, 2), ((8, 4096), False, 2), ((8, 3000), False, 2), ((8, 2048), False, 1)])
 def test_fourstep_along_strided_axis(run, oracle, shape, dp, passes):
     up = parity.check_c2c(run, oracle, shape, 1, dp, use_c_oracle=False)
     assert up[-1] == passes
@@ -229,7 +229,14 @@ def test_user_temp_buffer_too_small(emu_lib):
 
 def test_unsupported_features_are_rejected(emu_lib):
     buf = np.zeros(64, np.complex64)
-    for kw in (dict(performConvolution=1), dict(halfPrecision=1), dict(performZeropadding=[1, 0, 0, 0])):
+    for kw in (dict(performConvolution=1, matrixConvolution=9), dict(halfPrecision=1), dict(quadDoubleDoublePrecision=1), dict(bufferNum=2),
+               dict(performZeropadding=[1, 0, 0, 0], fft_zeropad_left=[10, 0, 0, 0], fft_zeropad_right=[80, 0, 0, 0]),  # range outside the axis
+               dict(performConvolution=1, numberKernels=2, numberBatches_override=2)):
+        if "numberBatches_override" in kw:
+            kw = dict(performConvolution=1, numberKernels=2)
+            with pytest.raises(api.VkFFTError):
+                api.App([64], 2, buffer_ptr=buf.ctypes.data, lib=emu_lib, **kw)
+            continue
         with pytest.raises(api.VkFFTError):
             api.App([64], 1, buffer_ptr=buf.ctypes.data, lib=emu_lib, **kw)
 

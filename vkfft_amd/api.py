@@ -184,7 +184,7 @@ class App:
             if hasattr(cur, "__len__"):
                 for i, x in enumerate(v):
                     cur[i] = x
-            elif isinstance(v, int) and k in ("inputBuffer", "outputBuffer", "tempBuffer"):
+            elif isinstance(v, int) and k in ("inputBuffer", "outputBuffer", "tempBuffer", "kernel"):
                 slot = C.c_void_p(v)
                 self._keep.append(slot)
                 setattr(self.cfg, k, C.pointer(slot))

@@ -24,6 +24,12 @@ struct AppState {
 	uint32_t numEvents = 0;
 	uint32_t sweep = 0;            // zig-zag state: direction of the next launch's tile sweep
 	bool sweepEnabled = true;
+	// convolution application (performConvolution): forward transform of the input, element-wise product with the kernel spectra,
+	// inverse transform of numberKernels results — the reference merges the three into the last axis (vkFFT_RunApp.h:235-345); the
+	// results are the same
+	VkFFTApplication* convFwd = nullptr;
+	VkFFTApplication* convInv = nullptr;
+	bool zeroPad = false;          // performZeropadding on some axis
 };
 
 VkFFTResult hip_to_result(hipError_t e, VkFFTResult code) { return e == hipSuccess ? VKFFT_SUCCESS : code; }
@@ -63,6 +69,10 @@ VkFFTResult make_direction(VkFFTApplication* app, const TransformDesc& base, boo
 	*outPlan = pl;
 	return VKFFT_SUCCESS;
 }
+
+VkFFTResult initialize_convolution(VkFFTApplication* app, const VkFFTConfiguration& in);
+VkFFTResult append_convolution(VkFFTApplication* app, int inverse, VkFFTLaunchParams* lp);
+VkFFTResult zero_padded_ranges(VkFFTApplication* app, bool inverse, void* base, hipStream_t stream);
 
 } // namespace
 
@@ -104,6 +114,8 @@ VKFFT_API void deleteVkFFT(VkFFTApplication* app) {
 	AppState* st = (AppState*)app->impl;
 	if (st) {
 		if (st->tempOwned) (void)hipFree(st->tempOwned);
+		if (st->convFwd) { deleteVkFFT(st->convFwd); free(st->convFwd); }
+		if (st->convInv) { deleteVkFFT(st->convInv); free(st->convInv); }
 		if (app->saveApplicationString) free(app->saveApplicationString);
 		if (st->events) {
 			for (uint32_t i = 0; i < st->numEvents; i++) if (st->events[i]) (void)hipEventDestroy(st->events[i]);
@@ -135,9 +147,16 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 		fprintf(stderr, "vkfft_mi355x: %s is outside the scope of this library (see DESIGN.md)\n", what);
 		return VKFFT_ERROR_PLAN_NOT_INITIALIZED;
 	};
-	if (in.performConvolution || in.kernelConvolution || in.matrixConvolution) return unsupported("convolution");
+	if (in.performConvolution) return initialize_convolution(app, in);
 	if (in.bufferNum > 1 || in.inputBufferNum > 1 || in.outputBufferNum > 1 || in.tempBufferNum > 1 || in.kernelNum > 1) return unsupported("a buffer split over several allocations (bufferNum > 1)");
-	for (int i = 0; i < VKFFT_MAX_FFT_DIMENSIONS; i++) if (in.performZeropadding[i]) return unsupported("zero-padding");
+	bool zeroPad = false;
+	for (pfUINT i = 0; i < in.FFTdim; i++) if (in.performZeropadding[i]) {
+		zeroPad = true;
+		if (in.fft_zeropad_left[i] > in.fft_zeropad_right[i] || in.fft_zeropad_right[i] > in.size[i]) return unsupported("a zero-padding range outside the axis");
+	}
+	// zero padding writes the zeros the reference only assumes (vkFFT_Zeropad.h:28): it needs a source it may write to
+	if (zeroPad && !in.frequencyZeroPadding && in.isInputFormatted) return unsupported("zero-padding of a separate input buffer");
+	if (zeroPad && in.frequencyZeroPadding && in.isOutputFormatted) return unsupported("frequency zero-padding of a separate output buffer");
 	if (in.halfPrecision || in.halfPrecisionMemoryOnly) return unsupported("half precision");
 	if (in.quadDoubleDoublePrecision || in.quadDoubleDoublePrecisionDoubleMemory) return unsupported("double-double precision");
 	if (in.doublePrecisionFloatMemory) return unsupported("doublePrecisionFloatMemory");
@@ -245,6 +264,7 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 	if (!st) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_MALLOC_FAILED; }
 	app->impl = st;
 	st->sweepEnabled = getenv("VKFFT_MI355X_NO_REVERSE") == nullptr;
+	st->zeroPad = zeroPad;
 
 	VkFFTResult res = VKFFT_SUCCESS;
 	if (!c.makeForwardPlanOnly) {
@@ -311,6 +331,7 @@ VKFFT_API VkFFTResult VkFFTAppend(VkFFTApplication* app, int inverse, VkFFTLaunc
 	VkFFTConfiguration& c = app->configuration;
 	AppState* st = (AppState*)app->impl;
 	if (st == nullptr) return VKFFT_ERROR_PLAN_NOT_INITIALIZED;
+	if (st->convFwd) return append_convolution(app, inverse, lp);
 	VkFFTPlan* pl;
 	if (inverse != 1) { // reference: anything but 1 is forward (vkFFT_RunApp.h:102-111)
 		if (!app->localFFTPlan) return VKFFT_ERROR_ONLY_INVERSE_FFT_INITIALIZED;
@@ -349,6 +370,10 @@ VKFFT_API VkFFTResult VkFFTAppend(VkFFTApplication* app, int inverse, VkFFTLaunc
 		ss.n = (uint32_t)std::min<pfUINT>(c.num_streams, 8);
 		for (uint32_t i = 0; i < ss.n; i++) ss.s[i] = c.stream[i];
 		if (ss.n > 1) { for (uint32_t i = 0; i < ss.n; i++) ss.ev[i] = st->events[i]; }
+	}
+	if (st->zeroPad && (inverse == 1) == (c.frequencyZeroPadding != 0)) {
+		VkFFTResult z = zero_padded_ranges(app, inverse == 1, lb.base[ROLE_BUFFER], ss.s[0]);
+		if (z != VKFFT_SUCCESS) return z;
 	}
 	int r = execute_direction(*dp, lb, ss, st->sweepEnabled ? &st->sweep : nullptr);
 	if (r) { fprintf(stderr, "vkfft_mi355x: kernel launch failed\n"); return (VkFFTResult)r; }
@@ -391,3 +416,103 @@ VKFFT_API const char* getVkFFTErrorString(VkFFTResult r) {
 }
 
 } // extern "C"
+
+namespace {
+
+// Zero padding (VkFFTConfiguration::performZeropadding / fft_zeropad_left / fft_zeropad_right, vkFFT_Structs.h:150-155): the range
+// [left, right) of an axis is taken as zero by the first transform that reads it — the forward one, or the inverse one with
+// frequencyZeroPadding.  The reference skips the reads (vkFFT_Zeropad.h:28); this library writes the zeros and transforms everything, so
+// the padded range of the OUTPUT holds computed values where the reference leaves it untouched.
+VkFFTResult zero_padded_ranges(VkFFTApplication* app, bool inverse, void* base, hipStream_t stream) {
+	const VkFFTConfiguration& c = app->configuration;
+	const bool r2c = c.performR2C != 0, real = c.performDCT || c.performDST || (r2c && !inverse);
+	ZeroParams z;
+	z.base = base;
+	z.words = (c.doublePrecision ? 2u : 1u) * (real ? 1u : 2u);
+	const uint64_t unit = (r2c && !inverse) ? 2 : 1; // the in-place real layout: strides in reals = twice the complex strides
+	for (int d = 0; d < 4; d++) {
+		z.size[d] = d < (int)c.FFTdim ? (uint32_t)c.size[d] : 1u;
+		z.stride[d] = d == 0 ? 1 : (uint64_t)c.bufferStride[d - 1] * unit;
+	}
+	if (r2c && inverse) z.size[0] = (uint32_t)(c.size[0] / 2 + 1);
+	z.systemStride = (uint64_t)c.bufferStride[c.FFTdim - 1] * unit;
+	z.systems = (uint32_t)(app->actualNumBatches * c.coordinateFeatures);
+	for (pfUINT i = 0; i < c.FFTdim; i++) {
+		if (!c.performZeropadding[i]) continue;
+		z.axis = (uint32_t)i; z.left = (uint32_t)c.fft_zeropad_left[i]; z.right = (uint32_t)std::min<pfUINT>(c.fft_zeropad_right[i], z.size[i]);
+		if (launch_zero_slab(z, stream)) return VKFFT_ERROR_FAILED_TO_LAUNCH_KERNEL;
+	}
+	return VKFFT_SUCCESS;
+}
+
+VkFFTResult initialize_convolution(VkFFTApplication* app, const VkFFTConfiguration& in) {
+	auto unsupported = [&](const char* what) {
+		fprintf(stderr, "vkfft_mi355x: convolution with %s is outside the scope of this library (see DESIGN.md)\n", what);
+		return VKFFT_ERROR_PLAN_NOT_INITIALIZED;
+	};
+	const pfUINT m = in.matrixConvolution ? in.matrixConvolution : 1, nk = in.numberKernels ? in.numberKernels : 1, nb = in.numberBatches ? in.numberBatches : 1;
+	if (m > 8) return unsupported("matrixConvolution > 8");
+	if (nk > 1 && nb > 1) return unsupported("numberKernels > 1 and numberBatches > 1");
+	if (in.isOutputFormatted) return unsupported("a separate output buffer");
+	if (in.performDCT || in.performDST) return unsupported("R2R transforms");
+	if (in.makeForwardPlanOnly || in.makeInversePlanOnly) return unsupported("makeForwardPlanOnly / makeInversePlanOnly");
+	for (pfUINT i = 0; i < in.FFTdim; i++) if (in.omitDimension[i]) return VKFFT_ERROR_UNSUPPORTED_FFT_OMIT; // reference: vkFFT_InitializeApp.h:1385-1400
+	AppState* st = new (std::nothrow) AppState();
+	if (!st) return VKFFT_ERROR_MALLOC_FAILED;
+	app->impl = st;
+	VkFFTConfiguration& c = app->configuration;
+	c = in;
+	c.matrixConvolution = m; c.numberKernels = nk; c.numberBatches = nb;
+	c.coordinateFeatures = m > 1 ? m : (in.coordinateFeatures ? in.coordinateFeatures : 1); // reference: vkFFT_InitializeApp.h:1374
+	c.reorderFourStep = 0;
+	app->actualNumBatches = nb;
+	VkFFTConfiguration f = in, b = in;
+	f.performConvolution = 0; f.matrixConvolution = 0; f.numberKernels = 0; f.symmetricKernel = 0; f.conjugateConvolution = 0; f.crossPowerSpectrumNormalization = 0;
+	f.kernel = nullptr; f.kernelSize = nullptr; f.kernelNum = 0;
+	f.coordinateFeatures = c.coordinateFeatures;
+	f.saveApplicationToString = 0; f.loadApplicationFromString = 0;
+	b = f;
+	f.makeForwardPlanOnly = 1;
+	b.makeInversePlanOnly = 1;
+	b.numberBatches = nb * nk;
+	b.isInputFormatted = 0; b.inverseReturnToInputBuffer = 0; b.inputBuffer = nullptr; b.inputBufferSize = nullptr;
+	if (nk > 1 && in.bufferSize) b.bufferSize = in.bufferSize;
+	st->convFwd = (VkFFTApplication*)calloc(1, sizeof(VkFFTApplication));
+	st->convInv = (VkFFTApplication*)calloc(1, sizeof(VkFFTApplication));
+	if (!st->convFwd || !st->convInv) { deleteVkFFT(app); return VKFFT_ERROR_MALLOC_FAILED; }
+	VkFFTResult r = initializeVkFFT(st->convFwd, f);
+	if (r == VKFFT_SUCCESS) r = initializeVkFFT(st->convInv, b);
+	if (r != VKFFT_SUCCESS) { deleteVkFFT(app); return r; }
+	for (int i = 0; i < VKFFT_MAX_FFT_DIMENSIONS; i++) c.bufferStride[i] = st->convFwd->configuration.bufferStride[i];
+	app->firstAxis = 0; app->lastAxis = c.FFTdim - 1;
+	return VKFFT_SUCCESS;
+}
+
+VkFFTResult append_convolution(VkFFTApplication* app, int inverse, VkFFTLaunchParams* lp) {
+	VkFFTConfiguration& c = app->configuration;
+	AppState* st = (AppState*)app->impl;
+	if (lp) {
+		if (lp->kernel) c.kernel = lp->kernel;
+		if (lp->buffer) c.buffer = lp->buffer;
+		if (c.specifyOffsetsAtLaunch) { c.kernelOffset = lp->kernelOffset; c.bufferOffset = lp->bufferOffset; }
+	}
+	VkFFTLaunchParams inv = VKFFT_ZERO_INIT;
+	if (lp) { inv.buffer = lp->buffer; inv.tempBuffer = lp->tempBuffer; inv.bufferOffset = lp->bufferOffset; inv.tempBufferOffset = lp->tempBufferOffset; }
+	if (inverse == 1) return VkFFTAppend(st->convInv, 1, lp ? &inv : nullptr); // a plain inverse of the numberKernels results
+	if (c.kernel == nullptr || c.kernel[0] == nullptr) return VKFFT_ERROR_EMPTY_kernel;
+	if (c.buffer == nullptr || c.buffer[0] == nullptr) return VKFFT_ERROR_EMPTY_buffer;
+	VkFFTResult r = VkFFTAppend(st->convFwd, -1, lp);
+	if (r != VKFFT_SUCCESS) return r;
+	ConvParams p;
+	p.data = (char*)c.buffer[0] + c.bufferOffset;
+	p.kernel = (const char*)c.kernel[0] + c.kernelOffset;
+	p.systemStride = c.bufferStride[c.FFTdim - 1];
+	p.matrix = (uint32_t)c.matrixConvolution; p.coordinates = (uint32_t)c.coordinateFeatures;
+	p.batches = (uint32_t)c.numberBatches; p.numKernels = (uint32_t)c.numberKernels;
+	p.symmetric = c.symmetricKernel ? 1u : 0u; p.conjugate = (uint32_t)c.conjugateConvolution; p.crossPower = c.crossPowerSpectrumNormalization ? 1u : 0u;
+	p.kernelSystems = p.matrix > 1 ? (p.symmetric ? p.matrix * (p.matrix + 1) / 2 : p.matrix * p.matrix) : p.coordinates;
+	if (launch_conv_pointwise(p, c.doublePrecision != 0, c.stream ? c.stream[0] : nullptr)) return VKFFT_ERROR_FAILED_TO_LAUNCH_KERNEL;
+	return VkFFTAppend(st->convInv, 1, lp ? &inv : nullptr);
+}
+
+} // namespace

@@ -179,4 +179,21 @@ struct FusedParams {
 	unsigned long long* prof; // development only (VKFFT_MI355X_FUSED_PROFILE): per-workgroup cycle sums of the tile phases, else nullptr
 };
 
+// element-wise product of a convolution plan (kernels_aux.hip): spectra of `coordinates` systems per batch, `systemStride` complex
+// elements apart; kernel k of `numKernels` holds `kernelSystems` component spectra with the same stride; output of kernel f goes to
+// batch f * batches + b
+struct ConvParams {
+	void* data; const void* kernel;
+	uint64_t systemStride;
+	uint32_t matrix, coordinates, batches, numKernels, kernelSystems;
+	uint32_t symmetric, conjugate, crossPower;
+};
+// zero padding (kernels_aux.hip): a slab [left, right) along `axis` of every system; offsets in elements of `words` 32-bit words
+struct ZeroParams {
+	void* base;
+	uint32_t size[4]; uint64_t stride[4];
+	uint64_t systemStride; uint32_t systems;
+	uint32_t axis, left, right, words;
+};
+
 } // namespace vkfft_mi355x

@@ -114,6 +114,10 @@ int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 bool opfft_lookup(uint64_t n, bool dp, bool col, bool trans, uint32_t pre, uint32_t post, int* variant, int rad[5], int* fpw, int* threads); // trans: column tile in, transposed (per-column contiguous) store out
 int launch_opfft(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 
+// convolution product and zero padding (kernels_aux.hip)
+int launch_conv_pointwise(const ConvParams& p, bool dp, hipStream_t stream);
+int launch_zero_slab(const ZeroParams& p, hipStream_t stream);
+
 // misc
 std::vector<uint32_t> factorize_radices(uint64_t n, bool* smooth);
 

@@ -1,0 +1,100 @@
+// Element-wise helpers of the convolution and zero-padding configurations: own translation unit.
+//   * conv_pointwise_kernel — the product the reference merges into the last axis of a convolution plan
+//     (appendKernelConvolution, vkFFT_CodeGen/vkFFT_KernelsLevel1/PrePostProcessing/vkFFT_Convolution.h:125-447): here a separate
+//     HBM-bound pass between the forward and the inverse transform (one read of every spectrum and kernel element, one write);
+//   * zero_slab_kernel — zero padding (vkFFT_KernelsLevel0/vkFFT_Zeropad.h:28): the reference does not read the padded range and
+//     takes it as zero; here the range is written with zeros before the transform that would read it.
+#include "engine.h"
+#include "butterflies.h"
+
+namespace vkfft_mi355x {
+
+constexpr int kConvMaxMatrix = 8;
+
+// index of kernel component (j, l) among the systems of one convolution kernel (vkFFT_Convolution.h:352-358)
+__host__ __device__ inline uint32_t conv_kernel_index(uint32_t j, uint32_t l, uint32_t m, bool symmetric) {
+	if (!symmetric) return j * m + l;
+	return l < j ? l * m - l * l + j : j * m - j * j + l;
+}
+
+template <typename T> __global__ void __launch_bounds__(256) conv_pointwise_kernel(const ConvParams p) {
+	const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= p.systemStride) return;
+	const uint32_t b = blockIdx.y; // batch of the input
+	cx<T>* const data = (cx<T>*)p.data;
+	const cx<T>* const ker = (const cx<T>*)p.kernel;
+	const uint32_t m = p.matrix, cf = p.coordinates;
+	if (m <= 1) {
+		// 1x1 convolution: every coordinate is multiplied by its own kernel component
+		for (uint32_t v = 0; v < cf; v++) {
+			cx<T> x = data[((uint64_t)b * cf + v) * p.systemStride + e];
+			if (p.conjugate == 1) x = cconj(x);
+			for (uint32_t f = p.numKernels; f-- > 0;) {
+				cx<T> k = ker[((uint64_t)f * p.kernelSystems + v) * p.systemStride + e];
+				if (p.conjugate == 2) k = cconj(k);
+				cx<T> y = cmul(k, x);
+				if (p.crossPower) { const T n = y.x * y.x + y.y * y.y; const T s = n > (T)0 ? (T)1 / sqrt(n) : (T)0; y = cscale(y, s); }
+				data[(((uint64_t)f * p.batches + b) * cf + v) * p.systemStride + e] = y;
+			}
+		}
+		return;
+	}
+	cx<T> x[kConvMaxMatrix];
+	for (uint32_t l = 0; l < m; l++) {
+		x[l] = data[((uint64_t)b * m + l) * p.systemStride + e];
+		if (p.conjugate == 1) x[l] = cconj(x[l]);
+	}
+	for (uint32_t f = p.numKernels; f-- > 0;) { // kernel 0 last: its output replaces the input
+		for (uint32_t j = 0; j < m; j++) {
+			cx<T> acc = cx<T>{(T)0, (T)0};
+			for (uint32_t l = 0; l < m; l++) {
+				cx<T> k = ker[((uint64_t)f * p.kernelSystems + conv_kernel_index(j, l, m, p.symmetric != 0)) * p.systemStride + e];
+				if (p.conjugate == 2) k = cconj(k);
+				acc = cadd(acc, cmul(k, x[l]));
+			}
+			if (p.crossPower) { const T n = acc.x * acc.x + acc.y * acc.y; const T s = n > (T)0 ? (T)1 / sqrt(n) : (T)0; acc = cscale(acc, s); }
+			data[(((uint64_t)f * p.batches + b) * m + j) * p.systemStride + e] = acc;
+		}
+	}
+}
+
+int launch_conv_pointwise(const ConvParams& p, bool dp, hipStream_t stream) {
+	if (p.matrix > (uint32_t)kConvMaxMatrix) return 4039;
+	if (p.systemStride == 0 || p.batches == 0) return 0;
+	const dim3 grid((uint32_t)((p.systemStride + 255) / 256), p.batches);
+	if (dp) hipLaunchKernelGGL(conv_pointwise_kernel<double>, grid, dim3(256), 0, stream, p);
+	else hipLaunchKernelGGL(conv_pointwise_kernel<float>, grid, dim3(256), 0, stream, p);
+	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
+
+// zeroes, in every system, the elements whose coordinate on `axis` lies in [left, right); 32-bit words, `words` per element
+__global__ void __launch_bounds__(256) zero_slab_kernel(const ZeroParams p) {
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	uint64_t n = 1;
+	uint32_t ext[4];
+	for (int d = 0; d < 4; d++) { ext[d] = d == (int)p.axis ? p.right - p.left : p.size[d]; n *= ext[d]; }
+	if (i >= n) return;
+	uint64_t r = i, off = 0;
+	for (int d = 0; d < 4; d++) {
+		const uint32_t c = (uint32_t)(r % ext[d]); r /= ext[d];
+		off += (uint64_t)(d == (int)p.axis ? c + p.left : c) * p.stride[d];
+	}
+	uint32_t* w = (uint32_t*)p.base + ((uint64_t)blockIdx.y * p.systemStride + off) * p.words;
+	for (uint32_t k = 0; k < p.words; k++) w[k] = 0u;
+}
+
+int launch_zero_slab(const ZeroParams& p, hipStream_t stream) {
+	if (p.right <= p.left || p.systems == 0) return 0;
+	uint64_t n = 1;
+	for (int d = 0; d < 4; d++) n *= d == (int)p.axis ? p.right - p.left : p.size[d];
+	if (n == 0) return 0;
+	for (uint32_t s0 = 0; s0 < p.systems; s0 += 65535u) { // grid.y limit
+		ZeroParams q = p;
+		q.base = (char*)p.base + (uint64_t)s0 * p.systemStride * p.words * 4u;
+		const uint32_t ns = p.systems - s0 < 65535u ? p.systems - s0 : 65535u;
+		hipLaunchKernelGGL(zero_slab_kernel, dim3((uint32_t)((n + 255) / 256), ns), dim3(256), 0, stream, q);
+	}
+	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
+
+} // namespace vkfft_mi355x

@@ -1037,7 +1037,17 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		return 0;
 	}
 
-	const uint64_t singleCap = unit ? rowCap : max_col_len(dp, d.maxLds, 1);
+	uint64_t singleCap = unit ? rowCap : max_col_len(dp, d.maxLds, 1);
+	if (!unit && !d.disableFastKernels && j.N > 2048 && j.N <= singleCap && !j.others.empty() && j.others[0].inStride == 1 && j.others[0].outStride == 1) {
+		// a strided axis longer than the hand-specialised column kernels reach (2048): one pass would put ONE column in LDS per workgroup
+		// (uncoalesced 8-byte accesses, measured 0.4 TB/s on 4096 x 4096); two passes over tiles of neighbouring columns run at copy speed
+		int variant, bits[4], tc, thr, rad5[5], fpw;
+		const bool p2 = (j.N & (j.N - 1)) == 0;
+		std::vector<uint64_t> probe;
+		if (!(p2 && pow2_col_lookup(ilog2(j.N), dp, &variant, bits, &tc, &thr)) && !opfft_lookup(j.N, dp, true, false, 0, 0, &variant, rad5, &fpw, &thr) &&
+		    choose_split(j.N, dp, d.maxLds, dmax, true, probe))
+			singleCap = 2048;
+	}
 	if (j.N <= singleCap || (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N <= (dp ? 8192u : 16384u))) {
 		b.L = j.N;
 		if (unit && !d.disableFastKernels && (j.N & (j.N - 1)) != 0) { // curated non-power-of-two lengths: hand-specialised mixed-radix kernel
