@@ -35,6 +35,6 @@ for k in (16, 18):
         rows.append((f"fused, lag {lag} ring {ring} slots/queue", {"VKFFT_MI355X_FUSED_LAG": str(lag), "VKFFT_MI355X_FUSED_RING": str(ring)}))
     for name, env in rows:
         ms = pair_ms(k, env)
-        chunk_mib = 1.0
+        chunk_mib = max(1.0, (8 << k) / 2.0 ** 20)  # the planner's chunk: about 1 MiB, at least one transform
         ring_mib = None if "ring" not in name or "default" in name else 8 * int(env["VKFFT_MI355X_FUSED_RING"]) * chunk_mib
         print(json.dumps(dict(log2N=k, config=name, ring_MiB=ring_mib, pair_ms=round(ms, 4), alg_GBps=round(4 * (8 << 27) / (ms * 1e-3) / 1e9, 1))), flush=True)
