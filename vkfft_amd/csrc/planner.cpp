@@ -1112,6 +1112,28 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	return 0;
 }
 
+// pair pass of the even R2C / C2R decomposition (r2c_even_pair_kernel), in place on the complex rows
+static int make_r2c_pair_pass(uint64_t N, bool dp, bool inverse, const std::vector<HostDim>& othersCplx, int cplxRole, Arena& ar, PassPlan& pair) {
+	const size_t es = dp ? 16 : 8;
+	memset(&pair.prm, 0, sizeof(pair.prm));
+	PassParams& q = pair.prm;
+	std::vector<HostDim> cd; for (auto& o : othersCplx) cd.push_back(o);
+	collapse_dims(cd);
+	while (cd.size() < 3) cd.push_back({1, 0, 0});
+	if (cd.size() > 3) return 3003;
+	for (int i = 0; i < 3; i++) { q.dim[i].count = (uint32_t)cd[i].count; q.dim[i].inStride = q.dim[i].outStride = cd[i].inStride; }
+	q.opN = (uint32_t)N; q.fsN = (uint32_t)N; q.scale = 1.0; q.swapIn = inverse ? 1 : 0;
+	uint32_t lo = (ceil_log2(N) + 1) / 2; uint64_t nlo = 1ull << lo, nhi = (N + nlo - 1) / nlo;
+	size_t off = ar.alloc((nlo + nhi) * es);
+	for (uint64_t i = 0; i < nlo; i++) ar.putc(off, i, unit_root(i, N), dp);
+	for (uint64_t i = 0; i < nhi; i++) ar.putc(off, nlo + i, unit_root(i * nlo, N), dp);
+	q.fsLoBits = lo; pair.auxOff = off;
+	q.tilesPerG0 = 1;
+	pair.kernel = KERNEL_R2C_PAIR; pair.dp = dp; pair.inRole = pair.outRole = cplxRole;
+	pair.inElemBytes = pair.outElemBytes = (int)es; pair.threads = 256; pair.label = inverse ? "c2r-pair" : "r2c-pair";
+	return 0;
+}
+
 // ---- real transforms ---------------------------------------------------------------------------------------
 // R2C/C2R along axis 0 (reference: two-sequences packing vkFFT_R2C.h:450/:178 for single-upload, even
 // decomposition vkFFT_R2C_even_decomposition.h:40 for long even N, callback form vkFFT_R2C.h:27 otherwise).
@@ -1135,6 +1157,37 @@ static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vecto
 		// keep the first N/2+1 outputs; vkFFT_R2C.h:27) around a fused Bluestein transform of length N
 		if (d.disableFastKernels) return 3003;
 		uint64_t Mp = 64; while (Mp < 2 * N - 1) Mp *= 2;
+		if (even && Mp > (dp ? 4096u : 8192u)) {
+			// long even rows: the full-length form would need a padded length of 16384 or more (one 128 KiB workgroup per CU, measured
+			// 0.24 TB/s at N = 5606).  Half-length complex transform of the packed pairs — whatever plan that length needs, here the fused
+			// Bluestein kernel on a quarter of the padded length — plus the pair pass of the even decomposition (vkFFT_R2C_even_decomposition.h:40)
+			const size_t mark = passes.size();
+			PassPlan pair;
+			int pr = make_r2c_pair_pass(N, dp, inverse, othersCplx, cplxRole, ar, pair);
+			if (pr == 0) {
+				AxisJob hj;
+				hj.N = N / 2; hj.dp = dp; hj.inverse = inverse; hj.scale = scale; hj.axisIndex = 0;
+				hj.inRole = inverse ? cplxRole : realRole; hj.outRole = inverse ? realRole : cplxRole;
+				bool ok = true;
+				for (size_t i = 0; i < othersReal.size(); i++) {
+					int64_t rs = othersReal[i].inStride; const int64_t cs = othersCplx[i].inStride;
+					if (rs % 2) { ok = false; break; }
+					rs /= 2;
+					hj.others.push_back(inverse ? HostDim{othersReal[i].count, cs, rs} : HostDim{othersReal[i].count, rs, cs});
+				}
+				if (ok) {
+					if (inverse) passes.push_back(pair);
+					const int r = plan_c2c_axis(d, hj, ar, out, passes);
+					if (r == 0) {
+						if (!inverse) passes.push_back(pair);
+						out.uploadsPerAxis[0] += 1;
+						out.axisSplit[0][0] = N; out.bigSequenceEvenR2C = 1;
+						return 0;
+					}
+					passes.resize(mark);
+				}
+			}
+		}
 		uint64_t pitch = N + 2;
 		if (!othersReal.empty()) pitch = (uint64_t)std::max<int64_t>(std::llabs(othersReal[0].inStride), 2 * std::llabs(othersCplx[0].inStride));
 		if ((pitch * 64 + 2 * N) * (dp ? 8 : 4) >= 0x7FFFFF00ull) return 3003; // 32-bit buffer offsets inside a tile of rows
@@ -1179,24 +1232,8 @@ static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vecto
 		if (!choose_split(H, dp, d.maxLds, dmax, !d.disableFastKernels, sp)) return 3003;
 		PassBuild proto; proto.dp = dp; proto.maxLds = d.maxLds; proto.raderDirectMax = dmax; proto.allowFast = !d.disableFastKernels;
 		// pair pass descriptor (in place on the complex rows)
-		PassPlan pair; memset(&pair.prm, 0, sizeof(pair.prm));
-		{
-			PassParams& q = pair.prm;
-			std::vector<HostDim> cd; for (auto& o : othersCplx) cd.push_back(o);
-			collapse_dims(cd);
-			while (cd.size() < 3) cd.push_back({1, 0, 0});
-			if (cd.size() > 3) return 3003;
-			for (int i = 0; i < 3; i++) { q.dim[i].count = (uint32_t)cd[i].count; q.dim[i].inStride = q.dim[i].outStride = cd[i].inStride; }
-			q.opN = (uint32_t)N; q.fsN = (uint32_t)N; q.scale = 1.0; q.swapIn = inverse ? 1 : 0;
-			uint32_t lo = (ceil_log2(N) + 1) / 2; uint64_t nlo = 1ull << lo, nhi = (N + nlo - 1) / nlo;
-			size_t off = ar.alloc((nlo + nhi) * es);
-			for (uint64_t i = 0; i < nlo; i++) ar.putc(off, i, unit_root(i, N), dp);
-			for (uint64_t i = 0; i < nhi; i++) ar.putc(off, nlo + i, unit_root(i * nlo, N), dp);
-			q.fsLoBits = lo; pair.auxOff = off;
-			q.tilesPerG0 = 1;
-			pair.kernel = KERNEL_R2C_PAIR; pair.dp = dp; pair.inRole = pair.outRole = cplxRole;
-			pair.inElemBytes = pair.outElemBytes = (int)es; pair.threads = 256; pair.label = inverse ? "c2r-pair" : "r2c-pair";
-		}
+		PassPlan pair;
+		if (int pr = make_r2c_pair_pass(N, dp, inverse, othersCplx, cplxRole, ar, pair)) return pr;
 		MultiPassIO io;
 		for (auto& h : dims) { io.othersIn.push_back({h.count, h.inStride, h.inStride}); io.othersOut.push_back({h.count, h.outStride, h.outStride}); }
 		io.inRole = inverse ? cplxRole : realRole; io.outRole = inverse ? realRole : cplxRole;
