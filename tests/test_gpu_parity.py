@@ -665,6 +665,35 @@ def test_multi_gpu_drivers_on_one_device(product_lib):
     assert torch.equal(part, whole[shard.lo:shard.hi])
 
 
+@pytest.mark.parametrize("N,B", [(1 << 10, 256), (1 << 16, 64), (3 * 5 * 7 * 11, 32), (1009, 16)])
+def test_append_can_be_captured_in_a_hip_graph(product_lib, N, B):
+    """VkFFTAppend only enqueues kernels on the caller's stream (no allocation, no synchronisation, no host-side state that depends on the
+    data), so a forward + inverse pair can be captured once and replayed — incl. the persistent fused kernel, whose counters the last
+    workgroup resets on the device."""
+    import torch
+    x = torch.randn(2 * N * B, device="cuda")
+    buf = x.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        app = api.App([N], B, buffer_ptr=buf.data_ptr(), stream=s.cuda_stream, normalize=True, lib=product_lib)
+        app.forward(); app.inverse()  # warm-up outside the capture (first-launch occupancy query)
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        app.forward(); app.inverse()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert (torch.linalg.norm(buf - x) / torch.linalg.norm(x)).item() < 3e-6
+    ref = torch.fft.fft(torch.view_as_complex(x.view(-1, 2)).view(B, N)[1].to(torch.complex128))
+    with torch.cuda.stream(s):
+        app.forward()
+    s.synchronize()
+    got = torch.view_as_complex(buf.view(-1, 2)).view(B, N)[1].to(torch.complex128)
+    assert (torch.linalg.norm(got - ref) / torch.linalg.norm(ref)).item() < 3e-6
+    app.delete()
+
+
 # ---- convolution and zero padding (SURVEY.md §8 f4) ------------------------------------------------------------------------
 import convpad
 
