@@ -694,6 +694,48 @@ def test_append_can_be_captured_in_a_hip_graph(product_lib, N, B):
     app.delete()
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("seed", range(8))
+def test_random_plans_against_the_oracle_on_device(run, oracle, seed):
+    """the differential fuzz of tests/test_emu_fuzz.py on the device: 240 random 1-D…3-D C2C / R2C / DCT / DST plans of smooth, prime and
+    arbitrary lengths, both precisions, against the double / long-double truth (seeds disjoint from the emulator's)"""
+    import test_emu_fuzz as fz
+    import random as _r
+    orig = _r.Random
+    try:
+        _r.Random = lambda s_: orig(7000 + seed * 13 + (s_ - 1000))  # the shared body seeds Random(1000 + seed)
+        fz.test_random_plans_against_the_oracle(run, oracle, seed)
+    finally:
+        _r.Random = orig
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kw", [dict(size=[1 << 10]), dict(size=[1 << 13]), dict(size=[1 << 14]), dict(size=[1 << 17]), dict(size=[1 << 20]), dict(size=[1080]), dict(size=[2187]),
+                                dict(size=[1009]), dict(size=[4096], r2c=True), dict(size=[1024], dct=2), dict(size=[1024], dct=4), dict(size=[256, 256]), dict(size=[64, 64, 64]),
+                                dict(size=[1 << 12], dp=True), dict(size=[8191])], ids=lambda k: "x".join(map(str, k["size"])) + "".join(f"-{a}" for a in k if a != "size"))
+def test_repeated_launches_are_bit_identical(product_lib, kw):
+    """100 forward transforms of the same input with the chip full must give the same bits every time: any intra-workgroup race (a missing
+    wait before a barrier) or inter-workgroup race shows up as a rare mismatch, whatever the values are"""
+    import torch
+    kw = dict(kw); size = kw.pop("size"); dp = kw.pop("dp", False)
+    n = int(np.prod(size))
+    real = kw.get("r2c") or kw.get("dct")
+    per = (n // size[0]) * (size[0] + 2) if kw.get("r2c") else n * (1 if real else 2)
+    B = max(1, (1 << 25) // per)
+    dt = torch.float64 if dp else torch.float32
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    x = torch.empty(per * B, dtype=dt, device="cuda").uniform_(-1, 1, generator=g)
+    buf = x.clone()
+    app = api.App(size, B, dp=dp, buffer_ptr=buf.data_ptr(), lib=product_lib, **kw)
+    app.forward(); first = buf.clone()
+    bad = 0
+    for _ in range(100):
+        buf.copy_(x); app.forward()
+        bad += int(not torch.equal(buf, first))
+    app.delete()
+    assert bad == 0, bad
+
+
 # ---- convolution and zero padding (SURVEY.md §8 f4) ------------------------------------------------------------------------
 import convpad
 
