@@ -270,7 +270,7 @@ def test_fused_fourstep_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
 
 
-@pytest.mark.parametrize("k,batch", [(14, 5), (15, 3), (16, 3), (17, 2)])
+@pytest.mark.parametrize("k,batch", [(14, 5), (15, 3), (16, 3), (17, 2), (18, 2), (19, 2), (20, 1)])
 def test_fused_fourstep_fp64(run, oracle, monkeypatch, k, batch):
     """fp64 members of the fused Four-Step family (16-byte elements, 16-column tiles), several chunks"""
     monkeypatch.setenv("VKFFT_MI355X_FUSED_CHUNK_KIB", str((16 << k) >> 10))

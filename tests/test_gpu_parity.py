@@ -58,9 +58,9 @@ def test_fused_fourstep_equals_separate_passes(run, oracle, monkeypatch, k, batc
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("k,batch", [(14, 33), (15, 17), (16, 9), (17, 5)])
+@pytest.mark.parametrize("k,batch", [(14, 33), (15, 17), (16, 9), (17, 5), (18, 5), (19, 3), (20, 3)])
 def test_fused_fourstep_fp64_equals_separate_passes(run, oracle, monkeypatch, k, batch):
-    """fp64 members of the fused Four-Step family (2^14..2^17) against the separate-pass plan and the long-double truth"""
+    """fp64 members of the fused Four-Step family (2^14..2^20) against the separate-pass plan and the long-double truth"""
     N = 1 << k
     x = parity.seeded_complex(N * batch, True, 177 + k)
     yf, zf, up = run.transform(x, (N,), batch, both=True)

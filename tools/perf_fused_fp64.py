@@ -2,7 +2,7 @@ import sys, os, json
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from vkfft_amd import api
-for k in (14, 15, 16, 17):
+for k in (14, 15, 16, 17, 18, 19, 20, 21):
     for fused in ("0", "1"):
         os.environ["VKFFT_MI355X_FUSED"] = fused
         N = 1 << k; B = (1 << 26) // N

@@ -50,11 +50,16 @@ static const Pow2FusedVariant kPow2FusedVariants[] = {
 	VKFFT_FUT(float, false, 5, 5, 0, 16, 5, 3, 3, 8, 0),
 	VKFFT_FUT(float, false, 5, 3, 3, 8, 5, 5, 0, 16, 0),
 	VKFFT_FUT(float, false, 5, 3, 3, 8, 5, 3, 3, 8, 0),
-	// fp64: 16-byte elements, 16 columns = 256-byte segments.  2^14 = 128 x 128, 2^15 = 128 x 256, 2^16 = 256 x 256, 2^17 = 256 x 512
+	// fp64: 16-byte elements, 8-16 columns = 128-256-byte segments.  2^14 = 128 x 128, 2^15 = 128 x 256, 2^16 = 256 x 256, 2^17 = 256 x 512
 	VKFFT_FU(double, true, 4, 3, 0, 16, 4, 3, 0, 16),
 	VKFFT_FU(double, true, 4, 3, 0, 16, 4, 4, 0, 8),
 	VKFFT_FU(double, true, 4, 4, 0, 16, 4, 4, 0, 16),
 	VKFFT_FUT(double, true, 4, 4, 0, 16, 4, 3, 2, 8, 0), // (stage twiddles through L2: the LDS copy would cost the second workgroup per CU)
+	// 2^18 = 512 x 512, 2^19 = 512 x 1024, 2^20 = 1024 x 1024: 128 KiB tiles, one workgroup per CU (2^18 with 64 KiB tiles and two workgroups
+	// per CU measured 2.07 TB/s against 2.80 — its ring of 4 MiB chunks does not fit the cache budget with the lag two workgroups per CU want)
+	VKFFT_FUT(double, true, 4, 3, 2, 16, 4, 3, 2, 16, 0),
+	VKFFT_FUT(double, true, 4, 3, 2, 16, 4, 3, 3, 8, 0),
+	VKFFT_FUT(double, true, 4, 3, 3, 8, 4, 3, 3, 8, 0),
 };
 constexpr int kNumPow2FusedVariants = (int)(sizeof(kPow2FusedVariants) / sizeof(kPow2FusedVariants[0]));
 
