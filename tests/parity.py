@@ -87,8 +87,8 @@ def opfft_transform_of(fam, L, col):
         return ((L * L * (L if fam == "c2c4" else 1),), {}, False)  # L^3 (three passes) the middle one
     if fam in ("r2cf", "c2rf"):
         return (L,), dict(r2c=True), True
-    n = {"r2c": 2 * L, "c2r": 2 * L, "dct2": L, "dct3": L, "dct2h": 2 * L, "dct3h": 2 * L, "dct4": 2 * L, "dct1": L // 2 + 1, "dst1": L // 2 - 1, "c2c": L}[fam]
-    kw = {"r2c": dict(r2c=True), "c2r": dict(r2c=True), "dct2": dict(dct=2), "dct3": dict(dct=3), "dct2h": dict(dct=2), "dct3h": dict(dct=3), "dct4": dict(dct=4), "dct1": dict(dct=1),
+    n = {"r2c": 2 * L, "c2r": 2 * L, "dct2": L, "dct3": L, "dct2h": 2 * L, "dct3h": 2 * L, "dct4": 2 * L, "dct1": L // 2 + 1, "dct1h": L + 1, "dst1": L // 2 - 1, "c2c": L}[fam]
+    kw = {"r2c": dict(r2c=True), "c2r": dict(r2c=True), "dct2": dict(dct=2), "dct3": dict(dct=3), "dct2h": dict(dct=2), "dct3h": dict(dct=3), "dct4": dict(dct=4), "dct1": dict(dct=1), "dct1h": dict(dct=1),
           "dst1": dict(dst=1), "c2c": {}}[fam]
     shape = (24, n) if col else (n,)
     return shape, kw, fam != "c2c"

@@ -22,7 +22,7 @@ FAMILIES = {
     "dct2h": ("OP_DCT2H_PRE", "OP_DCT2H_POST", True, True, True, False),   # even N through N/2 complex points
     "dct3h": ("OP_DCT3H_PRE", "OP_DCT3H_POST", True, True, True, False),
     "dct4": ("OP_DCT4_PRE", "OP_DCT4_POST", True, True, True, False),
-    "dct1": ("OP_DCT1_PRE", "OP_DCT1_POST", True, True, True, True),
+    "dct1h": ("OP_DCT1H_PRE", "OP_DCT1H_POST", True, True, True, True),    # DCT-I of N = L + 1 through L complex points
     "dst1": ("OP_DST1_PRE", "OP_DST1_POST", True, True, True, True),
     "r2cf": ("OP_R2C_FULL", "OP_R2C_FULL", False, True, False, False),    # odd real rows: full-length "callback" form
     "c2rf": ("OP_C2R_FULL", "OP_C2R_FULL", False, True, False, False),

@@ -81,6 +81,9 @@ enum : uint32_t {
 	OP_DCT3H_PRE = 28, OP_DCT3H_POST = 29,
 	OP_DST2H_PRE = 30, OP_DST2H_POST = 31,
 	OP_DST3H_PRE = 32, OP_DST3H_POST = 33,
+	// DCT-I of length N through ONE complex FFT of length N-1: the even extension (period 2N-2) is a real sequence, so its transform is the even
+	// R2C split of the packed pairs e[2n] + i e[2n+1] — half the points of the full-length form (vkFFT_R2R.h:28 runs the complex FFT of 2N-2)
+	OP_DCT1H_PRE = 36, OP_DCT1H_POST = 37,
 	OP_FOURSTEP_INV_COL_PRE = 35, // pre : column layout, swap, Four-Step twiddle (middle pass of a three-factor inverse run backwards)
 	OP_FOURSTEP_INV_PRE = 34, // pre : rows of the transposed Four-Step scratch, swap, Four-Step twiddle (first pass of the inverse run backwards)
 };

@@ -114,6 +114,11 @@ __device__ inline cx<T> pre_gather(const PassParams& p, const IO& io, uint32_t p
 		const cx<T> d = cmul(w, csub(a, b)), s2 = cadd(a, b);
 		return {s2.x - d.y, s2.y + d.x};
 	}
+	case OP_DCT1H_PRE: { // L = N-1: z[n] = e[2n] + i e[2n+1], e = even extension of x (period 2N-2)
+		const uint32_t N = p.opN, M = 2 * N - 2;
+		const uint32_t j0 = 2 * pos, j1 = 2 * pos + 1;
+		return {io.ldr(j0 < N ? j0 : M - j0), io.ldr(j1 < N ? j1 : M - j1)};
+	}
 	case OP_DCT1_PRE: { // even extension, L = 2N-2
 		const uint32_t N = p.opN, M = 2 * N - 2;
 		const uint32_t src = pos < N ? pos : M - pos;
@@ -224,6 +229,14 @@ __device__ inline void post_store(const PassParams& p, const IO& io, uint32_t k,
 	case OP_DCT1_POST:
 		io.str(k, rd(k).x * sc);
 		return;
+	case OP_DCT1H_POST: { // k in [0, N-1]: y[k] = Re X_k, X = even R2C split of Z (H = N-1 complex points)
+		const uint32_t H = p.opN - 1;
+		const cx<T> zk = rd(k == H ? 0 : k), zm = cconj(rd(k == 0 ? 0 : H - k));
+		const cx<T> w = ((const cx<T>*)p.aux)[k];
+		const cx<T> s2 = cadd(zk, zm), d = cmul(w, csub(zk, zm));
+		io.str(k, (T)0.5 * sc * (s2.x + d.y));
+		return;
+	}
 	case OP_DST1_POST:
 		io.str(k, -rd(k + 1).y * sc);
 		return;

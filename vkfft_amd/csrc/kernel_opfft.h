@@ -52,7 +52,7 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
                                 const uint32_t colIdx, const uint32_t nat) {
 	constexpr int N = SCH::N, R = SCH::rad[SI], NB = N / R, P = (NB + TPF - 1) / TPF, S = SCH::S(SI);
 	constexpr bool first = SI == 0, last = SI == SCH::NS - 1;
-	constexpr bool staged = POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST || TRANS; // the post-map (or the transposed store) gathers from LDS
+	constexpr bool staged = POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST || POST == OP_DCT1H_POST || TRANS; // the post-map (or the transposed store) gathers from LDS
 	constexpr bool pairIn = ROW && first && PRE == OP_DCT2H_PRE && opfft_can_pair<SCH, SI, TPF>();
 	constexpr bool pairOut = ROW && last && POST == OP_DCT3H_POST && opfft_can_pair<SCH, SI, TPF>();
 	// half-length DCT/DST-IV: FFT input n is (x[2n], x[Nr-1-2n]) * twiddle and output m feeds y[2m] and y[Nr-1-2m].  The two consecutive reals
@@ -295,6 +295,24 @@ __device__ inline void op_stage(cx<T>* ldsf, const Io32<T>& io, const GBuf glut,
 				if (2 * k != (uint32_t)N) io.stc((uint32_t)N - k, cx<T>{hs * (sS.x - d.y), -hs * (sS.y + d.x)});
 			}
 		}
+	} else if constexpr (staged && !TRANS && POST == OP_DCT1H_POST && ROW) {
+		// half-length DCT-I on unit-stride rows: y[k] = Re X[k], y[H-k] = Re X[H-k] from the pair (Z_k, Z_{H-k}) and one table entry (the R2C split above)
+		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
+		constexpr int HP = N / 2 + 1, PH = (HP + TPF - 1) / TPF;
+		const T hs = (T)0.5 * (T)p.scale;
+		const GBuf gw = make_gbuf(p.aux);
+#pragma unroll
+		for (int b = 0; b < PH; b++) {
+			const uint32_t k = tau + b * TPF;
+			if ((b + 1) * TPF <= HP || k < (uint32_t)HP) {
+				const uint32_t km = k == 0 ? 0u : (uint32_t)N - k;
+				const cx<T> zk = ldsf[k], zm = cconj(ldsf[km]);
+				const cx<T> w = gb_load<T>(gw, k * (uint32_t)sizeof(cx<T>), 0);
+				const cx<T> sS = cadd(zk, zm), d = cmul(w, csub(zk, zm));
+				io.str(k, hs * (sS.x + d.y));
+				if (2 * k != (uint32_t)N) io.str((uint32_t)N - k, hs * (sS.x - d.y));
+			}
+		}
 	} else if constexpr (staged && !TRANS && POST == OP_DCT2H_POST && ROW) {
 		// half-length DCT/DST-II post-map on unit-stride rows, pairs (k, H-k) together (H = N): 2V_k = s - i d and 2V_{H-k} = conj(s + i d) from one
 		// pair of LDS reads and one split twiddle (see the R2C split above), then y[k] = Re(c^k 2V_k), y[Nr-k] = -Im(c^k 2V_k) and the same for H-k
@@ -348,7 +366,7 @@ template <typename T, typename SCH, int TPF, int FPW, bool COL, int PRE, int POS
 __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	constexpr int N = SCH::N;
 	static_assert(!TRANS || (COL && (POST == OP_NONE || POST == OP_TWIDDLE_4STEP)), "transposed store: first Four-Step pass of a column tile");
-	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || TRANS || PRE == OP_DCT3H_PRE || (PRE == OP_C2R_EVEN_PRE && !COL) || POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST), MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems()>();
+	constexpr int LDSPF = opfft_pitch<N, FPW, COL, (SCH::NS > 1 || TRANS || PRE == OP_DCT3H_PRE || (PRE == OP_C2R_EVEN_PRE && !COL) || POST == OP_R2C_EVEN_POST || POST == OP_DCT2H_POST || POST == OP_DCT1H_POST), MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems()>();
 	constexpr bool waveOnly = !COL && (TPF <= 64) && (64 % TPF == 0); // a row FFT that never straddles wavefronts
 	__shared__ cx<T> lds[FPW * LDSPF];
 	const uint32_t tid = threadIdx.x;

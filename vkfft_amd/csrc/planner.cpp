@@ -1296,7 +1296,18 @@ static int plan_r2r_axis(const TransformDesc& d, int type, bool dst, uint64_t N,
 	b.inRole = inRole; b.outRole = outRole;
 	switch (type) {
 	case 1:
-		if (!dst) { if (N < 2) return 3004; b.L = 2 * N - 2; b.preOp = OP_DCT1_PRE; b.postOp = OP_DCT1_POST; }
+		if (!dst) {
+			if (N < 2) return 3004;
+			int v, r5[5], f, t;
+			if (!d.disableFastKernels && N >= 5 && opfft_lookup(N - 1, dp, !unit, false, OP_DCT1H_PRE, OP_DCT1H_POST, &v, r5, &f, &t)) {
+				// half-length form on an ahead-of-time instance: complex FFT of N-1 points + the even R2C split (real parts only)
+				const uint64_t H = N - 1;
+				b.L = H; b.preOp = OP_DCT1H_PRE; b.postOp = OP_DCT1H_POST;
+				size_t aux = ar.alloc((H + 1) * es);
+				for (uint64_t k = 0; k <= H; k++) ar.putc(aux, k, unit_root(k, 2 * H), dp);
+				b.auxOff = aux;
+			} else { b.L = 2 * N - 2; b.preOp = OP_DCT1_PRE; b.postOp = OP_DCT1_POST; }
+		}
 		else { b.L = 2 * N + 2; b.preOp = OP_DST1_PRE; b.postOp = OP_DST1_POST; }
 		break;
 	case 2: case 3: if (N % 2 == 0 && N >= 4) {
