@@ -149,6 +149,22 @@ def test_r2r_whose_embedding_length_needs_bluestein(run, oracle, N, dp, type, ds
     parity.check_r2r(run, oracle, (N,), 6, dp, type, dst)
 
 
+@pytest.mark.parametrize("shape", [(17, 17), (23, 19, 5), (37, 37, 37), (8, 947), (33, 83), (16, 2, 257)])
+@pytest.mark.parametrize("dp", [False, True])
+def test_prime_planes_use_the_column_bluestein_kernel(run, oracle, shape, dp):
+    """strided axes of non-smooth length (the reference's sample-7 systems): one pass of pow2_col_blue_kernel (MODE 5) per axis"""
+    up = parity.check_c2c(run, oracle, shape, 2, dp, kind="bluestein", use_c_oracle=False)
+    assert up == [1] * len(shape)
+    if dp and max(shape[1:]) > 512:
+        return  # fp64 column tiles reach 1024 padded points: longer strided axes stay on the generic kernel
+    buf = np.zeros(int(np.prod(shape)) * 2, np.complex128 if dp else np.complex64)
+    app = api.App(list(shape), 2, dp=dp, buffer_ptr=buf.ctypes.data, lib=run.lib)
+    names = C.create_string_buffer(1024)
+    run.lib.vkfftMI355XDescribePlan(C.byref(app.app), 0, names, 1024)
+    app.delete()
+    assert "pow2_col_blue_kernel" in names.value.decode()
+
+
 def test_golden_reference_fixtures(run, golden):
     """library (emulated) vs the reference's own outputs captured on an MI355X"""
     mod, data = golden

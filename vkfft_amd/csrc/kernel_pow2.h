@@ -278,6 +278,38 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
 #pragma unroll
 		for (int m = 0; m < E; m++) gb_store<T>(gout, lane, m * step, cswap(v[m]));
+	} else if constexpr (MODE == 5) {
+		// ONE-pass Bluestein along a strided axis (prime x prime planes, the reference's sample 7): the column tile's rows j < opN are the
+		// sequence, rows up to L = M are its zero padding; chirp multiply, FFT_M, * FFT(chirp)/M, inverse FFT_M (swap identity), chirp multiply —
+		// everything in registers and one LDS tile, lanes along the TC neighbouring columns on both sides (pow2_blue_kernel is the row form)
+		const GBuf gch = make_gbuf(p.aux), gbh = make_gbuf(p.aux2);
+		const uint32_t n = p.opN;
+		const uint32_t laneIn = valid ? (tau * (uint32_t)p.inStrideJ + c * (uint32_t)p.dim[0].inStride) * ES : kGbInvalid;
+		const uint32_t stepIn = (uint32_t)(TPF * (uint32_t)p.inStrideJ) * ES;
+#pragma unroll
+		for (int m = 0; m < E / 2; m++) { // opN <= M/2: rows of the upper half are padding
+			const uint32_t pos = tau + m * TPF;
+			cx<T> x = gb_load<T>(gin, pos < n ? laneIn : kGbInvalid, m * stepIn);
+			if (p.bluesteinSwapIn) x = cswap(x);
+			v[m] = cmulc(x, gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0));
+		}
+#pragma unroll
+		for (int m = E / 2; m < E; m++) v[m] = cx<T>{(T)0, (T)0};
+		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], gb_load<T>(gbh, (tau + m * TPF) * ES, 0)));
+		if constexpr (SCH::NS > 1) VKFFT_SYNC(); // the exchange buffer is reused
+		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
+		const uint32_t laneOut = valid ? (tau * (uint32_t)p.outStrideJ + c * (uint32_t)p.dim[0].outStride) * ES : kGbInvalid;
+		const uint32_t stepOut = (uint32_t)(TPF * (uint32_t)p.outStrideJ) * ES;
+#pragma unroll
+		for (int m = 0; m < E / 2; m++) {
+			const uint32_t pos = tau + m * TPF;
+			cx<T> y = cmulc(cswap(v[m]), gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0));
+			if (p.bluesteinSwapOut) y = cswap(y);
+			if (sc != (T)1) y = cscale(y, sc);
+			gb_store<T>(gout, pos < n ? laneOut : kGbInvalid, m * stepOut, y);
+		}
 	} else if constexpr (MODE == 4) {
 		// middle pass of a three-factor inverse run backwards, in place in the column layout: conj twiddle, inverse column FFT
 		const uint32_t lane = valid ? (tau * (uint32_t)p.inStrideJ + c) * ES : kGbInvalid;
@@ -424,13 +456,15 @@ template <typename T, typename SCH, int TC, int MODE> void pow2_col_blue_launch(
 struct Pow2ColBlueVariant { Pow2Variant v; int mode; };
 #define VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, mode) \
 	{ { (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, tc, (((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (tc)), &pow2_col_blue_launch<T, Pow2Sched<b0, b1, b2, b3>, tc, mode> }, mode }
-#define VKFFT_P2CB(T, dp, b0, b1, b2, b3, tc) VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 1), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 2), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 3), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 4)
+#define VKFFT_P2CB(T, dp, b0, b1, b2, b3, tc) VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 1), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 2), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 3), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 4), \
+	VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 5)
 static const Pow2ColBlueVariant kPow2ColBlueVariants[] = {
 	VKFFT_P2CB(float, false, 3, 3, 0, 0, 32),
 	VKFFT_P2CB(float, false, 4, 3, 0, 0, 32),
 	VKFFT_P2CB(float, false, 4, 4, 0, 0, 32),
 	VKFFT_P2CB(float, false, 4, 3, 2, 0, 16),
 	VKFFT_P2CB(float, false, 4, 3, 3, 0, 16),
+	VKFFT_P2CB1(float, false, 4, 4, 3, 0, 8, 5), // one-pass column Bluestein on 2048 padded points (147 KiB tile)
 	VKFFT_P2CB(double, true, 3, 3, 0, 0, 16),
 	VKFFT_P2CB(double, true, 3, 2, 2, 0, 16),
 	VKFFT_P2CB(double, true, 3, 3, 2, 0, 16),

@@ -175,6 +175,20 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 			for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
 		}
 	}
+	// ... and its column form for strided axes (tiles of neighbouring columns, one pass)
+	const bool fusedBluesteinCol = b.preOp == OP_BLUESTEIN_PRE && b.midOp == OP_BLUESTEIN_MID && b.postOp == OP_BLUESTEIN_POST && b.colIn && b.colOut && b.auxOff2ForPre == (size_t)-1;
+	if (fusedBluesteinCol && b.allowOp && b.fastKernel == KERNEL_GENERIC && (b.L & (b.L - 1)) == 0 && !b.forceT && b.radices.empty()) {
+		int variant, bits[4], tc, thr;
+		const uint64_t esz = b.dp ? 16 : 8;
+		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
+		const uint64_t spanIn = (b.L * (uint64_t)std::llabs(b.inStrideJ) + 64 * (uint64_t)std::llabs(d0.inStride)) * esz;
+		const uint64_t spanOut = (b.L * (uint64_t)std::llabs(b.outStrideJ) + 64 * (uint64_t)std::llabs(d0.outStride)) * esz;
+		if (spanIn < 0x7FFFFF00ull && spanOut < 0x7FFFFF00ull && b.opN * 2 <= b.L && pow2_col_blue_lookup(ilog2(b.L), b.dp, 5, &variant, bits, &tc, &thr)) {
+			b.fastKernel = KERNEL_POW2_COL_BLUE; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)tc;
+			b.radices.clear();
+			for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
+		}
+	}
 	// (column tile in, per-column contiguous run out = the first Four-Step pass: the transposed-store variant)
 	const bool transOut = b.colIn && !b.colOut && b.preOp == OP_NONE && (b.postOp == OP_NONE || b.postOp == OP_TWIDDLE_4STEP) && b.outStrideJ == 1 && !b.realIn && !b.realOut;
 	if (b.allowOp && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && (b.colIn == b.colOut || transOut) && b.radices.empty()
@@ -864,6 +878,14 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		uint64_t Mp = 64; while (Mp < 2 * j.N - 1) Mp *= 2; // measured: the power-of-two padded length wins even at 1.6x the {1,3,5}*2^k one
 		int v, bits[4], fpw, thr;
 		if ((rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && pow2_blue_lookup(ilog2(Mp), dp, &v, bits, &fpw, &thr)) fusedM = Mp;
+	}
+	if (!unit && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !j.others.empty()
+	    && j.others[0].inStride == 1 && j.others[0].outStride == 1) {
+		// strided axes of non-smooth length (prime x prime planes): the one-pass column Bluestein kernel on the power-of-two padded length beats
+		// the interpreter's Rader / Bluestein stages by 3-6x (measured on the reference's sample-7 systems)
+		uint64_t Mp = 64; while (Mp < 2 * j.N - 1) Mp *= 2;
+		int v, bits[4], tc, thr;
+		if (pow2_col_blue_lookup(ilog2(Mp), dp, 5, &v, bits, &tc, &thr)) fusedM = Mp;
 	}
 	if (!smoothOK || fusedM) {
 		// Bluestein (chirp-z) through a padded smooth length M >= 2N-1
