@@ -9,9 +9,10 @@ from gen_mixed_table import best_radices
 
 POW2 = [1 << k for k in range(2, 14)]  # complex FFT lengths up to 8192 (fp32) / 4096 (fp64): R2C rows up to 16384 / 8192 reals
 # complex FFT lengths L of popular non-power-of-two real sizes (N = L for DCT-II/III, N = 2L for R2C / DCT-IV)
-NONPOW2 = [6, 10, 12, 20, 24, 30, 40, 48, 50, 60, 80, 96, 100, 120, 125, 160, 192, 200, 240, 243, 250, 320, 343, 360, 384, 400, 480, 500, 540, 600, 625,
+NONPOW2 = [6, 10, 12, 20, 24, 30, 36, 40, 48, 50, 60, 72, 80, 90, 96, 100, 108, 120, 125, 144, 150, 160, 180, 192, 200, 216, 240, 243, 250, 270, 300, 320, 324, 343, 350, 360, 384, 400,
+           432, 450, 480, 500, 540, 600, 625,
            640, 720, 729, 768, 800, 960, 1000, 1080, 1200, 1280, 1440, 1536, 1600, 1920, 2000, 2160, 2187, 2400, 2560, 3000, 3072, 3125, 3840, 4000]
-NONPOW2_DP = [12, 24, 48, 60, 96, 100, 120, 192, 200, 240, 360, 384, 480, 500, 540, 600, 720, 768, 960, 1000, 1080, 1200, 1536, 1920, 2000]
+NONPOW2_DP = [12, 24, 48, 60, 96, 100, 120, 150, 192, 200, 240, 300, 350, 360, 384, 480, 500, 540, 600, 720, 768, 960, 1000, 1080, 1200, 1536, 1920, 2000]
 
 # family -> (pre, post, real data?, row?, col?, pow2 only?)
 FAMILIES = {

@@ -402,6 +402,7 @@ constexpr int kNumPow2Variants = (int)(sizeof(kPow2Variants) / sizeof(kPow2Varia
 
 // column kernels: first entry of each (log2n, dp) is the default; VKFFT_MI355X_P2C<log2n>=k selects the k-th
 static const Pow2Variant kPow2ColVariants[] = {
+	VKFFT_P2C(float, false, 1, 0, 0, 0, 64), VKFFT_P2C(float, false, 2, 0, 0, 0, 64), VKFFT_P2C(float, false, 3, 0, 0, 0, 64), // thin axes (a depth of 2, 4, 8): one butterfly per thread
 	VKFFT_P2C(float, false, 2, 2, 0, 0, 32), VKFFT_P2C(float, false, 2, 2, 0, 0, 16),
 	VKFFT_P2C(float, false, 3, 2, 0, 0, 32), VKFFT_P2C(float, false, 3, 2, 0, 0, 16),
 	VKFFT_P2C(float, false, 3, 3, 0, 0, 32), VKFFT_P2C(float, false, 3, 3, 0, 0, 16),
@@ -409,6 +410,7 @@ static const Pow2Variant kPow2ColVariants[] = {
 	VKFFT_P2C(float, false, 4, 4, 0, 0, 32), VKFFT_P2C(float, false, 4, 4, 0, 0, 16), VKFFT_P2C(float, false, 3, 3, 2, 0, 32), VKFFT_P2C(float, false, 3, 3, 2, 0, 16), VKFFT_P2C(float, false, 5, 3, 0, 0, 32),
 	VKFFT_P2C(float, false, 5, 4, 0, 0, 32), VKFFT_P2C(float, false, 4, 3, 2, 0, 16), VKFFT_P2C(float, false, 4, 3, 2, 0, 32), VKFFT_P2C(float, false, 3, 3, 3, 0, 16), VKFFT_P2C(float, false, 5, 4, 0, 0, 16),
 	VKFFT_P2C(float, false, 5, 5, 0, 0, 16), VKFFT_P2C(float, false, 4, 3, 3, 0, 16), VKFFT_P2C(float, false, 4, 3, 3, 0, 8),
+	VKFFT_P2C(double, true, 1, 0, 0, 0, 32), VKFFT_P2C(double, true, 2, 0, 0, 0, 32), VKFFT_P2C(double, true, 3, 0, 0, 0, 32),
 	VKFFT_P2C(double, true, 2, 2, 0, 0, 16),
 	VKFFT_P2C(double, true, 3, 2, 0, 0, 16),
 	VKFFT_P2C(double, true, 3, 3, 0, 0, 16),

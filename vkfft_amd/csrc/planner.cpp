@@ -149,7 +149,7 @@ static void collapse_dims(std::vector<HostDim>& d) {
 static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	PassBuild b = bIn;
 	// strided-tile passes of power-of-two length run on the hand-specialised column kernel
-	if (b.allowFast && b.fastKernel == KERNEL_GENERIC && b.colIn && b.L >= 16 && b.L <= 1024 && (b.L & (b.L - 1)) == 0 && b.preOp == OP_NONE
+	if (b.allowFast && b.fastKernel == KERNEL_GENERIC && b.colIn && b.L >= 2 && b.L <= 1024 && (b.L & (b.L - 1)) == 0 && b.preOp == OP_NONE
 	    && b.midOp == OP_NONE && (b.postOp == OP_NONE || b.postOp == OP_TWIDDLE_4STEP) && !b.realIn && !b.realOut && !b.forceT) {
 		int variant, bits[4], tc, thr;
 		// buffer addressing of the fast kernels: a tile must span less than 2 GiB on both sides
