@@ -165,6 +165,19 @@ def test_prime_planes_use_the_column_bluestein_kernel(run, oracle, shape, dp):
     assert "pow2_col_blue_kernel" in names.value.decode()
 
 
+@pytest.mark.parametrize("shape,dp", [((8, 1087), False), ((37, 3, 1229), False), ((33, 1031, 2), True), ((20, 2909), False)])
+def test_long_strided_axis_of_non_smooth_length_runs_as_transposed_rows(run, oracle, shape, dp):
+    """padded length above the column Bluestein kernel's reach: transpose into scratch, fused Bluestein on unit-stride rows, transpose back"""
+    up = parity.check_c2c(run, oracle, shape, 2, dp, kind="bluestein", use_c_oracle=False)
+    assert up == [1] * len(shape)
+    buf = np.zeros(int(np.prod(shape)) * 2, np.complex128 if dp else np.complex64)
+    app = api.App(list(shape), 2, dp=dp, buffer_ptr=buf.ctypes.data, lib=run.lib)
+    names = C.create_string_buffer(1024)
+    run.lib.vkfftMI355XDescribePlan(C.byref(app.app), 0, names, 1024)
+    app.delete()
+    assert names.value.decode().count("transpose_kernel") == 2
+
+
 def test_golden_reference_fixtures(run, golden):
     """library (emulated) vs the reference's own outputs captured on an MI355X"""
     mod, data = golden

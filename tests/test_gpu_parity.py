@@ -736,7 +736,7 @@ def test_repeated_launches_are_bit_identical(product_lib, kw):
     assert bad == 0, bad
 
 
-@pytest.mark.parametrize("shape,dp", [((17, 17), False), ((97, 97), False), ((37, 37, 37), False), ((89, 89, 89), True), ((947, 947), False), ((64, 3, 1021), False), ((419, 419), True)])
+@pytest.mark.parametrize("shape,dp", [((17, 17), False), ((97, 97), False), ((37, 37, 37), False), ((89, 89, 89), True), ((947, 947), False), ((64, 3, 1021), False), ((419, 419), True), ((1087, 1087), False), ((2909, 300), False), ((96, 5, 1523), True), ((7727, 7727), False)])
 def test_prime_planes(run, oracle, shape, dp):
     """the reference's sample-7 systems (prime x prime, prime^3): fused Bluestein on the rows, one-pass column Bluestein on the strided axes"""
     up = parity.check_c2c(run, oracle, shape, 1, dp, kind="bluestein", use_c_oracle=False)

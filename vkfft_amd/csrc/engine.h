@@ -11,7 +11,7 @@
 namespace vkfft_mi355x {
 
 enum BufRole : int { ROLE_BUFFER = 0, ROLE_TEMP = 1, ROLE_INPUT = 2, ROLE_OUTPUT = 3 };
-enum KernelKind : int { KERNEL_GENERIC = 0, KERNEL_POW2_ROW = 1, KERNEL_POW2_COL = 2, KERNEL_R2C_PAIR = 3, KERNEL_MIXED_ROW = 5, KERNEL_OPFFT = 6, KERNEL_POW2_BLUE = 7, KERNEL_POW2_COL_BLUE = 8, KERNEL_POW2_BLUE_R2R = 9, KERNEL_POW2_FUSED = 10 };
+enum KernelKind : int { KERNEL_GENERIC = 0, KERNEL_POW2_ROW = 1, KERNEL_POW2_COL = 2, KERNEL_R2C_PAIR = 3, KERNEL_MIXED_ROW = 5, KERNEL_OPFFT = 6, KERNEL_POW2_BLUE = 7, KERNEL_POW2_COL_BLUE = 8, KERNEL_POW2_BLUE_R2R = 9, KERNEL_POW2_FUSED = 10, KERNEL_TRANSPOSE = 11 };
 
 struct HostDim {
 	uint64_t count;
@@ -117,6 +117,8 @@ int launch_opfft(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 // convolution product and zero padding (kernels_aux.hip)
 int launch_conv_pointwise(const ConvParams& p, bool dp, hipStream_t stream);
 int launch_zero_slab(const ZeroParams& p, hipStream_t stream);
+// tile transposition of a strided axis against its unit-stride companion (kernels_aux.hip): awkward strided axes run as rows of a dense scratch copy
+int launch_transpose(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 
 // misc
 std::vector<uint32_t> factorize_radices(uint64_t n, bool* smooth);

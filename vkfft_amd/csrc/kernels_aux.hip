@@ -6,6 +6,7 @@
 //     takes it as zero; here the range is written with zeros before the transform that would read it.
 #include "engine.h"
 #include "butterflies.h"
+#include "memops.h"
 
 namespace vkfft_mi355x {
 
@@ -94,6 +95,41 @@ int launch_zero_slab(const ZeroParams& p, hipStream_t stream) {
 		const uint32_t ns = p.systems - s0 < 65535u ? p.systems - s0 : 65535u;
 		hipLaunchKernelGGL(zero_slab_kernel, dim3((uint32_t)((n + 255) / 256), ns), dim3(256), 0, stream, q);
 	}
+	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
+
+// out[j * outStrideJ + c * dim0.outStride + outer] = in[j * inStrideJ + c * dim0.inStride + outer] for j < L, c < dim0.count: 32 x 32 tiles through
+// LDS, lanes along c on the read side and along j on the write side (the planner names the dimensions so that these are the unit-stride ones)
+template <typename T> __global__ void __launch_bounds__(256) transpose_kernel(const PassParams p) {
+	__shared__ cx<T> tile[32][33];
+	const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;
+	const uint32_t tilesC = (p.dim[0].count + 31u) / 32u, tilesJ = (p.L + 31u) / 32u;
+	uint32_t b = blockIdx.x;
+	const uint32_t tc = b % tilesC; b /= tilesC;
+	const uint32_t tj = b % tilesJ; b /= tilesJ;
+	const uint32_t g1 = b % p.dim[1].count, g2 = b / p.dim[1].count;
+	const cx<T>* in = (const cx<T>*)p.in + ((int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride);
+	cx<T>* out = (cx<T>*)p.out + ((int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride);
+	const uint32_t j0 = tj * 32u, c0 = tc * 32u;
+#pragma unroll
+	for (uint32_t r = 0; r < 4; r++) {
+		const uint32_t j = j0 + ty + 8u * r, c = c0 + tx;
+		if (j < p.L && c < p.dim[0].count) tile[ty + 8u * r][tx] = in[(int64_t)j * p.inStrideJ + (int64_t)c * p.dim[0].inStride];
+	}
+	VKFFT_SYNC();
+#pragma unroll
+	for (uint32_t r = 0; r < 4; r++) {
+		const uint32_t c = c0 + ty + 8u * r, j = j0 + tx;
+		if (j < p.L && c < p.dim[0].count) out[(int64_t)j * p.outStrideJ + (int64_t)c * p.dim[0].outStride] = tile[tx][ty + 8u * r];
+	}
+}
+
+int launch_transpose(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
+	const uint64_t blocks = (uint64_t)((prm.dim[0].count + 31u) / 32u) * ((prm.L + 31u) / 32u) * prm.dim[1].count * prm.dim[2].count;
+	if (blocks == 0) return 0;
+	if (blocks > 0x7fffffffull) return 4039;
+	if (pp.dp) hipLaunchKernelGGL(transpose_kernel<double>, dim3((uint32_t)blocks), dim3(256), 0, stream, prm);
+	else hipLaunchKernelGGL(transpose_kernel<float>, dim3((uint32_t)blocks), dim3(256), 0, stream, prm);
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
 }
 
