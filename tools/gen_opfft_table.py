@@ -87,6 +87,10 @@ def plan_row(n, dp, pair=None):
                 rad = order
                 tpf = min(cands)  # fewest threads that keep every stage within the register budget... smallest admissible divisor
                 tpf = max(c for c in cands if c <= max(tpf_for(n, rad, 16), min(cands)))
+    if n <= 64:
+        # short rows: with one or two threads per FFT the lanes of a wave are a whole row apart (dozens of cache lines per access, measured
+        # 1.0-1.6 TB/s on 64-point real rows); eight threads per FFT read 64-byte runs
+        tpf = max(tpf, min(8, max(n // r for r in rad)))
     if tpf > 1024:
         return None
     lds_per = pitch(n, 1, False) * es
