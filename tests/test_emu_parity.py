@@ -149,7 +149,7 @@ def test_r2r_whose_embedding_length_needs_bluestein(run, oracle, N, dp, type, ds
     parity.check_r2r(run, oracle, (N,), 6, dp, type, dst)
 
 
-@pytest.mark.parametrize("shape", [(17, 17), (23, 19, 5), (37, 37, 37), (8, 947), (33, 83), (16, 2, 257)])
+@pytest.mark.parametrize("shape", [(53, 53), (41, 43, 5), (37, 37, 37), (8, 947), (33, 83), (16, 2, 257)])
 @pytest.mark.parametrize("dp", [False, True])
 def test_prime_planes_use_the_column_bluestein_kernel(run, oracle, shape, dp):
     """strided axes of non-smooth length (the reference's sample-7 systems): one pass of pow2_col_blue_kernel (MODE 5) per axis"""
@@ -176,6 +176,21 @@ def test_long_strided_axis_of_non_smooth_length_runs_as_transposed_rows(run, ora
     run.lib.vkfftMI355XDescribePlan(C.byref(app.app), 0, names, 1024)
     app.delete()
     assert names.value.decode().count("transpose_kernel") == 2
+
+
+@pytest.mark.parametrize("shape", [(17,), (31,), (17, 17), (23, 19, 5), (29, 29, 29)])
+@pytest.mark.parametrize("dp", [False, True])
+def test_small_primes_use_direct_butterflies(run, oracle, shape, dp):
+    """17 .. 31 are radices of the mixed-radix row kernel and the strided op-FFT kernel (direct symmetric butterfly in registers)"""
+    up = parity.check_c2c(run, oracle, shape, 70, dp, use_c_oracle=False)
+    assert up == [1] * len(shape)
+    buf = np.zeros(int(np.prod(shape)) * 2, np.complex128 if dp else np.complex64)
+    app = api.App(list(shape), 2, dp=dp, buffer_ptr=buf.ctypes.data, lib=run.lib)
+    names = C.create_string_buffer(1024)
+    run.lib.vkfftMI355XDescribePlan(C.byref(app.app), 0, names, 1024)
+    app.delete()
+    got = names.value.decode()
+    assert "blue" not in got and "mixed_row_kernel" in got and (len(shape) == 1 or "opfft_kernel" in got)
 
 
 def test_golden_reference_fixtures(run, golden):

@@ -5,7 +5,7 @@ with a fused pre/post map: R2C/C2R even split, DCT/DST I-IV, strided C2C of non-
 Re-run after changing the heuristics; the generated files are committed."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from gen_mixed_table import best_radices
+from gen_mixed_table import best_radices, DIRECT_PRIMES
 
 POW2 = [1 << k for k in range(2, 14)]  # complex FFT lengths up to 8192 (fp32) / 4096 (fp64): R2C rows up to 16384 / 8192 reals
 # complex FFT lengths L of popular non-power-of-two real sizes (N = L for DCT-II/III, N = 2L for R2C / DCT-IV)
@@ -137,7 +137,7 @@ def main():
                 if (col and not col_ok) or (not col and not row_ok): continue
                 fourstep = fam in ("c2c", "c2c4", "c2cT")
                 oddreal = fam in ("r2cf", "c2rf")
-                for n in sorted(set(lens) | (set(FOURSTEP_EXTRA) if fourstep and not dp else set()) | (set(ODD_EXTRA) if oddreal else set())):
+                for n in sorted(set(lens) | (set(FOURSTEP_EXTRA) if fourstep and not dp else set()) | (set(ODD_EXTRA) if oddreal else set()) | (set(DIRECT_PRIMES) if fam == "c2c" else set())):
                     ispow2 = n & (n - 1) == 0
                     if oddreal and n % 2 == 0: continue
                     if pow2only and not ispow2: continue

@@ -873,13 +873,19 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		int v, r5[5], f, t;
 		smoothNoInstance = !mixed_row_lookup(j.N, dp, &v, r5, &f, &t);
 	}
-	if (unit && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && (!smooth13(j.N) || smoothNoInstance)) {
+	// prime lengths with a direct butterfly instance (17 .. 47: tools/gen_mixed_table.py DIRECT_PRIMES) stay on the radix kernels
+	bool nativeInstance = false;
+	if (!d.disableFastKernels && !smooth13(j.N) && j.N <= 64) {
+		int v, r5[5], f, t;
+		nativeInstance = unit ? mixed_row_lookup(j.N, dp, &v, r5, &f, &t) : opfft_lookup(j.N, dp, true, false, OP_NONE, OP_NONE, &v, r5, &f, &t);
+	}
+	if (unit && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && (!smooth13(j.N) || smoothNoInstance)) {
 		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
 		uint64_t Mp = 64; while (Mp < 2 * j.N - 1) Mp *= 2; // measured: the power-of-two padded length wins even at 1.6x the {1,3,5}*2^k one
 		int v, bits[4], fpw, thr;
 		if ((rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && pow2_blue_lookup(ilog2(Mp), dp, &v, bits, &fpw, &thr)) fusedM = Mp;
 	}
-	if (!unit && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !j.others.empty()
+	if (!unit && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !j.others.empty()
 	    && j.others[0].inStride == 1 && j.others[0].outStride == 1) {
 		// strided axes of non-smooth length (prime x prime planes): the one-pass column Bluestein kernel on the power-of-two padded length beats
 		// the interpreter's Rader / Bluestein stages by 3-6x (measured on the reference's sample-7 systems)
@@ -887,7 +893,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		int v, bits[4], tc, thr;
 		if (pow2_col_blue_lookup(ilog2(Mp), dp, 5, &v, bits, &tc, &thr)) fusedM = Mp;
 	}
-	if (!unit && !fusedM && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !j.others.empty() && j.others.size() <= 3
+	if (!unit && !fusedM && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !j.others.empty() && j.others.size() <= 3
 	    && j.others[0].inStride == 1 && j.others[0].outStride == 1 && j.inStrideJ > 0 && j.outStrideJ > 0) {
 		// a strided axis of non-smooth length beyond the reach of the column Bluestein kernel (padded length above 2048): transpose it against its
 		// unit-stride companion into a dense scratch copy, run it there as unit-stride rows (the fused Bluestein row kernel) and transpose back.
