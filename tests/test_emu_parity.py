@@ -30,7 +30,8 @@ def test_mixed_radix(run, oracle, N, dp):
 def _mixed_table_sizes():
     import os, re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    txt = "".join(open(os.path.join(root, "vkfft_amd", "csrc", "mixed_table_%d.inc" % h)).read() for h in range(3))
+    import glob
+    txt = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(root, "vkfft_amd", "csrc", "mixed_table_*.inc"))))
     return sorted(set(int(m) for m in re.findall(r"// N=(\d+)", txt)))
 
 

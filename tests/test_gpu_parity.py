@@ -235,7 +235,8 @@ def test_every_mixed_radix_table_entry(run, oracle):
     buffer-store data hazard (memops.h)."""
     import os, re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    txt = "".join(open(os.path.join(root, "vkfft_amd", "csrc", "mixed_table_%d.inc" % h)).read() for h in range(3))
+    import glob
+    txt = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(root, "vkfft_amd", "csrc", "mixed_table_*.inc"))))
     for N in sorted(set(int(m) for m in re.findall(r"// N=(\d+)", txt))):
         for dp in (False, True):
             if dp and N > 4096:

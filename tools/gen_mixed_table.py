@@ -1,24 +1,23 @@
 #!/usr/bin/env python3
-"""Generates vkfft_amd/csrc/mixed_table_{0,1,2}.inc: the curated list of non-power-of-two lengths that get a hand-specialised
+"""Generates vkfft_amd/csrc/mixed_table_{0..5}.inc: the curated list of non-power-of-two lengths that get a hand-specialised
 ahead-of-time kernel (kernel_mixed.h).  For every length: radix list (fewest stages, radices <= 16), threads per FFT,
 FFTs per workgroup.  Re-run after changing the heuristics; the generated file is committed."""
 import itertools, math, os, sys
 
 ALLOWED = [16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2]
-# measured (DESIGN.md 4.4): the composite radix 25 = 5*5 pays off where it removes two stages (5^5: 5 -> 3 stages, +13 %), not in
-# mixed lengths (4000 = 25*16*10: -2 %); radix 27 = 9*3 was slower everywhere (3^7: -11 %) and is not used
-def allowed_for(n):
-    m = n
-    while m % 5 == 0: m //= 5
-    return ([25] if m == 1 and n >= 125 else []) + ALLOWED
-
 # primes whose butterfly is the direct symmetric form in registers ((p-1)^2 FMAs per transform: cheaper than Bluestein on 64 padded points, and
 # the reference's sample 7 is made of such axes); a thread owns a whole transform.  From 37 on the butterfly does not fit the register file
 # (measured: 37^3 and 47^2 at 0.03 TB/s, all scratch traffic) — those stay on the Bluestein kernels
 DIRECT_PRIMES = [17, 19, 23, 29, 31]
 
+# measured (DESIGN.md 4.4): the composite radix 25 = 5*5 pays off where it removes two stages (5^5: 5 -> 3 stages, +13 %), not in
+# mixed lengths (4000 = 25*16*10: -2 %); radix 27 = 9*3 was slower everywhere (3^7: -11 %) and is not used
+def allowed_for(n):
+    m = n
+    while m % 5 == 0: m //= 5
+    return ([25] if m == 1 and n >= 125 else []) + [p for p in reversed(DIRECT_PRIMES) if n % p == 0] + ALLOWED
+
 def best_radices(n, max_stages=5):
-    if n in DIRECT_PRIMES: return [n]
     best = None
     def rec(rem, seq):
         nonlocal best
@@ -88,6 +87,12 @@ def sizes():
         if n & (n - 1) and smooth(n, (2, 3, 5, 7, 11, 13)): s.add(n)
     s.update([1001, 1287, 7000])
     s.update(DIRECT_PRIMES)
+    # lengths whose largest prime factor is 17 .. 31 (the direct butterflies as radices of a mixed schedule): up to 2048 (fp64: 1024, see main)
+    for n in range(34, 2049):
+        m = n
+        for q in (2, 3, 5, 7, 11, 13) + tuple(DIRECT_PRIMES):
+            while m % q == 0: m //= q
+        if m == 1 and not smooth(n, (2, 3, 5, 7, 11, 13)): s.add(n)
     # every 13-smooth length up to 4096 (fp64: up to 2048, see main): the alternative for such a length is the fused Bluestein kernel on twice
     # to four times the points (1092 = 4*3*7*13 ran at 1.2 TB/s against the reference's 5.1)
     for n in range(1025, 4097):
@@ -111,12 +116,13 @@ if __name__ == "__main__":
             if cnt >= limit: break
             if dp and n > 4096: continue
             if dp and n > 2048 and not (smooth(n, (2, 3, 5, 7)) or smooth(n, (2, 11)) or smooth(n, (2, 13))): continue
+            if dp and n > 1024 and not smooth(n, (2, 3, 5, 7, 11, 13)): continue
             r = plan(n, dp)
             if r is None: continue
             rad, tpf, fpw = r
             rr = rad + [1] * (5 - len(rad))
             lines.append("VKFFT_MX(%s, %s, %d, %d, %d, %d, %d, %d, %d) // N=%d" % (tname, "true" if dp else "false", *rr, tpf, fpw, n))
             cnt += 1
-    for part in range(3):  # three translation units (kernels_mixed_{0,1,2}.hip), entries dealt round-robin
-        open(os.path.join(root, "mixed_table_%d.inc" % part), "w").write("\n".join([head] + lines[part::3]) + "\n")
+    for part in range(6):  # six translation units (kernels_mixed_{0..5}.hip), entries dealt round-robin
+        open(os.path.join(root, "mixed_table_%d.inc" % part), "w").write("\n".join([head] + lines[part::6]) + "\n")
     print("wrote", len(lines), "entries")

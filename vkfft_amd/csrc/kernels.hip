@@ -61,13 +61,21 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
 }
 
-// ---- mixed-radix registry: three table parts, one translation unit each (kernels_mixed_*.hip) --------------------
+// ---- mixed-radix registry: six table parts, one translation unit each (kernels_mixed_*.hip) --------------------
+constexpr int kMixedParts = 6;
 const MixedVariant* mixed_table_0(int*);
 const MixedVariant* mixed_table_1(int*);
 const MixedVariant* mixed_table_2(int*);
-static const MixedVariant* mixed_part(int part, int* count) { return part == 0 ? mixed_table_0(count) : part == 1 ? mixed_table_1(count) : mixed_table_2(count); }
+const MixedVariant* mixed_table_3(int*);
+const MixedVariant* mixed_table_4(int*);
+const MixedVariant* mixed_table_5(int*);
+static const MixedVariant* mixed_part(int part, int* count) {
+	typedef const MixedVariant* (*Fn)(int*);
+	static const Fn fns[kMixedParts] = {&mixed_table_0, &mixed_table_1, &mixed_table_2, &mixed_table_3, &mixed_table_4, &mixed_table_5};
+	return fns[part % kMixedParts](count);
+}
 bool mixed_row_lookup(uint64_t n, bool dp, int* variant, int rad[5], int* fpw, int* threads) {
-	for (int part = 0; part < 3; part++) {
+	for (int part = 0; part < kMixedParts; part++) {
 		int cnt = 0;
 		const MixedVariant* tab = mixed_part(part, &cnt);
 		for (int i = 0; i < cnt; i++) {
@@ -84,7 +92,7 @@ int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream) 
 	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
 	if (grid64 == 0) return 0;
 	int cnt = 0;
-	const MixedVariant* tab = mixed_part((pp.variant >> 16) % 3, &cnt);
+	const MixedVariant* tab = mixed_part((pp.variant >> 16) % kMixedParts, &cnt);
 	const int idx = pp.variant & 0xffff;
 	if (grid64 > 0x7fffffffull || pp.variant < 0 || idx >= cnt) return 4039;
 	tab[idx].launch(prm, dim3((uint32_t)grid64), stream);

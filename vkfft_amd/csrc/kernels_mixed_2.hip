@@ -1,4 +1,4 @@
-// Translation unit of the mixed-radix kernel family (kernel_mixed.h), table part 2 (generated mixed_table_2.inc); three
+// Translation unit of the mixed-radix kernel family (kernel_mixed.h), table part 2 (generated mixed_table_2.inc); six
 // parts so that a parallel build is not dominated by one file.
 #include "kernel_mixed.h"
 namespace vkfft_mi355x {
