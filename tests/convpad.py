@@ -161,3 +161,56 @@ ZEROPAD_CASES = [
     dict(shape=(40, 6), pads={0: (20, 40)}, dct=2),
     dict(shape=(1 << 15,), pads={0: (1 << 14, 1 << 15)}, batch=3),
 ]
+
+
+def conv_zeropad_case(run, shape, pads, *, m=1, r2c=False, dp=False, seed=0):
+    """the reference's sample 51 pattern: matrix convolution of zero-padded systems (garbage in the padded range of the data on entry)"""
+    rng = np.random.default_rng(seed)
+    rt = np.float64 if dp else np.float32
+    ct = np.complex128 if dp else np.complex64
+    dims = tuple(reversed(shape)); nd = len(dims); ax = tuple(range(-nd, 0))
+    nsys = m; ksys = m * m if m > 1 else 1
+    left = [0] * 4; right = [0] * 4; flag = [0] * 4
+    for a, (l, r) in pads.items():
+        left[a], right[a], flag[a] = l, r, 1
+    def mask(sh):
+        mk = np.ones(sh, bool)
+        for a, (l, r) in pads.items():
+            idx = [slice(None)] * len(sh); idx[len(sh) - 1 - a] = slice(l, r); mk[tuple(idx)] = False
+        return mk
+    if r2c:
+        nx = shape[0]; pad = dims[:-1] + (nx + 2,)
+        kern = rng.uniform(-1, 1, (ksys,) + dims).astype(rt); data = rng.uniform(-1, 1, (nsys,) + dims).astype(rt)
+        kbuf = np.zeros((ksys,) + pad, rt); kbuf[..., :nx] = kern
+        dbuf = rng.uniform(-1, 1, (nsys,) + pad).astype(rt); dbuf[..., :nx] = data
+        fwd = lambda a: np.fft.rfftn(a.astype(np.float64), axes=ax); inv = lambda a: np.fft.irfftn(a, s=dims, axes=ax)
+    else:
+        kern = (rng.uniform(-1, 1, (ksys,) + dims) + 1j * rng.uniform(-1, 1, (ksys,) + dims)).astype(ct)
+        data = (rng.uniform(-1, 1, (nsys,) + dims) + 1j * rng.uniform(-1, 1, (nsys,) + dims)).astype(ct)
+        kbuf, dbuf = kern.copy(), data.copy()
+        fwd = lambda a: np.fft.fftn(a.astype(np.complex128), axes=ax); inv = lambda a: np.fft.ifftn(a, axes=ax)
+    K, X = fwd(kern), fwd(np.where(mask(data.shape), data, 0))
+    Y = np.zeros_like(X)
+    for j in range(m):
+        for l in range(m):
+            Y[j] += K[_kernel_index(j, l, m, False) if m > 1 else 0] * X[l]
+    want = inv(Y)
+    hk, pk = run._alloc(kbuf); hd, pd = run._alloc(dbuf)
+    common = dict(dp=dp, r2c=r2c, lib=run.lib, normalize=True)
+    ka = api.App(list(shape), 1, buffer_ptr=pk, coordinateFeatures=ksys, kernelConvolution=1, **common)
+    ka.forward()
+    ca = api.App(list(shape), 1, buffer_ptr=pd, coordinateFeatures=nsys, performConvolution=1, matrixConvolution=m, kernel=pk,
+                 performZeropadding=flag, fft_zeropad_left=left, fft_zeropad_right=right, **common)
+    ca.forward()
+    got = run._fetch(hd, rt if r2c else ct).reshape(dbuf.shape)
+    ka.delete(); ca.delete()
+    if r2c:
+        got = got[..., : shape[0]]
+    return rel_l2(got, want)
+
+
+CONV_ZEROPAD_CASES = [
+    dict(shape=(32, 32, 32), pads={0: (16, 32), 1: (16, 32), 2: (16, 32)}, m=3, r2c=True),   # the reference's sample 51
+    dict(shape=(64, 48), pads={0: (32, 64), 1: (24, 48)}, m=2),
+    dict(shape=(128,), pads={0: (64, 128)}, m=1, dp=True),
+]

@@ -762,6 +762,13 @@ def test_zero_padding(run, case):
     assert err < (1e-13 if c.get("dp") else 3e-6), err
 
 
+@pytest.mark.parametrize("case", convpad.CONV_ZEROPAD_CASES, ids=lambda c: "x".join(map(str, c["shape"])) + f"-m{c['m']}")
+def test_convolution_of_zero_padded_systems(run, case):
+    c = dict(case); shape = c.pop("shape"); pads = c.pop("pads")
+    err = convpad.conv_zeropad_case(run, shape, pads, **c)
+    assert err < (1e-13 if c.get("dp") else 3e-5), err
+
+
 def _ref_lib():
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
