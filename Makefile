@@ -6,7 +6,8 @@ LIBDIR := vkfft_amd/lib
 CXXFLAGS := -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I$(CSRC) -Wno-unused-result
 OBJS := build/obj/api.o build/obj/planner.o build/obj/kernels.o build/obj/kernels_blue_r2r.o build/obj/kernels_fused.o build/obj/kernels_aux.o build/obj/kernels_mixed_0.o build/obj/kernels_mixed_1.o build/obj/kernels_mixed_2.o build/obj/kernels_mixed_3.o build/obj/kernels_mixed_4.o build/obj/kernels_mixed_5.o \
         $(foreach t,f32_row f32_col f64_row f64_col,build/obj/kernels_opfft_$(t)_0.o build/obj/kernels_opfft_$(t)_1.o)
-HDRS := $(wildcard $(CSRC)/*.h) include/vkFFT.h
+FUSED_HDRS := $(CSRC)/kernel_pow2_fused.h $(CSRC)/kernel_pow2_fused2.h
+HDRS := $(filter-out $(FUSED_HDRS),$(wildcard $(CSRC)/*.h)) include/vkFFT.h
 
 all: $(LIBDIR)/libvkfft_mi355x.so build/vkfft_mi355x_cli
 
@@ -27,10 +28,20 @@ $(LIBDIR)/libvkfft_mi355x.so: $(OBJS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
 
+# development build of the fused Four-Step kernels (per-phase cycle profile, arithmetic-free variants): tools/prof_fused.py,
+# selected with VKFFT_MI355X_LIB=build/libvkfft_mi355x_dev.so; never shipped
+build/obj/kernels_fused.o: $(FUSED_HDRS)
+build/obj/kernels_fused_dev.o: $(CSRC)/kernels_fused.hip $(HDRS) $(FUSED_HDRS)
+	@mkdir -p build/obj
+	$(HIPCC) $(CXXFLAGS) -DVKFFT_MI355X_DEV --offload-arch=$(ARCH) -c $< -o $@
+build/libvkfft_mi355x_dev.so: $(OBJS) build/obj/kernels_fused_dev.o
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(filter-out build/obj/kernels_fused.o,$(OBJS)) build/obj/kernels_fused_dev.o -o $@
+dev: build/libvkfft_mi355x_dev.so
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
 	rm -rf build/obj $(LIBDIR)/*.so
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean dev

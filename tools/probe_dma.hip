@@ -1,0 +1,175 @@
+// GPU probe (tools/, not product): LDS-DMA (buffer_load_dwordx4 ... lds) semantics on gfx950 and what a double-buffered column-tile stream built
+// on it reaches.  JSON lines.
+//   1. semantics: lane-linear destination, M0 beyond 64 KiB / 128 KiB, what an out-of-range lane writes, cache-policy bits accepted
+//   2. stream: persistent workgroups move column tiles (ROWS rows of SEG bytes, row stride = pitch) HBM -> LDS (DMA, two buffers) -> registers -> HBM
+//      (same tile position in a second buffer): the memory pattern of the fused Four-Step kernel's pass A read + pass B write, no arithmetic
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#include <functional>
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n",hipGetErrorString(e),__LINE__); exit(1);} }while(0)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline u32x4 mkrsrc(const void* p) {
+	const uint64_t a = (uint64_t)p;
+	u32x4 r; r.x = __builtin_amdgcn_readfirstlane((uint32_t)a); r.y = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) & 0xffffu; r.z = 0x7FFFFFF0u; r.w = 0x00020000u; return r;
+}
+__device__ inline __amdgpu_buffer_rsrc_t rsrc(const void* p) {
+	const uint64_t a = (uint64_t)p;
+	const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+	return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), (short)0, 0x7FFFFFF0, 0x00020000);
+}
+template <int AUX> __device__ inline void dma16(uint32_t ldsAddr, u32x4 rs, uint32_t voff, uint32_t soff) {
+	uint32_t keep;
+	if constexpr (AUX == 0) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "s"(ldsAddr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+	else if constexpr (AUX == 2) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "s"(ldsAddr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+	else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen sc1 lds\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "s"(ldsAddr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+#define RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// ---- 1. semantics
+__global__ void __launch_bounds__(64) k_sem(const uint32_t* src, uint32_t* out) {
+	__shared__ uint32_t lds[36864 + 256]; // 144 KiB + 1 KiB
+	const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+	const uint32_t lane = threadIdx.x;
+	for (uint32_t i = lane; i < 36864 + 256; i += 64) lds[i] = 0xAAAA0000u + i;
+	RAW_BARRIER();
+	const u32x4 rs = mkrsrc(src);
+	const uint32_t offs[4] = {0u, 66560u, 132096u, 146432u};
+	// lane l reads source piece (63 - l) (16 bytes); odd test: lanes 5 and 9 out of range
+	const uint32_t voff = (lane == 5 || lane == 9) ? 0x7FFFFFF8u : (63u - lane) * 16u;
+	dma16<0>(base + offs[0], rs, voff, 0);
+	dma16<2>(base + offs[1], rs, voff, 1024);
+	dma16<16>(base + offs[2], rs, voff, 2048);
+	dma16<0>(base + offs[3], rs, voff, 3072);
+	wait_vm<0>();
+	RAW_BARRIER();
+	for (int t = 0; t < 4; t++) for (uint32_t i = lane; i < 256; i += 64) out[t * 256 + i] = lds[offs[t] / 4 + i];
+	// neighbours (must be untouched)
+	if (lane < 4) out[1024 + lane] = lds[offs[1] / 4 - 1 - lane];
+	if (lane < 4) out[1028 + lane] = lds[offs[1] / 4 + 256 + lane];
+}
+
+// ---- 2. column-tile stream
+// tile = ROWS rows of SEG bytes; NT threads; a wave-instruction moves 1 KiB = 1024/SEG rows
+template <int ROWS, int SEG, int NT, int WPC, int LDAUX, int STAUX, int DMA>
+__global__ void __launch_bounds__(NT, (WPC * NT + 255) / 256) k_stream(const char* in, char* out, uint32_t pitch, uint32_t tilesPerMat, uint32_t nTiles) {
+	constexpr int TILEB = ROWS * SEG, NW = NT / 64, NI = TILEB / 1024, IPW = NI / NW, RPI = 1024 / SEG, LPR = SEG / 16;
+	constexpr int PERT = TILEB / 16 / NT; // 16-byte pieces per thread
+	static_assert(NI % NW == 0 && TILEB % (16 * NT) == 0, "shape");
+	__shared__ u32x4 lds[2 * TILEB / 16];
+	const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint64_t matB = (uint64_t)ROWS * pitch;
+	const uint32_t voffD = (lane / LPR) * pitch + (lane % LPR) * 16u;
+	// consumer mapping: thread handles piece p = tid + k*NT: row = p / LPR, piece = p % LPR
+	auto tileBase = [&](uint32_t t) -> uint64_t { return (uint64_t)(t / tilesPerMat) * matB + (uint64_t)(t % tilesPerMat) * SEG; };
+	if constexpr (DMA) {
+		uint32_t t = blockIdx.x;
+		if (t >= nTiles) return;
+		{
+			const u32x4 rs = mkrsrc(in + tileBase(t));
+#pragma unroll
+			for (int j = 0; j < IPW; j++) { const uint32_t ins = w * IPW + j; dma16<LDAUX>(base + ins * 1024u, rs, voffD, ins * RPI * pitch); }
+		}
+		uint32_t it = 0;
+		bool first = true;
+		for (; t < nTiles; t += gridDim.x, it ^= 1u) {
+			const uint32_t tn = t + gridDim.x;
+			if (tn < nTiles) {
+				const u32x4 rs = mkrsrc(in + tileBase(tn));
+#pragma unroll
+				for (int j = 0; j < IPW; j++) { const uint32_t ins = w * IPW + j; dma16<LDAUX>(base + (it ^ 1u) * TILEB + ins * 1024u, rs, voffD, ins * RPI * pitch); }
+				// queue: DMA(t), stores(prev), DMA(tn)
+				if (first) wait_vm<IPW>(); else wait_vm<IPW + PERT>();
+			} else wait_vm<0>();
+			first = false;
+			RAW_BARRIER();
+			const __amdgpu_buffer_rsrc_t ro = rsrc(out + tileBase(t));
+			u32x4 v[PERT];
+#pragma unroll
+			for (int k = 0; k < PERT; k++) v[k] = lds[it * (TILEB / 16) + tid + k * NT];
+#pragma unroll
+			for (int k = 0; k < PERT; k++) { const uint32_t p = tid + k * NT; __builtin_amdgcn_raw_buffer_store_b128(v[k], ro, (p / LPR) * pitch + (p % LPR) * 16u, 0, STAUX); }
+			RAW_BARRIER(); // reads of this buffer done before the DMA after next lands in it
+		}
+	} else {
+		for (uint32_t t = blockIdx.x; t < nTiles; t += gridDim.x) {
+			const __amdgpu_buffer_rsrc_t ri = rsrc(in + tileBase(t)), ro = rsrc(out + tileBase(t));
+			u32x4 v[PERT];
+#pragma unroll
+			for (int k = 0; k < PERT; k++) { const uint32_t p = tid + k * NT; v[k] = __builtin_amdgcn_raw_buffer_load_b128(ri, (p / LPR) * pitch + (p % LPR) * 16u, 0, LDAUX); }
+#pragma unroll
+			for (int k = 0; k < PERT; k++) { const uint32_t p = tid + k * NT; __builtin_amdgcn_raw_buffer_store_b128(v[k], ro, (p / LPR) * pitch + (p % LPR) * 16u, 0, STAUX); }
+		}
+	}
+}
+
+static float timeit(hipStream_t s, int iters, const std::function<void()>& f) {
+	hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); f(); f(); (void)hipStreamSynchronize(s);
+	(void)hipEventRecord(a, s); for (int i = 0; i < iters; i++) f(); (void)hipEventRecord(b, s); (void)hipEventSynchronize(b);
+	float ms; (void)hipEventElapsedTime(&ms, a, b); return ms / iters;
+}
+
+template <int ROWS, int SEG, int NT, int WPC, int DMA> static void run_stream(hipStream_t s, const char* A, char* B, uint32_t pitch, uint32_t* hostA, uint32_t* hostB) {
+	const uint64_t GiB = 1ull << 30;
+	const uint32_t tilesPerMat = pitch / SEG, nTiles = (uint32_t)(GiB / ((uint64_t)ROWS * SEG));
+	const int grid = 256 * WPC;
+	(void)hipMemsetAsync(B, 0, GiB, s);
+	auto f = [&] { hipLaunchKernelGGL((k_stream<ROWS, SEG, NT, WPC, 2, 2, DMA>), dim3(grid), dim3(NT), 0, s, A, B, pitch, tilesPerMat, nTiles); };
+	f(); CK(hipStreamSynchronize(s));
+	// verify a sample
+	CK(hipMemcpy(hostB, B, 64 << 20, hipMemcpyDeviceToHost));
+	size_t bad = 0; for (size_t i = 0; i < (64u << 20) / 4; i++) if (hostA[i] != hostB[i]) bad++;
+	const float ms = timeit(s, 10, f);
+	printf("{\"probe\":\"stream\",\"dma\":%d,\"rows\":%d,\"segB\":%d,\"threads\":%d,\"wgPerCu\":%d,\"pitch\":%u,\"ms\":%.4f,\"GBps_rw\":%.1f,\"bad\":%zu}\n", DMA, ROWS, SEG, NT, WPC, pitch, ms, 2.0 * GiB / ms / 1e6, bad);
+	fflush(stdout);
+}
+
+int main() {
+	hipStream_t s; (void)hipStreamCreate(&s);
+	{ // semantics
+		std::vector<uint32_t> h(1024); for (int i = 0; i < 1024; i++) h[i] = 0x51000000u + i;
+		uint32_t *src, *out; CK(hipMalloc(&src, 4096)); CK(hipMalloc(&out, 8192)); CK(hipMemcpy(src, h.data(), 4096, hipMemcpyHostToDevice)); CK(hipMemset(out, 0, 8192));
+		hipLaunchKernelGGL(k_sem, dim3(1), dim3(64), 0, s, (const uint32_t*)src, out); CK(hipStreamSynchronize(s));
+		std::vector<uint32_t> o(2048); CK(hipMemcpy(o.data(), out, 8192, hipMemcpyDeviceToHost));
+		const uint32_t offs[4] = {0u, 66560u, 132096u, 146432u};
+		for (int t = 0; t < 4; t++) {
+			int ok = 0, oobZero = 0, oobKeep = 0, other = 0;
+			for (int l = 0; l < 64; l++) for (int d = 0; d < 4; d++) {
+				const uint32_t got = o[t * 256 + l * 4 + d], want = 0x51000000u + t * 256 + (63 - l) * 4 + d, prev = 0xAAAA0000u + offs[t] / 4 + l * 4 + d;
+				if (l == 5 || l == 9) { if (got == 0) oobZero++; else if (got == prev) oobKeep++; else other++; }
+				else if (got == want) ok++; else other++;
+			}
+			printf("{\"probe\":\"dma_semantics\",\"ldsOffset\":%u,\"lanes_ok_dwords\":%d,\"of\":248,\"oob_zero\":%d,\"oob_untouched\":%d,\"other\":%d}\n", offs[t], ok, oobZero, oobKeep, other);
+		}
+		int nb = 0; for (int i = 0; i < 4; i++) { if (o[1024 + i] != 0xAAAA0000u + 66560 / 4 - 1 - i) nb++; if (o[1028 + i] != 0xAAAA0000u + 66560 / 4 + 256 + i) nb++; }
+		printf("{\"probe\":\"dma_semantics_neighbours_touched\",\"count\":%d}\n", nb); fflush(stdout);
+	}
+	const uint64_t GiB = 1ull << 30;
+	char *A, *B; CK(hipMalloc(&A, GiB)); CK(hipMalloc(&B, GiB));
+	std::vector<uint32_t> hA((64u << 20) / 4), hB((64u << 20) / 4);
+	{ // pattern in the first 64 MiB, rest arbitrary
+		uint32_t x = 12345; for (auto& v : hA) { x = x * 1664525u + 1013904223u; v = x; }
+		CK(hipMemset(A, 7, GiB)); CK(hipMemcpy(A, hA.data(), 64 << 20, hipMemcpyHostToDevice));
+	}
+	// pitch 2 KiB = 2^16 as 256 x 256 (fp32), pitch 4 KiB = 512-column matrices
+	run_stream<256, 128, 256, 2, 1>(s, A, B, 2048, hA.data(), hB.data());
+	run_stream<256, 128, 256, 2, 0>(s, A, B, 2048, hA.data(), hB.data());
+	run_stream<256, 256, 256, 1, 1>(s, A, B, 2048, hA.data(), hB.data());
+	run_stream<256, 256, 512, 1, 1>(s, A, B, 2048, hA.data(), hB.data());
+	run_stream<256, 256, 256, 1, 0>(s, A, B, 2048, hA.data(), hB.data());
+	run_stream<256, 256, 256, 2, 0>(s, A, B, 2048, hA.data(), hB.data());
+	run_stream<128, 256, 256, 2, 1>(s, A, B, 2048, hA.data(), hB.data());
+	run_stream<128, 128, 256, 4, 1>(s, A, B, 2048, hA.data(), hB.data());
+	run_stream<256, 64, 256, 4, 1>(s, A, B, 2048, hA.data(), hB.data());
+	run_stream<512, 128, 512, 1, 1>(s, A, B, 4096, hA.data(), hB.data());
+	run_stream<512, 128, 256, 1, 1>(s, A, B, 4096, hA.data(), hB.data());
+	run_stream<1024, 64, 512, 1, 1>(s, A, B, 8192, hA.data(), hB.data());
+	run_stream<1024, 64, 256, 1, 1>(s, A, B, 8192, hA.data(), hB.data());
+	run_stream<256, 128, 256, 2, 1>(s, A, B, 16384, hA.data(), hB.data());
+	run_stream<256, 256, 512, 1, 1>(s, A, B, 16384, hA.data(), hB.data());
+	return 0;
+}

@@ -92,6 +92,8 @@ _lib = None
 
 
 def lib_path():
+    if os.environ.get("VKFFT_MI355X_LIB"):  # development builds (make dev): tools/ only
+        return os.path.abspath(os.environ["VKFFT_MI355X_LIB"])
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvkfft_mi355x.so")
 
 

@@ -68,7 +68,8 @@ template <typename T> struct alignas(4 * sizeof(T)) cx2 { cx<T> a, b; };
 
 // CPT = columns per thread (column kernels only): 1, or 2 adjacent columns kept in v[0..E) and v[E..2E) — 16-byte global and LDS
 // accesses for fp32 data, one twiddle read serves both columns (needs an even column pitch TCP and ldsf at an even column)
-template <typename T, typename SCH, int SI, int TPF, int TCP, typename TW, int CPT = 1>
+// RAW = 1: barriers without the compiler's fence (VKFFT_SYNC_RAW, memops.h) — for kernels that keep LDS-DMA transfers in flight across them
+template <typename T, typename SCH, int SI, int TPF, int TCP, typename TW, int CPT = 1, int RAW = 0>
 __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const TW lut, const uint32_t tau, const bool waveOnly) {
 	constexpr int LOGE = SCH::LOGE, E = 1 << LOGE;
 	constexpr int LOGR = SCH::bits[SI], R = 1 << LOGR, NB = E / R;
@@ -122,10 +123,10 @@ __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const TW lut, const ui
 	}
 	if constexpr (!last) {
 #if defined(VKFFT_PROBE_NO_EXCHANGE)
-		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, TCP, TW, CPT>(v, ldsf, lut, tau, waveOnly);
+		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, TCP, TW, CPT, RAW>(v, ldsf, lut, tau, waveOnly);
 		return;
 #endif
-		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
+		if (waveOnly) VKFFT_WAVE_SYNC(); else if constexpr (RAW) VKFFT_SYNC_RAW(); else VKFFT_SYNC();
 #pragma unroll
 		for (int m = 0; m < E; m++) {
 			const uint32_t a = tau + m * TPF;
@@ -133,9 +134,9 @@ __device__ inline void pow2_stages(cx<T>* v, cx<T>* ldsf, const TW lut, const ui
 			else { const cx2<T> q = *(const cx2<T>*)(ldsf + pow2_slot<TCP, LOGE>(a)); v[m] = q.a; v[E + m] = q.b; }
 		}
 		if constexpr (SI + 2 < SCH::NS) { // another exchange will overwrite the buffer: all reads must be done first
-			if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
+			if (waveOnly) VKFFT_WAVE_SYNC(); else if constexpr (RAW) VKFFT_SYNC_RAW(); else VKFFT_SYNC();
 		}
-		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, TCP, TW, CPT>(v, ldsf, lut, tau, waveOnly);
+		pow2_stages<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, TCP, TW, CPT, RAW>(v, ldsf, lut, tau, waveOnly);
 	}
 }
 

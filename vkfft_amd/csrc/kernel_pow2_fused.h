@@ -335,6 +335,7 @@ struct Pow2FusedVariant {
 	int log2n; bool dp; int mode; int la, lb; int bitsA[4], bitsB[4]; int tca, tcb, threads, wgPerCu; // la, lb: log2 of the two factors
 	void (*launch)(const FusedParams&, dim3, hipStream_t);
 	const void* fn;
+	int gen; // 1: kernel_pow2_fused.h, 2: kernel_pow2_fused2.h (LDS-DMA double buffering)
 };
 
 template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE, int TWL, int CPT> void pow2_fused_launch(const FusedParams& prm, dim3 grid, hipStream_t s) {

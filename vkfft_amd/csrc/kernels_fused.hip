@@ -1,6 +1,6 @@
 // Instantiations and registry of the fused Four-Step kernels (kernel_pow2_fused.h): own translation unit (build time).
 #include "engine.h"
-#include "kernel_pow2_fused.h"
+#include "kernel_pow2_fused2.h"
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
@@ -11,7 +11,7 @@ namespace vkfft_mi355x {
 	{ (a0) + (a1) + (a2) + (b0) + (b1) + (b2), dp, mode, (a0) + (a1) + (a2), (b0) + (b1) + (b2), {a0, a1, a2, 0}, {b0, b1, b2, 0}, tca, tcb, \
 	  ((1 << ((a0) + (a1) + (a2))) >> Pow2Sched<a0, a1, a2, 0>::LOGE) * (tca) / (cpt), pow2_fused_wg_per_cu<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, twl, cpt>(), \
 	  &pow2_fused_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt>, \
-	  (const void*)&pow2_fused_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt> }
+	  (const void*)&pow2_fused_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt>, 1 }
 // mode 2 = product (non-temporal hint on the streamed side); the others exist only in development builds (-DVKFFT_MI355X_DEV):
 // 0 = no hint, 6 = per-phase cycle profile, 8 / 16 / 24 = without the FFT arithmetic / without the ring traffic / without both
 #if defined(VKFFT_MI355X_DEV)
@@ -24,19 +24,40 @@ namespace vkfft_mi355x {
 #define VKFFT_FU(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 1)
 #define VKFFT_FU2(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 2) /* two columns per thread */
 
+// second generation (kernel_pow2_fused2.h): tiles arrive by LDS-DMA into two buffers, the next tile in flight while the current one computes
+#define VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, mode, cpt, wpc) \
+	{ (a0) + (a1) + (a2) + (b0) + (b1) + (b2), dp, mode, (a0) + (a1) + (a2), (b0) + (b1) + (b2), {a0, a1, a2, 0}, {b0, b1, b2, 0}, tca, tcb, \
+	  Fused2Shape<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, cpt>::NT, wpc, \
+	  &pow2_fused2_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, cpt, wpc>, \
+	  (const void*)&pow2_fused2_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, cpt, wpc>, 2 }
+#if defined(VKFFT_MI355X_DEV)
+#define VKFFT_FG(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, cpt, wpc) \
+	VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 10, cpt, wpc)
+#else
+#define VKFFT_FG(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, cpt, wpc) VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, cpt, wpc)
+#endif
+
 // first entry of each (log2 N, dp, mode) is the default; VKFFT_MI355X_FUV<log2n>=k selects the k-th shape (tuning)
 static const Pow2FusedVariant kPow2FusedVariants[] = {
 	// fp32, two adjacent columns per thread (16-byte accesses): measured 3-18 % above the one-column shapes that follow them
 	// 2^15 = 128 x 256
+	VKFFT_FG(float, false, 4, 3, 0, 32, 4, 4, 0, 16, 1, 2),
 	VKFFT_FU2(float, false, 4, 3, 0, 32, 4, 4, 0, 16),
 	VKFFT_FU(float, false, 4, 3, 0, 32, 4, 4, 0, 16),
 	// 2^16 = 256 x 256
+	VKFFT_FG(float, false, 4, 4, 0, 16, 4, 4, 0, 16, 1, 2),
+	VKFFT_FG(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 1, 1),
+	VKFFT_FG(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 2, 1),
+	VKFFT_FG(float, false, 3, 3, 2, 16, 3, 3, 2, 16, 1, 2), // 8 points per thread: 512 threads, 16 waves per CU
+	VKFFT_FG(float, false, 3, 3, 2, 32, 3, 3, 2, 32, 2, 1),
 	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 4, 0, 32),
 	VKFFT_FU(float, false, 4, 4, 0, 32, 4, 4, 0, 32),
 	// 2^17 = 256 x 512
+	VKFFT_FG(float, false, 4, 4, 0, 32, 4, 3, 2, 16, 1, 1),
 	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
 	VKFFT_FU(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
 	// 2^18 = 512 x 512
+	VKFFT_FG(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 1),
 	VKFFT_FU2(float, false, 4, 3, 2, 16, 4, 3, 2, 16),
 	VKFFT_FU(float, false, 5, 4, 0, 16, 5, 4, 0, 16),
 	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: one workgroup per CU (the 1024-point column tile needs 139 KiB of LDS); 8-column tiles
@@ -104,7 +125,7 @@ int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t st
 #if !defined(VKFFT_HOSTEMU)
 	if ((v.mode & 4) && getenv("VKFFT_MI355X_FUSED_PROFILE")) { // development: per-phase cycle sums (blocking)
 		static unsigned long long* dbuf = nullptr;
-		if (!dbuf) (void)hipMalloc(&dbuf, 8192 * 12 * sizeof(unsigned long long));
+		if (!dbuf) (void)hipMalloc(&dbuf, 8192 * 24 * sizeof(unsigned long long));
 		FusedParams q = prm; q.prof = dbuf;
 		if (grid > 8192) grid = 8192;
 		v.launch(q, dim3((uint32_t)grid), stream);
@@ -114,6 +135,21 @@ int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t st
 		double sum[12] = {};
 		for (uint64_t w = 0; w < grid; w++) for (int i = 0; i < 12; i++) sum[i] += (double)h[w * 12 + i];
 		const double nt = sum[7] > 0 ? sum[7] : 1;
+		if (v.gen == 2) { // two records per workgroup: thread 0 (ticket thread, wave 0: no DMA) and thread 64 (a DMA wave)
+			std::vector<unsigned long long> h2(grid * 24);
+			(void)hipMemcpy(h2.data(), dbuf, h2.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+			static const char* nm[12] = {"top_wait_A_tile", "A_landing_read", "A_stages", "A_fs_twiddle", "A_transpose", "ticket_block", "ring_stores", "", "mid_wait_B_tile", "B_landing_read_dmaA_issue", "B_stages", "B_flags_hbm_stores"};
+			for (int who = 0; who < 2; who++) {
+				double sm[12] = {};
+				for (uint64_t w = 0; w < grid; w++) for (int i = 0; i < 12; i++) sm[i] += (double)h2[(w * 2 + who) * 12 + i];
+				const double ntk = sm[7] / 1e6 > 0 ? sm[7] / 1e6 : 1;
+				double tot = 0;
+				fprintf(stderr, "{\"fused2_profile\": {\"log2n\": %d, \"tca\": %d, \"tcb\": %d, \"threads\": %d, \"grid\": %llu, \"thread\": %d, \"tickets_per_wg\": %.1f, \"cycles_per_ticket\": {", v.log2n, v.tca, v.tcb, v.threads, (unsigned long long)grid, who * 64, ntk / grid);
+				for (int i = 0; i < 12; i++) { if (i == 7) continue; fprintf(stderr, "\"%s\": %.0f, ", nm[i], sm[i] / ntk); tot += sm[i] / ntk; }
+				fprintf(stderr, "\"total\": %.0f}}}\n", tot);
+			}
+			return 0;
+		}
 		fprintf(stderr, "[fused profile] grid %llu tickets/wg %.1f | cycles per ticket: S1 %.0f  A-load %.0f  A-stages %.0f A-twiddle %.0f A-transpose %.0f A-stores %.0f  B-load %.0f  B-compute %.0f  waitA %.0f waitB %.0f | total %.0f\n",
 		        (unsigned long long)grid, nt / grid, sum[0] / nt, sum[1] / nt, sum[8] / nt, sum[9] / nt, sum[10] / nt, sum[2] / nt, sum[3] / nt, sum[4] / nt, sum[5] / nt, sum[6] / nt, (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6] + sum[8] + sum[9] + sum[10]) / nt);
 		return 0;

@@ -9,6 +9,7 @@
 #if defined(VKFFT_HOSTEMU)
 #define VKFFT_WAVE_SYNC() hostemu::wave_sync()
 #define VKFFT_SYNC() __syncthreads()
+#define VKFFT_SYNC_RAW() __syncthreads()
 #define VKFFT_OPAQUE_ZERO(z) uint32_t z = 0
 #define VKFFT_SCHED_FENCE() do { } while (0)
 #else
@@ -22,6 +23,9 @@
 // persistent loop the barrier then followed two ds_writes of thread 0 directly, and on MI355X other waves occasionally passed the barrier
 // and read the previous contents (a stale ticket: 2-29 wrong transforms in 300 under unbalanced queues, none with the wait).
 #define VKFFT_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+// The same barrier without the compiler's fence: the wave's own LDS operations are waited for, vector-memory operations are NOT (a fence would
+// drain them).  For kernels that keep LDS-DMA transfers (memops: gb_dma16) and stores in flight across barriers and count them themselves.
+#define VKFFT_SYNC_RAW() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 // orders this wave's LDS writes before its later LDS reads without an s_barrier
 #define VKFFT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #endif
@@ -67,6 +71,14 @@ template <typename T, int AUX> inline void gb_store_x(GBuf b, uint32_t voff, uin
 template <typename T, int AUX> inline void gb_store2_x(GBuf b, uint32_t voff, cx<T> v0, cx<T> v1) { gb_store<T>(b, voff, 0, v0); gb_store<T>(b, voff + (uint32_t)sizeof(cx<T>), 0, v1); }
 template <typename T, int E> inline void gb_landed(cx<T>*) { }
 template <typename T, int AUX> inline void gb_load2_x(GBuf b, uint32_t voff, uint32_t soff, cx<T>& v0, cx<T>& v1) { v0 = gb_load<T>(b, voff, soff); v1 = gb_load<T>(b, voff + (voff >= kGbRange ? 0u : (uint32_t)sizeof(cx<T>)), soff); }
+// LDS-DMA (device arm below): on the emulator every work-item copies its own 16 bytes at once, the waits are empty
+struct GDma { const char* base; };
+inline GDma make_gdma(const void* p) { return {(const char*)p}; }
+template <int AUX> inline void gb_dma16(void* ldsWaveBase, GDma b, uint32_t voff, uint32_t soff) {
+	char* d = (char*)ldsWaveBase + (threadIdx.x & 63u) * 16u;
+	if (voff >= kGbRange) memset(d, 0, 16); else memcpy(d, b.base + (uint64_t)voff + soff, 16);
+}
+template <int N> inline void gb_wait_vm() { }
 #else
 typedef unsigned int vk_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int vk_u32x4 __attribute__((ext_vector_type(4)));
@@ -179,6 +191,30 @@ template <typename T, int AUX> __device__ inline void gb_store2_x(GBuf b, uint32
 	vk_u32x4 t; t.x = __float_as_uint(v0.x); t.y = __float_as_uint(v0.y); t.z = __float_as_uint(v1.x); t.w = __float_as_uint(v1.y);
 	__builtin_amdgcn_raw_buffer_store_b128(t, b.r, voff, 0, AUX);
 }
+// ---- LDS-DMA: buffer_load_dwordx4 ... lds.  One wave-instruction moves 64 x 16 bytes from per-lane global addresses (resource base + soff + voff)
+// to ONE contiguous KiB of LDS at ldsWaveBase + lane * 16 (the destination is wave-uniform base + lane-linear; measured on gfx950 with
+// tools/probe_dma.hip: any LDS offset up to 160 KiB, out-of-range lanes write zeros).  No VGPR holds the data and the transfer stays in flight
+// across barriers: what lets a persistent kernel fetch its next tile while the current one computes.  The statement is inline assembly on purpose:
+// an LDS-DMA issued through the compiler's builtin is a pending LDS write to its wait-count pass, which then drains the vector-memory queue
+// (vmcnt(0)) before the next LDS read or barrier — the opposite of what the transfer is for.  The caller counts: the queue is in order, so
+// gb_wait_vm<N>() = "all but the N youngest vector-memory instructions of this wave have completed".
+struct GDma { vk_u32x4 r; };
+__device__ inline GDma make_gdma(const void* p) {
+	const uint64_t a = (uint64_t)p;
+	GDma b;
+	b.r.x = __builtin_amdgcn_readfirstlane((uint32_t)a); b.r.y = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) & 0xffffu; b.r.z = kGbRange; b.r.w = 0x00020000u;
+	return b;
+}
+template <int AUX> __device__ inline void gb_dma16(void* ldsWaveBase, GDma b, uint32_t voff, uint32_t soff) {
+	const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ldsWaveBase);
+	const uint32_t so = __builtin_amdgcn_readfirstlane(soff);
+	uint32_t keep;
+	static_assert(AUX == 0 || AUX == 2 || AUX == 16, "policy: default, nt, sc1");
+	if constexpr (AUX == 0) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "s"(la), "v"(voff), "s"(b.r), "s"(so) : "memory");
+	else if constexpr (AUX == 2) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "s"(la), "v"(voff), "s"(b.r), "s"(so) : "memory");
+	else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen sc1 lds\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "s"(la), "v"(voff), "s"(b.r), "s"(so) : "memory");
+}
+template <int N> __device__ inline void gb_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 #endif
 
 } // namespace vkfft_mi355x
