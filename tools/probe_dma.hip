@@ -107,6 +107,111 @@ __global__ void __launch_bounds__(NT, (WPC * NT + 255) / 256) k_stream(const cha
 	}
 }
 
+static float timeit(hipStream_t s, int iters, const std::function<void()>& f);
+
+// ---- 3. the same stream with a round trip through an on-die ring between the read and the write (the fused Four-Step kernel's traffic, no arithmetic,
+// no tickets): per tile  HBM -> LDS (DMA, prefetched one tile ahead) -> registers -> ring (write-through or plain 16-byte stores);  the tile written
+// one iteration earlier comes back  ring -> registers (sc1 loads) -> HBM.  Every workgroup has its own two ring slots (RINGMODE 1) or the slots of
+// all workgroups are spread over a region of ringBytes (RINGMODE 2: slot = hash of (workgroup, iteration), no reuse of fresh lines by the same XCD).
+template <int ROWS, int SEG, int NT, int WPC, int STAUX, int ORDER>
+__global__ void __launch_bounds__(NT, (WPC * NT + 255) / 256) k_ring(const char* in, char* out, char* ring, uint32_t ringSlots, uint32_t pitch, uint32_t tilesPerMat, uint32_t nTiles) {
+	constexpr int TILEB = ROWS * SEG, NW = NT / 64, NI = TILEB / 1024, IPW = NI / NW, RPI = 1024 / SEG, LPR = SEG / 16;
+	constexpr int PERT = TILEB / 16 / NT;
+	__shared__ u32x4 lds[2 * TILEB / 16];
+	const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint64_t matB = (uint64_t)ROWS * pitch;
+	const uint32_t voffD = (lane / LPR) * pitch + (lane % LPR) * 16u;
+	auto tileBase = [&](uint32_t t) -> uint64_t { return (uint64_t)(t / tilesPerMat) * matB + (uint64_t)(t % tilesPerMat) * SEG; };
+	auto slotOf = [&](uint32_t i) -> uint64_t { return ringSlots ? (uint64_t)((blockIdx.x * 2u + (i & 1u) + (i >> 1) * 2u * gridDim.x) % ringSlots) * TILEB : (uint64_t)(((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * 2u + (i & 1u)) * TILEB; }; // private slots, contiguous per XCD (block b runs on XCD b % 8)
+	uint32_t t = blockIdx.x;
+	if (t >= nTiles) return;
+	{
+		const u32x4 rs = mkrsrc(in + tileBase(t));
+#pragma unroll
+		for (int j = 0; j < IPW; j++) { const uint32_t ins = w * IPW + j; dma16<2>(base + ins * 1024u, rs, voffD, ins * RPI * pitch); }
+	}
+	uint32_t it = 0, i = 0;
+	for (; t < nTiles; t += gridDim.x, it ^= 1u, i++) {
+		const uint32_t tn = t + gridDim.x;
+		const __amdgpu_buffer_rsrc_t rr = rsrc(ring + slotOf(i)), rp = rsrc(ring + slotOf(i - 1u)), ro = rsrc(out + tileBase(t >= gridDim.x ? t - gridDim.x : t));
+		u32x4 b[PERT];
+		if (ORDER == 1 && i > 0) { // ring loads first: nothing slow ahead of them in the queue
+#pragma unroll
+			for (int k = 0; k < PERT; k++) b[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, (tid + k * NT) * 16u, 0, 16);
+		}
+		if (tn < nTiles) {
+			const u32x4 rs = mkrsrc(in + tileBase(tn));
+#pragma unroll
+			for (int j = 0; j < IPW; j++) { const uint32_t ins = w * IPW + j; dma16<2>(base + (it ^ 1u) * TILEB + ins * 1024u, rs, voffD, ins * RPI * pitch); }
+		}
+		if (ORDER == 0 && i > 0) {
+#pragma unroll
+			for (int k = 0; k < PERT; k++) b[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, (tid + k * NT) * 16u, 0, 16);
+		}
+		// the tile of this iteration has landed: everything older than the youngest DMA batch (+ the ring loads issued after it)
+		if (tn < nTiles) { if (ORDER == 0 && i > 0) wait_vm<IPW + PERT>(); else wait_vm<IPW>(); } else wait_vm<0>();
+		RAW_BARRIER();
+		u32x4 v[PERT];
+#pragma unroll
+		for (int k = 0; k < PERT; k++) v[k] = lds[it * (TILEB / 16) + tid + k * NT];
+#pragma unroll
+		for (int k = 0; k < PERT; k++) __builtin_amdgcn_raw_buffer_store_b128(v[k], rr, (tid + k * NT) * 16u, 0, STAUX);
+		if (i > 0) {
+#pragma unroll
+			for (int k = 0; k < PERT; k++) { const uint32_t p = tid + k * NT; __builtin_amdgcn_raw_buffer_store_b128(b[k], ro, (p / LPR) * pitch + (p % LPR) * 16u, 0, 2); }
+		}
+		RAW_BARRIER();
+	}
+}
+template <int ROWS, int SEG, int NT, int WPC, int STAUX, int ORDER> static void run_ring(hipStream_t s, const char* A, char* B, char* R, uint64_t ringBytes, uint32_t pitch) {
+	const uint64_t GiB = 1ull << 30;
+	const uint32_t tilesPerMat = pitch / SEG, nTiles = (uint32_t)(GiB / ((uint64_t)ROWS * SEG));
+	const int grid = 256 * WPC;
+	const uint32_t slots = (uint32_t)(ringBytes / ((uint64_t)ROWS * SEG));
+	auto f = [&] { hipLaunchKernelGGL((k_ring<ROWS, SEG, NT, WPC, STAUX, ORDER>), dim3(grid), dim3(NT), 0, s, A, B, R, slots, pitch, tilesPerMat, nTiles); };
+	const float ms = timeit(s, 10, f);
+	printf("{\"probe\":\"stream_with_ring_trip\",\"rows\":%d,\"segB\":%d,\"threads\":%d,\"wgPerCu\":%d,\"ring_store_policy\":\"%s\",\"ring_loads\":\"%s\",\"ringMiB\":%.0f,\"ms\":%.4f,\"alg_GBps\":%.1f}\n", ROWS, SEG, NT, WPC, STAUX == 16 ? "sc1" : "plain", ORDER ? "ahead of the DMA" : "behind the DMA", ringBytes / 1048576.0, ms, 2.0 * GiB / ms / 1e6);
+	fflush(stdout);
+}
+
+// ---- 4. ring trip through registers only (no LDS, no DMA): what occupancy buys.  Per iteration: column tile HBM -> registers -> ring; previous ring tile -> registers -> HBM
+template <int ROWS, int SEG, int NT, int WPC, int STAUX>
+__global__ void __launch_bounds__(NT, (WPC * NT + 255) / 256) k_ring_reg(const char* in, char* out, char* ring, uint32_t ringSlots, uint32_t pitch, uint32_t tilesPerMat, uint32_t nTiles) {
+	constexpr int TILEB = ROWS * SEG, LPR = SEG / 16, PERT = TILEB / 16 / NT;
+	const uint32_t tid = threadIdx.x;
+	const uint64_t matB = (uint64_t)ROWS * pitch;
+	auto tileBase = [&](uint32_t t) -> uint64_t { return (uint64_t)(t / tilesPerMat) * matB + (uint64_t)(t % tilesPerMat) * SEG; };
+	auto slotOf = [&](uint32_t i) -> uint64_t { return (uint64_t)((blockIdx.x * 2u + (i & 1u) + (i >> 1) * 2u * gridDim.x) % ringSlots) * TILEB; };
+	uint32_t i = 0;
+	for (uint32_t t = blockIdx.x; t < nTiles; t += gridDim.x, i++) {
+		const __amdgpu_buffer_rsrc_t ri = rsrc(in + tileBase(t)), rr = rsrc(ring + slotOf(i)), rp = rsrc(ring + slotOf(i - 1u)), ro = rsrc(out + tileBase(t >= gridDim.x ? t - gridDim.x : t));
+		u32x4 v[PERT], b[PERT];
+		if (i > 0) {
+#pragma unroll
+			for (int k = 0; k < PERT; k++) b[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, (tid + k * NT) * 16u, 0, 16);
+		}
+#pragma unroll
+		for (int k = 0; k < PERT; k++) { const uint32_t p = tid + k * NT; v[k] = __builtin_amdgcn_raw_buffer_load_b128(ri, (p / LPR) * pitch + (p % LPR) * 16u, 0, 2); }
+		if (i > 0) {
+#pragma unroll
+			for (int k = 0; k < PERT; k++) { const uint32_t p = tid + k * NT; __builtin_amdgcn_raw_buffer_store_b128(b[k], ro, (p / LPR) * pitch + (p % LPR) * 16u, 0, 2); }
+		}
+#pragma unroll
+		for (int k = 0; k < PERT; k++) __builtin_amdgcn_raw_buffer_store_b128(v[k], rr, (tid + k * NT) * 16u, 0, STAUX);
+	}
+}
+template <int ROWS, int SEG, int NT, int WPC, int STAUX> static void run_ring_reg(hipStream_t s, const char* A, char* B, char* R, uint64_t ringBytes, uint32_t pitch) {
+	const uint64_t GiB = 1ull << 30;
+	const uint32_t tilesPerMat = pitch / SEG, nTiles = (uint32_t)(GiB / ((uint64_t)ROWS * SEG));
+	const int grid = 256 * WPC;
+	const uint32_t slots = (uint32_t)(ringBytes / ((uint64_t)ROWS * SEG));
+	auto f = [&] { hipLaunchKernelGGL((k_ring_reg<ROWS, SEG, NT, WPC, STAUX>), dim3(grid), dim3(NT), 0, s, A, B, R, slots, pitch, tilesPerMat, nTiles); };
+	const float ms = timeit(s, 10, f);
+	printf("{\"probe\":\"ring_trip_through_registers\",\"rows\":%d,\"segB\":%d,\"threads\":%d,\"wgPerCu\":%d,\"ring_store_policy\":\"%s\",\"ringMiB\":%.0f,\"ms\":%.4f,\"alg_GBps\":%.1f}\n", ROWS, SEG, NT, WPC, STAUX == 16 ? "sc1" : "plain", ringBytes / 1048576.0, ms, 2.0 * GiB / ms / 1e6);
+	fflush(stdout);
+}
+
 static float timeit(hipStream_t s, int iters, const std::function<void()>& f) {
 	hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); f(); f(); (void)hipStreamSynchronize(s);
 	(void)hipEventRecord(a, s); for (int i = 0; i < iters; i++) f(); (void)hipEventRecord(b, s); (void)hipEventSynchronize(b);
@@ -171,5 +276,40 @@ int main() {
 	run_stream<1024, 64, 256, 1, 1>(s, A, B, 8192, hA.data(), hB.data());
 	run_stream<256, 128, 256, 2, 1>(s, A, B, 16384, hA.data(), hB.data());
 	run_stream<256, 256, 512, 1, 1>(s, A, B, 16384, hA.data(), hB.data());
+	{
+		char* R; CK(hipMalloc(&R, 512ull << 20));
+		for (uint64_t rb : {32ull << 20, 128ull << 20, 512ull << 20}) {
+			run_ring<256, 128, 256, 2, 16, 0>(s, A, B, R, rb, 2048);
+			run_ring<256, 128, 256, 2, 16, 1>(s, A, B, R, rb, 2048);
+			run_ring<256, 128, 256, 2, 0, 1>(s, A, B, R, rb, 2048);
+		}
+		run_ring<256, 256, 256, 2, 16, 1>(s, A, B, R, 128ull << 20, 2048);
+		run_ring<256, 256, 512, 1, 16, 1>(s, A, B, R, 128ull << 20, 2048);
+		run_ring<256, 256, 256, 1, 16, 1>(s, A, B, R, 128ull << 20, 2048);
+		run_ring<256, 128, 256, 1, 16, 1>(s, A, B, R, 128ull << 20, 2048);
+		run_ring<256, 128, 256, 1, 0, 1>(s, A, B, R, 0, 2048);
+		run_ring<256, 128, 256, 1, 16, 1>(s, A, B, R, 0, 2048);
+		run_ring<256, 128, 256, 2, 0, 1>(s, A, B, R, 0, 2048);
+		run_ring<256, 256, 512, 1, 0, 1>(s, A, B, R, 0, 2048);
+		run_ring<128, 128, 256, 2, 0, 1>(s, A, B, R, 0, 2048);
+		run_ring<128, 128, 256, 2, 16, 1>(s, A, B, R, 0, 2048);
+		run_ring<128, 128, 256, 1, 0, 1>(s, A, B, R, 0, 2048);
+		run_ring<128, 128, 256, 4, 0, 1>(s, A, B, R, 0, 2048);
+		run_ring<64, 128, 256, 2, 0, 1>(s, A, B, R, 0, 2048);
+		run_ring<64, 128, 256, 4, 0, 1>(s, A, B, R, 0, 2048);
+		run_ring<128, 256, 256, 1, 0, 1>(s, A, B, R, 0, 2048);
+		run_ring<128, 256, 512, 1, 0, 1>(s, A, B, R, 0, 2048);
+		run_ring<256, 128, 512, 1, 0, 1>(s, A, B, R, 0, 2048);
+		run_ring<128, 128, 256, 2, 0, 0>(s, A, B, R, 0, 2048);
+		run_ring<128, 128, 256, 4, 16, 1>(s, A, B, R, 128ull << 20, 2048);
+		run_ring<64, 128, 256, 8, 16, 1>(s, A, B, R, 128ull << 20, 2048);
+		run_ring_reg<256, 128, 256, 2, 16>(s, A, B, R, 128ull << 20, 2048);
+		run_ring_reg<256, 128, 256, 4, 16>(s, A, B, R, 128ull << 20, 2048);
+		run_ring_reg<256, 128, 256, 8, 16>(s, A, B, R, 128ull << 20, 2048);
+		run_ring_reg<256, 256, 256, 4, 16>(s, A, B, R, 128ull << 20, 2048);
+		run_ring_reg<256, 256, 512, 4, 16>(s, A, B, R, 128ull << 20, 2048);
+		run_ring_reg<128, 128, 256, 8, 16>(s, A, B, R, 128ull << 20, 2048);
+		run_ring_reg<256, 128, 256, 8, 0>(s, A, B, R, 32ull << 20, 2048);
+	}
 	return 0;
 }

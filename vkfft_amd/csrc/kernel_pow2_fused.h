@@ -119,7 +119,7 @@ pow2_fused_kernel(const FusedParams p) {
 	static_assert(LA * TCA == LB * TCB, "both phases move the same number of points per tile");
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	constexpr int AUX_SC = 16;                   // ring loads: agent scope, served from the memory side
-	constexpr int AUX_ST = 16;                   // ring stores: write-through (no XCD's L2 ever holds a ring line)
+	constexpr int AUX_ST = (MODE & 32) ? 0 : 16;  // ring stores: write-through (no XCD's L2 ever holds a ring line); (development, MODE bit 5: plain — wrong across XCDs, timing only)
 	constexpr int AUX_HBM = (MODE & 2) ? 2 : 0;
 	constexpr int LDSN = LA * TCPA > LB * TCPB ? LA * TCPA : LB * TCPB;
 	constexpr int LUTA = TWL ? SA::lutTotal() : 0, LUTB = TWL ? SB::lutTotal() : 0;

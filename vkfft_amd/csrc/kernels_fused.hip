@@ -1,6 +1,9 @@
 // Instantiations and registry of the fused Four-Step kernels (kernel_pow2_fused.h): own translation unit (build time).
 #include "engine.h"
+#include "kernel_pow2_fused.h"
+#if defined(VKFFT_MI355X_DEV) || defined(VKFFT_HOSTEMU)
 #include "kernel_pow2_fused2.h"
+#endif
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
@@ -16,7 +19,7 @@ namespace vkfft_mi355x {
 // 0 = no hint, 6 = per-phase cycle profile, 8 / 16 / 24 = without the FFT arithmetic / without the ring traffic / without both
 #if defined(VKFFT_MI355X_DEV)
 #define VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, cpt) \
-	VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 0, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 8, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 16, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 24, twl, cpt)
+	VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 0, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 8, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 16, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 24, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 34, twl, cpt)
 #else
 #define VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, cpt) VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, cpt)
 #endif
@@ -32,7 +35,8 @@ namespace vkfft_mi355x {
 	  (const void*)&pow2_fused2_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, cpt, wpc>, 2 }
 #if defined(VKFFT_MI355X_DEV)
 #define VKFFT_FG(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, cpt, wpc) \
-	VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 10, cpt, wpc)
+	VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 10, cpt, wpc), \
+	VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 18, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 26, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 34, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 42, cpt, wpc)
 #else
 #define VKFFT_FG(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, cpt, wpc) VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, cpt, wpc)
 #endif
@@ -41,25 +45,26 @@ namespace vkfft_mi355x {
 static const Pow2FusedVariant kPow2FusedVariants[] = {
 	// fp32, two adjacent columns per thread (16-byte accesses): measured 3-18 % above the one-column shapes that follow them
 	// 2^15 = 128 x 256
-	VKFFT_FG(float, false, 4, 3, 0, 32, 4, 4, 0, 16, 1, 2),
 	VKFFT_FU2(float, false, 4, 3, 0, 32, 4, 4, 0, 16),
 	VKFFT_FU(float, false, 4, 3, 0, 32, 4, 4, 0, 16),
 	// 2^16 = 256 x 256
-	VKFFT_FG(float, false, 4, 4, 0, 16, 4, 4, 0, 16, 1, 2),
-	VKFFT_FG(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 1, 1),
-	VKFFT_FG(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 2, 1),
-	VKFFT_FG(float, false, 3, 3, 2, 16, 3, 3, 2, 16, 1, 2), // 8 points per thread: 512 threads, 16 waves per CU
-	VKFFT_FG(float, false, 3, 3, 2, 32, 3, 3, 2, 32, 2, 1),
 	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 4, 0, 32),
 	VKFFT_FU(float, false, 4, 4, 0, 32, 4, 4, 0, 32),
 	// 2^17 = 256 x 512
-	VKFFT_FG(float, false, 4, 4, 0, 32, 4, 3, 2, 16, 1, 1),
 	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
 	VKFFT_FU(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
 	// 2^18 = 512 x 512
-	VKFFT_FG(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 1),
 	VKFFT_FU2(float, false, 4, 3, 2, 16, 4, 3, 2, 16),
 	VKFFT_FU(float, false, 5, 4, 0, 16, 5, 4, 0, 16),
+#if defined(VKFFT_MI355X_DEV) || defined(VKFFT_HOSTEMU)
+	// Second generation (kernel_pow2_fused2.h: service wave + LDS-DMA), measured and NOT adopted (profiles/r03_fused_gen2*): development
+	// and emulator builds only; the first entries above stay the defaults.  VKFFT_MI355X_FUV<k> = 2.. selects them (15, 17, 18: index 2; 16: 2, 3)
+	VKFFT_FG(float, false, 4, 3, 0, 32, 4, 4, 0, 16, 1, 2),
+	VKFFT_FG(float, false, 4, 4, 0, 16, 4, 4, 0, 16, 1, 2),
+	VKFFT_FG(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 1, 1),
+	VKFFT_FG(float, false, 4, 4, 0, 32, 4, 3, 2, 16, 1, 1),
+	VKFFT_FG(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 1),
+#endif
 	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: one workgroup per CU (the 1024-point column tile needs 139 KiB of LDS); 8-column tiles
 	// (two workgroups per CU, 64-byte segments on the HBM side) measured 12 % slower, 2^20 as 512 x 2048 20 % slower
 	VKFFT_FU2(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
@@ -135,16 +140,16 @@ int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t st
 		double sum[12] = {};
 		for (uint64_t w = 0; w < grid; w++) for (int i = 0; i < 12; i++) sum[i] += (double)h[w * 12 + i];
 		const double nt = sum[7] > 0 ? sum[7] : 1;
-		if (v.gen == 2) { // two records per workgroup: thread 0 (ticket thread, wave 0: no DMA) and thread 64 (a DMA wave)
+		if (v.gen == 2) { // two records per workgroup: compute thread 0 and the ticket thread (service wave)
 			std::vector<unsigned long long> h2(grid * 24);
 			(void)hipMemcpy(h2.data(), dbuf, h2.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-			static const char* nm[12] = {"top_wait_A_tile", "A_landing_read", "A_stages", "A_fs_twiddle", "A_transpose", "ticket_block", "ring_stores", "", "mid_wait_B_tile", "B_landing_read_dmaA_issue", "B_stages", "B_flags_hbm_stores"};
+			static const char* nm[12] = {"top_wait_and_barrier", "A_landing_read", "A_stages", "A_fs_twiddle", "A_transpose", "unused5", "B_request_and_ring_stores", "", "mid_barrier", "unused9", "B_stages", "B_hbm_stores_and_tail"};
 			for (int who = 0; who < 2; who++) {
 				double sm[12] = {};
 				for (uint64_t w = 0; w < grid; w++) for (int i = 0; i < 12; i++) sm[i] += (double)h2[(w * 2 + who) * 12 + i];
 				const double ntk = sm[7] / 1e6 > 0 ? sm[7] / 1e6 : 1;
 				double tot = 0;
-				fprintf(stderr, "{\"fused2_profile\": {\"log2n\": %d, \"tca\": %d, \"tcb\": %d, \"threads\": %d, \"grid\": %llu, \"thread\": %d, \"tickets_per_wg\": %.1f, \"cycles_per_ticket\": {", v.log2n, v.tca, v.tcb, v.threads, (unsigned long long)grid, who * 64, ntk / grid);
+				fprintf(stderr, "{\"fused2_profile\": {\"log2n\": %d, \"tca\": %d, \"tcb\": %d, \"threads\": %d, \"grid\": %llu, \"thread\": \"%s\", \"tickets_per_wg\": %.1f, \"cycles_per_ticket\": {", v.log2n, v.tca, v.tcb, v.threads, (unsigned long long)grid, who ? "ticket thread (service wave)" : "compute thread 0", ntk / grid);
 				for (int i = 0; i < 12; i++) { if (i == 7) continue; fprintf(stderr, "\"%s\": %.0f, ", nm[i], sm[i] / ntk); tot += sm[i] / ntk; }
 				fprintf(stderr, "\"total\": %.0f}}}\n", tot);
 			}
