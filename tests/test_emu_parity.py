@@ -142,6 +142,21 @@ def test_r2c_whose_half_length_needs_bluestein(run, oracle, shape, dp):
     parity.check_r2c(run, oracle, shape, 3, dp)
 
 
+@pytest.mark.parametrize("kind,shape,dp,type,dst", [("r2r", (64, 239), False, 2, False), ("r2r", (64, 239), True, 2, False), ("r2r", (10007,), False, 2, False),
+                                                    ("r2r", (9001,), False, 4, False), ("r2r", (4999, 2), False, 1, True), ("r2r", (5, 239), False, 3, True),
+                                                    ("r2r", (3, 239), True, 4, True), ("r2r", (24, 1451), False, 4, False), ("r2r", (7, 3, 241), False, 1, False),
+                                                    ("r2c", (20011,), False, 0, False), ("r2c", (10007,), True, 0, False), ("r2c", (8209, 3), False, 0, False)])
+def test_real_transforms_without_a_fused_bluestein_form(run, oracle, kind, shape, dp, type, dst):
+    """Real transforms whose embedding length needs Bluestein along a STRIDED axis (DCT-II 64 x 239: the 239-point axis) or on more points than the
+    fused Bluestein kernels hold (DCT-II 10007, DCT-IV 9001, DST-I 4999, R2C 20011): pre-map pass, complex plan of the embedding length on dense
+    scratch rows, post-map pass (planner.cpp plan_real_by_maps; the reference: vkFFT_Scheduler.h:2271-2280, 2894-2944).  These lengths used to be
+    rejected with VKFFT_ERROR_UNSUPPORTED_FFT_LENGTH_R2C / _R2R."""
+    if kind == "r2c":
+        parity.check_r2c(run, oracle, shape, 2, dp)
+    else:
+        parity.check_r2r(run, oracle, shape, 2, dp, type, dst)
+
+
 @pytest.mark.parametrize("N,dp,type,dst", [(240, False, 1, False), (1014, False, 1, False), (478, False, 2, False), (478, False, 3, True), (239, False, 2, True),
                                            (240, True, 1, False), (718, True, 3, False), (1902, True, 4, False), (1451, False, 4, True), (879, False, 4, False)])
 def test_r2r_whose_embedding_length_needs_bluestein(run, oracle, N, dp, type, dst):

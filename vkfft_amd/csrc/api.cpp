@@ -89,7 +89,7 @@ VKFFT_API void vkfftMI355XStructSizes(pfUINT out[4]) {
 
 VKFFT_API int vkfftMI355XDescribePlan(const VkFFTApplication* app, int inverse, char* names, pfUINT cap) {
 	static const char* kname[] = {"generic_pass_kernel", "pow2_row_kernel", "pow2_col_kernel", "r2c_even_pair_kernel", "?", "mixed_row_kernel", "opfft_kernel", "pow2_blue_kernel",
-	                              "pow2_col_blue_kernel", "pow2_blue_r2r_kernel", "pow2_fused_kernel", "transpose_kernel"};
+	                              "pow2_col_blue_kernel", "pow2_blue_r2r_kernel", "pow2_fused_kernel", "transpose_kernel", "real_map_kernel"};
 	if (names && cap) names[0] = 0;
 	if (!app) return 0;
 	const VkFFTPlan* pl = inverse == 1 ? app->localFFTPlan_inverse : app->localFFTPlan;
@@ -102,7 +102,7 @@ VKFFT_API int vkfftMI355XDescribePlan(const VkFFTApplication* app, int inverse, 
 		for (const HostDim& h : q.hostLoop) rep *= h.count;
 		launches += (int)rep;
 		if (!names || !cap) continue;
-		const char* nm = kname[q.kernel >= 0 && q.kernel < 12 ? q.kernel : 4];
+		const char* nm = kname[q.kernel >= 0 && q.kernel < 13 ? q.kernel : 4];
 		int w = snprintf(names + pos, pos < cap ? (size_t)cap - pos : 0, "%s%s<%s>", pos ? "," : "", nm, q.dp ? "double" : "float");
 		if (w > 0) pos = std::min<size_t>(pos + (size_t)w, (size_t)cap - 1);
 	}
@@ -276,7 +276,7 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 		if (res != VKFFT_SUCCESS) { deleteVkFFT(app); return res; }
 	}
 	if (c.printMemoryLayout || getenv("VKFFT_MI355X_PRINT_PLAN")) { // one line per launch: which kernel family serves it
-		static const char* kname[] = {"generic", "pow2_row", "pow2_col", "r2c_pair", "?", "mixed_row", "opfft", "pow2_blue", "pow2_col_blue", "pow2_blue_r2r", "pow2_fused", "transpose"};
+		static const char* kname[] = {"generic", "pow2_row", "pow2_col", "r2c_pair", "?", "mixed_row", "opfft", "pow2_blue", "pow2_col_blue", "pow2_blue_r2r", "pow2_fused", "transpose", "real_map"};
 		for (int dir = 0; dir < 2; dir++) {
 			VkFFTPlan* pl = dir ? app->localFFTPlan_inverse : app->localFFTPlan;
 			if (!pl) continue;
@@ -289,15 +289,15 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 					continue;
 				}
 				fprintf(stderr, "[vkfft_mi355x] %s pass %zu: %-10s kernel=%s variant=%d L=%u threads=%u tile=%u grid=%llu\n", dir ? "inverse" : "forward", i, q.label.c_str(),
-				        kname[q.kernel < 12 ? q.kernel : 4], q.variant, q.prm.L, q.threads, q.prm.T,
+				        kname[q.kernel < 13 ? q.kernel : 4], q.variant, q.prm.L, q.threads, q.prm.T,
 				        (unsigned long long)q.prm.tilesPerG0 * q.prm.dim[1].count * q.prm.dim[2].count);
 			}
 		}
 	}
 	// ---- scratch ------------------------------------------------------------------------------------------
 	uint64_t need = 0;
-	if (app->localFFTPlan) need = std::max<uint64_t>(need, ((DirectionPlan*)app->localFFTPlan->impl)->tempBytes);
-	if (app->localFFTPlan_inverse) need = std::max<uint64_t>(need, ((DirectionPlan*)app->localFFTPlan_inverse->impl)->tempBytes);
+	if (app->localFFTPlan) need = std::max<uint64_t>(need, ((DirectionPlan*)app->localFFTPlan->impl)->totalTemp());
+	if (app->localFFTPlan_inverse) need = std::max<uint64_t>(need, ((DirectionPlan*)app->localFFTPlan_inverse->impl)->totalTemp());
 	if (need && !c.userTempBuffer) {
 		if (hipMalloc(&st->tempOwned, need) != hipSuccess) { deleteVkFFT(app); return VKFFT_ERROR_FAILED_TO_ALLOCATE; }
 		st->tempOwnedBytes = need;
@@ -359,11 +359,12 @@ VKFFT_API VkFFTResult VkFFTAppend(VkFFTApplication* app, int inverse, VkFFTLaunc
 	lb.base[ROLE_BUFFER] = (char*)c.buffer[0] + c.bufferOffset;
 	if (c.isInputFormatted) lb.base[ROLE_INPUT] = (char*)c.inputBuffer[0] + c.inputBufferOffset;
 	if (c.isOutputFormatted) lb.base[ROLE_OUTPUT] = (char*)c.outputBuffer[0] + c.outputBufferOffset;
-	if (dp->tempBytes) {
+	if (dp->totalTemp()) {
 		if (c.userTempBuffer) {
 			if (c.tempBuffer == nullptr || c.tempBuffer[0] == nullptr) return VKFFT_ERROR_EMPTY_tempBuffer;
 			lb.base[ROLE_TEMP] = (char*)c.tempBuffer[0] + c.tempBufferOffset;
 		} else lb.base[ROLE_TEMP] = st->tempOwned;
+		lb.base[ROLE_TEMP2] = (char*)lb.base[ROLE_TEMP] + dp->temp2Offset();
 	}
 	StreamSet ss;
 	if (c.stream && c.num_streams >= 1) {

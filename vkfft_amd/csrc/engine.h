@@ -10,8 +10,9 @@
 
 namespace vkfft_mi355x {
 
-enum BufRole : int { ROLE_BUFFER = 0, ROLE_TEMP = 1, ROLE_INPUT = 2, ROLE_OUTPUT = 3 };
-enum KernelKind : int { KERNEL_GENERIC = 0, KERNEL_POW2_ROW = 1, KERNEL_POW2_COL = 2, KERNEL_R2C_PAIR = 3, KERNEL_MIXED_ROW = 5, KERNEL_OPFFT = 6, KERNEL_POW2_BLUE = 7, KERNEL_POW2_COL_BLUE = 8, KERNEL_POW2_BLUE_R2R = 9, KERNEL_POW2_FUSED = 10, KERNEL_TRANSPOSE = 11 };
+// ROLE_TEMP2: a second scratch region behind ROLE_TEMP in the same allocation, for plans that wrap an inner plan which uses ROLE_TEMP itself
+enum BufRole : int { ROLE_BUFFER = 0, ROLE_TEMP = 1, ROLE_INPUT = 2, ROLE_OUTPUT = 3, ROLE_TEMP2 = 4 };
+enum KernelKind : int { KERNEL_GENERIC = 0, KERNEL_POW2_ROW = 1, KERNEL_POW2_COL = 2, KERNEL_R2C_PAIR = 3, KERNEL_MIXED_ROW = 5, KERNEL_OPFFT = 6, KERNEL_POW2_BLUE = 7, KERNEL_POW2_COL_BLUE = 8, KERNEL_POW2_BLUE_R2R = 9, KERNEL_POW2_FUSED = 10, KERNEL_TRANSPOSE = 11, KERNEL_REAL_MAP = 12 };
 
 struct HostDim {
 	uint64_t count;
@@ -43,7 +44,10 @@ struct DirectionPlan {
 	std::vector<PassPlan> passes;
 	std::vector<unsigned char> arena;  // host image of every LUT of this direction
 	void* dArena = nullptr;            // device copy
-	uint64_t tempBytes = 0;            // scratch this direction needs (0: none)
+	uint64_t tempBytes = 0;            // scratch this direction needs in ROLE_TEMP (0: none)
+	uint64_t temp2Bytes = 0;           // ... and in ROLE_TEMP2, which starts temp2Offset() bytes into the same allocation
+	uint64_t temp2Offset() const { return (tempBytes + 255ull) & ~255ull; }
+	uint64_t totalTemp() const { return temp2Bytes ? temp2Offset() + temp2Bytes : tempBytes; }
 	uint32_t uploadsPerAxis[4] = {0, 0, 0, 0};
 	uint32_t bigSequenceEvenR2C = 0;
 	uint64_t axisSplit[4][4] = {};
@@ -84,7 +88,7 @@ int build_direction_plan(const TransformDesc& d, DirectionPlan& out);
 
 // launchers (kernels.hip)
 struct LaunchBuffers {
-	void* base[4] = {nullptr, nullptr, nullptr, nullptr}; // by BufRole
+	void* base[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // by BufRole
 };
 int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 // The caller's streams (VkFFTConfiguration::stream / num_streams).  Everything is ordered on s[0]; a pass that the host has to split
@@ -119,6 +123,8 @@ int launch_conv_pointwise(const ConvParams& p, bool dp, hipStream_t stream);
 int launch_zero_slab(const ZeroParams& p, hipStream_t stream);
 // tile transposition of a strided axis against its unit-stride companion (kernels_aux.hip): awkward strided axes run as rows of a dense scratch copy
 int launch_transpose(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
+// pre / post map of a real transform as a pass of its own (kernels_aux.hip): coverage path around an arbitrary complex plan of the embedding length
+int launch_real_map(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 
 // misc
 std::vector<uint32_t> factorize_radices(uint64_t n, bool* smooth);

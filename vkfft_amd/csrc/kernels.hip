@@ -30,6 +30,8 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 		return launch_pow2_col_blue(pp, prm, stream);
 	case KERNEL_TRANSPOSE:
 		return launch_transpose(pp, prm, stream);
+	case KERNEL_REAL_MAP:
+		return launch_real_map(pp, prm, stream);
 	case KERNEL_POW2_BLUE_R2R:
 		return launch_pow2_blue_r2r(pp, prm, stream);
 	case KERNEL_MIXED_ROW:

@@ -7,6 +7,7 @@
 #include "engine.h"
 #include "butterflies.h"
 #include "memops.h"
+#include "kernel_generic.h"
 
 namespace vkfft_mi355x {
 
@@ -122,6 +123,43 @@ template <typename T> __global__ void __launch_bounds__(256) transpose_kernel(co
 		const uint32_t c = c0 + ty + 8u * r, j = j0 + tx;
 		if (j < p.L && c < p.dim[0].count) out[(int64_t)j * p.outStrideJ + (int64_t)c * p.dim[0].outStride] = tile[tx][ty + 8u * r];
 	}
+}
+
+// Pre / post map of a real transform as a pass of its own (coverage path: real transforms whose embedding length no fused kernel serves — it needs
+// Bluestein along a strided axis, or more points than the fused Bluestein kernels hold — run as  map -> complex plan of the embedding length on
+// dense scratch rows -> map).  The reference builds these maps into its Bluestein kernels (vkFFT_R2R.h, vkFFT_R2C.h:27, vkFFT_Scheduler.h:2271-2280);
+// the maps themselves are the element-wise full-length forms of kernel_generic.h (pre_gather / post_scatter), addressed by the natural index.
+//   preNat  = 1: scratch[row][n] = pre-map of the row's elements, n < L                    (row side = in, strides dim[].inStride / inStrideJ)
+//   postNat = 1: FFT output a of scratch[row][.] -> post-map -> the row's output element(s)  (row side = out, strides dim[].outStride / outStrideJ)
+// rows are enumerated by dim[0..2]; the scratch rows are dense: row index = g0 + count0 * (g1 + count1 * g2), pitch L
+template <typename T> __global__ void __launch_bounds__(256) real_map_kernel(const PassParams p) {
+	const uint32_t chunks = (p.L + 255u) / 256u;
+	const uint32_t row = blockIdx.x / chunks, n = (blockIdx.x % chunks) * 256u + threadIdx.x;
+	if (n >= p.L) return;
+	const uint32_t g0 = row % p.dim[0].count, r1 = row / p.dim[0].count;
+	const uint32_t g1 = r1 % p.dim[1].count, g2 = r1 / p.dim[1].count;
+	if (p.preNat) {
+		const int64_t rowBase = (int64_t)g0 * p.dim[0].inStride + (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride;
+		const Io64<T> io{p.in, nullptr, rowBase, 0, p.inStrideJ, 1};
+		cx<T> v = pre_gather<T>(p, io, n, 0, p.preOp);
+		if (p.swapIn) v = cswap(v);
+		((cx<T>*)p.out)[(int64_t)row * p.L + n] = v;
+	} else {
+		const int64_t rowBase = (int64_t)g0 * p.dim[0].outStride + (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride;
+		const Io64<T> io{nullptr, p.out, 0, rowBase, 1, p.outStrideJ};
+		cx<T> v = ((const cx<T>*)p.in)[(int64_t)row * p.L + n];
+		if (p.swapOut) v = cswap(v);
+		post_scatter<T>(p, io, n, v, 0, 0, p.postOp, p.natOutLen);
+	}
+}
+
+int launch_real_map(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
+	const uint64_t blocks = (uint64_t)((prm.L + 255u) / 256u) * prm.dim[0].count * prm.dim[1].count * prm.dim[2].count;
+	if (blocks == 0) return 0;
+	if (blocks > 0x7fffffffull) return 4039;
+	if (pp.dp) hipLaunchKernelGGL(real_map_kernel<double>, dim3((uint32_t)blocks), dim3(256), 0, stream, prm);
+	else hipLaunchKernelGGL(real_map_kernel<float>, dim3((uint32_t)blocks), dim3(256), 0, stream, prm);
+	return hipGetLastError() == hipSuccess ? 0 : 4039;
 }
 
 int launch_transpose(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {

@@ -919,12 +919,12 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 					q.L = (uint32_t)j.N; q.inStrideJ = j.inStrideJ; q.outStrideJ = 1;
 					q.dim[0] = {(uint32_t)C, 1, (int64_t)j.N};
 					q.dim[1] = {(uint32_t)o1.count, o1.inStride, d1}; q.dim[2] = {(uint32_t)o2.count, o2.inStride, d2};
-					t.inRole = j.inRole; t.outRole = ROLE_TEMP;
+					t.inRole = j.inRole; t.outRole = ROLE_TEMP2;
 				} else {
 					q.L = (uint32_t)C; q.inStrideJ = (int64_t)j.N; q.outStrideJ = 1;
 					q.dim[0] = {(uint32_t)j.N, 1, j.outStrideJ};
 					q.dim[1] = {(uint32_t)o1.count, d1, o1.outStride}; q.dim[2] = {(uint32_t)o2.count, d2, o2.outStride};
-					t.inRole = ROLE_TEMP; t.outRole = j.outRole;
+					t.inRole = ROLE_TEMP2; t.outRole = j.outRole;
 				}
 				q.tilesPerG0 = 1; // (launch_pass skips empty passes by this count; the kernel derives its own grid)
 				t.kernel = KERNEL_TRANSPOSE; t.dp = dp; t.threads = 256; t.inElemBytes = t.outElemBytes = (int)(dp ? 16 : 8);
@@ -934,17 +934,16 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 			transpose(false);
 			AxisJob rj;
 			rj.N = j.N; rj.inStrideJ = rj.outStrideJ = 1; rj.dp = dp; rj.inverse = j.inverse; rj.scale = j.scale;
-			rj.inRole = rj.outRole = ROLE_TEMP; rj.axisIndex = j.axisIndex;
+			// the dense copy lives in ROLE_TEMP2: the row plan is free to use ROLE_TEMP for a scratch of its own
+			rj.inRole = rj.outRole = ROLE_TEMP2; rj.axisIndex = j.axisIndex;
 			rj.others.push_back({C * outer, (int64_t)j.N, (int64_t)j.N}); // the scratch rows are dense: one collapsed batch dimension
-			const uint64_t tempBefore = out.tempBytes;
 			const int r = plan_c2c_axis(d, rj, ar, out, passes);
-			if (r == 0 && out.tempBytes == tempBefore) {
+			if (r == 0) {
 				transpose(true);
-				out.tempBytes = std::max<uint64_t>(out.tempBytes, C * j.N * outer * (dp ? 16 : 8));
+				out.temp2Bytes = std::max<uint64_t>(out.temp2Bytes, C * j.N * outer * (dp ? 16 : 8));
 				out.uploadsPerAxis[j.axisIndex] = 1;
 				return 0;
 			}
-			out.tempBytes = tempBefore;
 			passes.resize(mark);
 		}
 	}
@@ -1217,13 +1216,89 @@ static int make_r2c_pair_pass(uint64_t N, bool dp, bool inverse, const std::vect
 	return 0;
 }
 
+// ---- real transforms: coverage path -------------------------------------------------------------------------
+// A real transform along one axis as  pre-map pass -> complex transform of the embedding sequence on dense rows in ROLE_TEMP2 -> post-map pass
+// (kernels_aux.hip real_map_kernel).  The complex transform is whatever plan its length needs: Bluestein of any size, several passes.  Used where no
+// fused form exists: the embedding length needs Bluestein on a strided axis or beyond the fused Bluestein kernels' reach (the reference covers
+// these inside its Bluestein kernels: vkFFT_Scheduler.h:2271-2280, 2894-2944; vkFFT_R2R.h; vkFFT_R2C.h:27).  Two extra trips through memory.
+struct RealMapJob {
+	uint32_t preOp = 0, postOp = 0;
+	uint64_t N = 0, Lm = 0;            // real length, length of the embedding sequence
+	uint32_t outLen = 0;               // outputs per row (limit of the post-map's scatter)
+	bool cinverse = false;             // the embedding sequence is transformed backwards
+	int64_t strideIn = 1, strideOut = 1; // element strides along the axis (elements of the respective side)
+	std::vector<HostDim> others;       // rows: count, inStride (input elements), outStride (output elements)
+	int inRole = ROLE_BUFFER, outRole = ROLE_BUFFER, inElemBytes = 4, outElemBytes = 4;
+	size_t preAux3 = (size_t)-1, postAux = (size_t)-1, postAux2 = (size_t)-1;
+	double scale = 1.0;
+	int axisIndex = 0;
+};
+static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes);
+static int plan_real_by_maps(const TransformDesc& d, const RealMapJob& m, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
+	const bool dp = d.dp;
+	const size_t es = dp ? 16 : 8;
+	std::vector<HostDim> rows = m.others;
+	collapse_dims(rows);
+	while (rows.size() < 3) rows.push_back({1, 0, 0});
+	if (rows.size() > 3 || m.Lm < 2 || m.Lm >= (1ull << 31)) return 3002;
+	uint64_t nsub = 1; for (auto& r : rows) { if (r.count >= (1ull << 31)) return 3002; nsub *= r.count; }
+	if (nsub * ((m.Lm + 255) / 256) >= (1ull << 31)) return 3002;
+	const size_t mark = passes.size();
+	auto mapPass = [&](bool pre) {
+		PassPlan t; memset(&t.prm, 0, sizeof(t.prm));
+		PassParams& q = t.prm;
+		q.L = (uint32_t)m.Lm; q.opN = (uint32_t)m.N; q.tilesPerG0 = 1; q.scale = pre ? 1.0 : m.scale;
+		for (int i = 0; i < 3; i++) q.dim[i] = {(uint32_t)rows[i].count, rows[i].inStride, rows[i].outStride};
+		q.inStrideJ = m.strideIn; q.outStrideJ = m.strideOut;
+		if (pre) { q.preNat = 1; q.preOp = m.preOp; t.aux3Off = m.preAux3; t.inRole = m.inRole; t.outRole = ROLE_TEMP2; t.inElemBytes = m.inElemBytes; t.outElemBytes = (int)es; }
+		else { q.postNat = 1; q.postOp = m.postOp; q.natOutLen = m.outLen; t.auxOff = m.postAux; t.aux2Off = m.postAux2; t.inRole = ROLE_TEMP2; t.outRole = m.outRole; t.inElemBytes = (int)es; t.outElemBytes = m.outElemBytes; }
+		t.kernel = KERNEL_REAL_MAP; t.dp = dp; t.threads = 256; t.label = pre ? "real-pre-map" : "real-post-map";
+		passes.push_back(t);
+	};
+	mapPass(true);
+	AxisJob hj;
+	hj.N = m.Lm; hj.dp = dp; hj.inverse = m.cinverse; hj.scale = 1.0; hj.inRole = hj.outRole = ROLE_TEMP2; hj.axisIndex = m.axisIndex;
+	hj.others.push_back({nsub, (int64_t)m.Lm, (int64_t)m.Lm});
+	const int r = plan_c2c_axis(d, hj, ar, out, passes);
+	if (r) { passes.resize(mark); return r; }
+	mapPass(false);
+	out.temp2Bytes = std::max<uint64_t>(out.temp2Bytes, nsub * m.Lm * es);
+	out.uploadsPerAxis[m.axisIndex] += 2;
+	out.axisSplit[m.axisIndex][0] = m.N;
+	return 0;
+}
+
 // ---- real transforms ---------------------------------------------------------------------------------------
 // R2C/C2R along axis 0 (reference: two-sequences packing vkFFT_R2C.h:450/:178 for single-upload, even
 // decomposition vkFFT_R2C_even_decomposition.h:40 for long even N, callback form vkFFT_R2C.h:27 otherwise).
 // Here: even N -> one half-length complex FFT per row with the split fused as a post/pre operation of the
 // same kernel; odd N -> full-length complex FFT of the real row.
+static int plan_r2c_axis0_fused(const TransformDesc& d, bool inverse, const std::vector<HostDim>& othersReal, const std::vector<HostDim>& othersCplx,
+                                int realRole, int cplxRole, double scale, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes);
 static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vector<HostDim>& othersReal, const std::vector<HostDim>& othersCplx,
                           int realRole, int cplxRole, double scale, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
+	const size_t mark = passes.size();
+	const int r = plan_r2c_axis0_fused(d, inverse, othersReal, othersCplx, realRole, cplxRole, scale, ar, out, passes);
+	if (r != 3003) return r;
+	// no fused form (a row length that needs Bluestein beyond the fused kernels' reach): full-length "callback" form (vkFFT_R2C.h:27) as separate map passes
+	passes.resize(mark);
+	const uint64_t N = d.size[0];
+	RealMapJob m;
+	m.N = N; m.Lm = N; m.cinverse = inverse; m.scale = scale; m.axisIndex = 0;
+	m.preOp = m.postOp = inverse ? OP_C2R_FULL : OP_R2C_FULL;
+	m.outLen = (uint32_t)(inverse ? N : N / 2 + 1);
+	const int rb = d.dp ? 8 : 4;
+	m.inRole = inverse ? cplxRole : realRole; m.outRole = inverse ? realRole : cplxRole;
+	m.inElemBytes = inverse ? 2 * rb : rb; m.outElemBytes = inverse ? rb : 2 * rb;
+	for (size_t i = 0; i < othersReal.size(); i++) {
+		const int64_t rs = othersReal[i].inStride, cs = othersCplx[i].inStride;
+		m.others.push_back(inverse ? HostDim{othersReal[i].count, cs, rs} : HostDim{othersReal[i].count, rs, cs});
+	}
+	const int r2 = plan_real_by_maps(d, m, ar, out, passes);
+	return r2 == 3002 ? 3003 : r2;
+}
+static int plan_r2c_axis0_fused(const TransformDesc& d, bool inverse, const std::vector<HostDim>& othersReal, const std::vector<HostDim>& othersCplx,
+                                int realRole, int cplxRole, double scale, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
 	const uint64_t N = d.size[0];
 	const bool dp = d.dp;
 	const size_t es = dp ? 16 : 8;
@@ -1362,8 +1437,44 @@ static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vecto
 
 // DCT / DST of type 1..4 along one axis through a complex FFT with fused pre/post maps
 // (reference: vkFFT_R2R.h, size rules vkFFT_Scheduler.h:2271-2280).
+static int plan_r2r_axis_fused(const TransformDesc& d, int type, bool dst, uint64_t N, int64_t strideIn, int64_t strideOut, const std::vector<HostDim>& others,
+                               int inRole, int outRole, double scale, int axisIndex, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes);
 static int plan_r2r_axis(const TransformDesc& d, int type, bool dst, uint64_t N, int64_t strideIn, int64_t strideOut, const std::vector<HostDim>& others,
                          int inRole, int outRole, double scale, int axisIndex, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
+	const size_t mark = passes.size();
+	const int r = plan_r2r_axis_fused(d, type, dst, N, strideIn, strideOut, others, inRole, outRole, scale, axisIndex, ar, out, passes);
+	if (r != 3004 || type < 1 || type > 4 || N < 2) return r;
+	// no fused form (the embedding length needs Bluestein on a strided axis or beyond the fused kernels' reach): the element-wise full-length
+	// forms of the maps as separate passes around the complex plan of the embedding length
+	passes.resize(mark);
+	const bool dp = d.dp;
+	const size_t es = dp ? 16 : 8;
+	const int rb = dp ? 8 : 4;
+	RealMapJob m;
+	m.N = N; m.scale = scale; m.axisIndex = axisIndex; m.strideIn = strideIn; m.strideOut = strideOut; m.others = others;
+	m.inRole = inRole; m.outRole = outRole; m.inElemBytes = m.outElemBytes = rb; m.outLen = (uint32_t)N;
+	auto quarter = [&]() { const size_t a = ar.alloc(N * es); for (uint64_t k = 0; k < N; k++) ar.putc(a, k, unit_root(k, 4 * N), dp); return a; };
+	switch (type) {
+	case 1:
+		if (!dst) { m.Lm = 2 * N - 2; m.preOp = OP_DCT1_PRE; m.postOp = OP_DCT1_POST; }
+		else { m.Lm = 2 * N + 2; m.preOp = OP_DST1_PRE; m.postOp = OP_DST1_POST; }
+		break;
+	case 2: m.Lm = N; m.preOp = dst ? OP_DST2_PRE : OP_DCT2_PRE; m.postOp = dst ? OP_DST2_POST : OP_DCT2_POST; m.postAux = quarter(); break;
+	case 3: m.Lm = N; m.preOp = dst ? OP_DST3_PRE : OP_DCT3_PRE; m.postOp = dst ? OP_DST3_POST : OP_DCT3_POST; m.preAux3 = quarter(); m.cinverse = true; break;
+	default: { // type 4: zero-padded 2N form, its maps are element-wise
+		m.Lm = 2 * N; m.preOp = dst ? OP_DST4_PRE : OP_DCT4_PRE; m.postOp = dst ? OP_DST4_POST : OP_DCT4_POST;
+		m.preAux3 = quarter();
+		const size_t a2 = ar.alloc(N * es);
+		for (uint64_t n = 0; n < N; n++) ar.putc(a2, n, unit_root(2 * n + 1, 8 * N), dp);
+		m.postAux2 = a2;
+		break;
+	}
+	}
+	const int r2 = plan_real_by_maps(d, m, ar, out, passes);
+	return r2 == 3002 ? 3004 : r2;
+}
+static int plan_r2r_axis_fused(const TransformDesc& d, int type, bool dst, uint64_t N, int64_t strideIn, int64_t strideOut, const std::vector<HostDim>& others,
+                               int inRole, int outRole, double scale, int axisIndex, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
 	const bool dp = d.dp;
 	const size_t es = dp ? 16 : 8;
 	const uint32_t dmax = direct_max(d);
@@ -1636,7 +1747,7 @@ int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
 		}
 	}
 
-	if (d.userTempBytes && out.tempBytes > d.userTempBytes) return 2016;
+	if (d.userTempBytes && out.totalTemp() > d.userTempBytes) return 2016;
 	return 0;
 }
 
