@@ -113,8 +113,15 @@ int ref_convolution(int fftdim, const uint64_t* size, int r2c, int dp, uint64_t 
 }
 
 // sample-0 protocol on a device buffer of `nbytes` (random data): returns ms per FFT+iFFT pair.
+double ref_bench_pair_zeropad_ms(int fftdim, const uint64_t* size, uint64_t batch, int dp, int kind, uint64_t nbytes,
+                                 int num_iter, uint64_t* uploads_out, const uint64_t* flags, const uint64_t* left, const uint64_t* right);
 double ref_bench_pair_ms(int fftdim, const uint64_t* size, uint64_t batch, int dp, int kind, uint64_t nbytes,
                          int num_iter, uint64_t* uploads_out) {
+    return ref_bench_pair_zeropad_ms(fftdim, size, batch, dp, kind, nbytes, num_iter, uploads_out, nullptr, nullptr, nullptr);
+}
+// the same timing loop with the reference's native zero padding (flags / left / right per axis; nullptr: none)
+double ref_bench_pair_zeropad_ms(int fftdim, const uint64_t* size, uint64_t batch, int dp, int kind, uint64_t nbytes,
+                                 int num_iter, uint64_t* uploads_out, const uint64_t* flags, const uint64_t* left, const uint64_t* right) {
     hipInit(0); hipDevice_t dev; hipDeviceGet(&dev, 0); hipSetDevice(0);
     void* buf = nullptr; if (hipMalloc(&buf, nbytes) != hipSuccess) return -3.0;
     { // deterministic fill in [-1,1]
@@ -128,6 +135,7 @@ double ref_bench_pair_ms(int fftdim, const uint64_t* size, uint64_t batch, int d
     cfg.doublePrecision = dp;
     if (kind == 1) cfg.performR2C = 1;
     if (kind >= 11 && kind <= 14) cfg.performDCT = kind - 10;
+    if (flags) for (int i = 0; i < fftdim; i++) { cfg.performZeropadding[i] = flags[i]; cfg.fft_zeropad_left[i] = left[i]; cfg.fft_zeropad_right[i] = right[i]; }
     VkFFTResult r = initializeVkFFT(&app, cfg);
     if (r != VKFFT_SUCCESS) { hipFree(buf); return -(double)r; }
     if (uploads_out) for (int i = 0; i < fftdim; i++) uploads_out[i] = app.localFFTPlan->numAxisUploads[i];

@@ -7,9 +7,13 @@ from vkfft_amd import api
 
 
 def _kernel_index(j, l, m, symmetric):
+    """position of component (j, l) among the spectra of one convolution kernel: rows then columns, or — symmetricKernel — the packed upper triangle in
+    the documented order xx, xy, xz, yy, yz, zz (API guide, symmetricKernel).  Written independently of the library: enumerate the triangle."""
     if not symmetric:
         return j * m + l
-    return l * m - l * l + j if l < j else j * m - j * j + l
+    a, b = (j, l) if j <= l else (l, j)
+    order = [(r, c) for r in range(m) for c in range(r, m)]
+    return order.index((a, b))
 
 
 def conv_case(run, shape, *, m=1, cf=1, nk=1, nb=1, symmetric=False, conjugate=0, cross=False, r2c=False, dp=False, seed=0):
@@ -206,11 +210,122 @@ def conv_zeropad_case(run, shape, pads, *, m=1, r2c=False, dp=False, seed=0):
     ka.delete(); ca.delete()
     if r2c:
         got = got[..., : shape[0]]
-    return rel_l2(got, want)
+    # like the reference (vkFFT_Plan_FFT.h:532-541: the inverse of a spatially padded plan does not write the padded range), only the unpadded part of
+    # the result is defined
+    ok = mask(want.shape)
+    return rel_l2(got[ok], want[ok])
 
 
 CONV_ZEROPAD_CASES = [
     dict(shape=(32, 32, 32), pads={0: (16, 32), 1: (16, 32), 2: (16, 32)}, m=3, r2c=True),   # the reference's sample 51
     dict(shape=(64, 48), pads={0: (32, 64), 1: (24, 48)}, m=2),
     dict(shape=(128,), pads={0: (64, 128)}, m=1, dp=True),
+]
+
+
+def zeropad_semantics_case(run, shape, pads, *, r2c=False, dp=False, seed=0):
+    """What the reference's zero padding promises besides the values (vkFFT_Zeropad.h:28, vkFFT_Plan_FFT.h:522-560, API guide "Zero padding parameters"):
+    the padded range of the SOURCE is never read — so it is never written either, also when the source is a separate input buffer —, the inverse of
+    a spatially padded plan does not write the padded range of its result, and sequences inside the padded range of an axis still to come are not
+    visited.  Returns a dict of error figures / flags; the caller asserts."""
+    rng = np.random.default_rng(seed)
+    rt = np.float64 if dp else np.float32
+    ct = np.complex128 if dp else np.complex64
+    dims = tuple(reversed(shape)); nd = len(dims); ax = tuple(range(-nd, 0))
+    left = [0] * 4; right = [0] * 4; flag = [0] * 4
+    for a, (l, r) in pads.items():
+        left[a], right[a], flag[a] = l, r, 1
+    def mask(sh):
+        mk = np.ones(sh, bool)
+        for a, (l, r) in pads.items():
+            idx = [slice(None)] * len(sh); idx[len(sh) - 1 - a] = slice(l, r); mk[tuple(idx)] = False
+        return mk
+    kw = dict(dp=dp, lib=run.lib, performZeropadding=flag, fft_zeropad_left=left, fft_zeropad_right=right)
+    out = {}
+    last = nd - 1                       # the axis transformed first by the inverse: its padded range stays untouched by the whole inverse
+    if not r2c:
+        x = (rng.uniform(-1, 1, dims) + 1j * rng.uniform(-1, 1, dims)).astype(ct)
+        want = np.fft.fftn(np.where(mask(x.shape), x, 0).astype(np.complex128), axes=ax)
+        # (1) forward, separate input buffer: the input is bit-unchanged, padded range included
+        hin, pin = run._alloc(x); hout, pout = run._alloc(np.zeros_like(x))
+        strides = [0] * 4
+        acc = 1
+        for i in range(nd):
+            acc *= shape[i]; strides[i] = acc
+        app = api.App(list(shape), 1, buffer_ptr=pout, isInputFormatted=1, inputBuffer=pin, inputBufferStride=strides, **kw)
+        app.forward()
+        out["fwd_out_of_place"] = rel_l2(run._fetch(hout, ct).reshape(x.shape), want)
+        out["input_untouched"] = bool((run._fetch(hin, ct).reshape(x.shape).view(rt) == x.view(rt)).all())
+        app.delete()
+        # (2) inverse in place: unpadded part = the inverse transform; the padded range of the last axis keeps the bits it had
+        spec = (rng.uniform(-1, 1, dims) + 1j * rng.uniform(-1, 1, dims)).astype(ct)
+        h, ptr = run._alloc(spec)
+        app = api.App(list(shape), 1, buffer_ptr=ptr, **kw)
+        app.inverse()
+        got = run._fetch(h, ct).reshape(spec.shape)
+        app.delete()
+        wanti = np.fft.ifftn(spec.astype(np.complex128), axes=ax) * np.prod(dims)
+        ok = mask(spec.shape)
+        out["inv_valid_part"] = rel_l2(got[ok], wanti[ok])
+        if last in pads:
+            idx = [slice(None)] * nd; idx[nd - 1 - last] = slice(*pads[last])
+            out["inv_padded_range_untouched"] = bool((got[tuple(idx)].view(rt) == spec[tuple(idx)].view(rt)).all())
+        # (3) only axis 0 transformed (the others omitted): sequences inside the padded range of a later axis are not visited
+        if nd > 1 and any(a > 0 and r == shape[a] for a, (l, r) in pads.items()):
+            omit = [0] + [1] * (nd - 1) + [0] * (4 - nd)
+            h, ptr = run._alloc(x)
+            app = api.App(list(shape), 1, buffer_ptr=ptr, omitDimension=omit, **kw)
+            app.forward()
+            got = run._fetch(h, ct).reshape(x.shape)
+            app.delete()
+            skipped = np.zeros(x.shape, bool)
+            for a, (l, r) in pads.items():
+                if a > 0 and r == shape[a]:
+                    idx = [slice(None)] * nd; idx[nd - 1 - a] = slice(l, r); skipped[tuple(idx)] = True
+            out["skipped_sequences_untouched"] = bool((got.view(rt).reshape(x.shape + (2,))[skipped] == x.view(rt).reshape(x.shape + (2,))[skipped]).all())
+            xm = x.copy().astype(np.complex128)
+            if 0 in pads:
+                xm[..., pads[0][0]:pads[0][1]] = 0
+            w0 = np.fft.fft(xm, axis=-1)
+            out["visited_sequences"] = rel_l2(got[~skipped], w0[~skipped])
+        return out
+    nx = shape[0]; rowlen = 2 * (nx // 2 + 1)
+    x = rng.uniform(-1, 1, dims).astype(rt)
+    garbage = rng.uniform(-1, 1, dims[:-1] + (rowlen,)).astype(rt)
+    buf = garbage.copy(); buf[..., :nx] = x
+    want = np.fft.rfftn(np.where(mask(x.shape), x, 0).astype(np.float64), axes=ax)
+    h, ptr = run._alloc(buf)
+    app = api.App(list(shape), 1, buffer_ptr=ptr, r2c=True, **kw)
+    app.forward()
+    out["fwd"] = rel_l2(run._fetch(h, ct).reshape(want.shape), want)
+    app.delete()
+    # inverse: Hermitian spectrum in, real rows out; the padded range of the last axis (and of the real rows) keeps its bits
+    spec = np.fft.rfftn(rng.uniform(-1, 1, dims), axes=ax).astype(ct)
+    h, ptr = run._alloc(spec)
+    app = api.App(list(shape), 1, buffer_ptr=ptr, r2c=True, **kw)
+    app.inverse()
+    gotr = run._fetch(h, rt).reshape(dims[:-1] + (rowlen,))
+    app.delete()
+    wanti = np.fft.irfftn(spec.astype(np.complex128), s=dims, axes=ax) * np.prod(dims)
+    ok = mask(x.shape)
+    out["inv_valid_part"] = rel_l2(gotr[..., :nx][ok], wanti[ok])
+    before = spec.view(rt).reshape(dims[:-1] + (rowlen,))
+    if last in pads and last > 0:
+        idx = [slice(None)] * nd; idx[nd - 1 - last] = slice(*pads[last])
+        out["inv_padded_range_untouched"] = bool((gotr[tuple(idx)] == before[tuple(idx)]).all())
+    if 0 in pads and nd == 1: # (with more axes the complex passes of the other axes have gone over these positions before the C2R pass, as in the reference)
+        l, r = pads[0]
+        out["inv_padded_reals_untouched"] = bool((gotr[..., l:r] == before[..., l:r]).all())
+    return out
+
+
+ZEROPAD_SEMANTICS_CASES = [
+    dict(shape=(64,), pads={0: (32, 64)}),
+    dict(shape=(64, 32), pads={0: (32, 64), 1: (16, 32)}),
+    dict(shape=(32, 16, 8), pads={0: (16, 32), 1: (8, 16), 2: (4, 8)}, dp=True),      # the reference's sample 4 at a small size
+    dict(shape=(48, 20), pads={0: (10, 30), 1: (12, 20)}),                            # an inner range on axis 0, non-power-of-two lengths
+    dict(shape=(64, 32), pads={0: (32, 64), 1: (16, 32)}, r2c=True),
+    dict(shape=(30, 16, 4), pads={0: (10, 20), 2: (2, 4)}, r2c=True, dp=True),
+    dict(shape=(128,), pads={0: (64, 128)}, r2c=True),
+    dict(shape=(45,), pads={0: (20, 45)}, r2c=True),                                  # odd rows: the full-length form, masks in real elements
 ]

@@ -29,7 +29,7 @@ struct AppState {
 	// results are the same
 	VkFFTApplication* convFwd = nullptr;
 	VkFFTApplication* convInv = nullptr;
-	bool zeroPad = false;          // performZeropadding on some axis
+	uint32_t zeroPadMask = 0;      // zero-padded axes whose plan cannot skip the range: it is written with zeros ahead of the transform that reads it
 };
 
 VkFFTResult hip_to_result(hipError_t e, VkFFTResult code) { return e == hipSuccess ? VKFFT_SUCCESS : code; }
@@ -154,9 +154,6 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 		zeroPad = true;
 		if (in.fft_zeropad_left[i] > in.fft_zeropad_right[i] || in.fft_zeropad_right[i] > in.size[i]) return unsupported("a zero-padding range outside the axis");
 	}
-	// zero padding writes the zeros the reference only assumes (vkFFT_Zeropad.h:28): it needs a source it may write to
-	if (zeroPad && !in.frequencyZeroPadding && in.isInputFormatted) return unsupported("zero-padding of a separate input buffer");
-	if (zeroPad && in.frequencyZeroPadding && in.isOutputFormatted) return unsupported("frequency zero-padding of a separate output buffer");
 	if (in.halfPrecision || in.halfPrecisionMemoryOnly) return unsupported("half precision");
 	if (in.quadDoubleDoublePrecision || in.quadDoubleDoublePrecisionDoubleMemory) return unsupported("double-double precision");
 	if (in.doublePrecisionFloatMemory) return unsupported("doublePrecisionFloatMemory");
@@ -248,6 +245,8 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 	d.fixMaxRadixBluestein = (int)c.fixMaxRadixBluestein;
 	if (c.fixMaxRaderPrimeMult) d.raderMultMax = c.fixMaxRaderPrimeMult;
 	if (c.userTempBuffer && c.tempBufferSize) d.userTempBytes = c.tempBufferSize[0];
+	for (pfUINT i = 0; i < c.FFTdim && i < 4; i++) if (c.performZeropadding[i] && c.fft_zeropad_right[i] > c.fft_zeropad_left[i]) { d.padL[i] = c.fft_zeropad_left[i]; d.padR[i] = c.fft_zeropad_right[i]; }
+	d.padFrequency = c.frequencyZeroPadding != 0;
 	// fused Four-Step tuning knobs (experiments only; defaults are the planner's)
 	if (const char* e = getenv("VKFFT_MI355X_FUSED")) d.fused = atoi(e) != 0;
 	if (const char* e = getenv("VKFFT_MI355X_FUSED_MODE")) d.fusedMode = atoi(e);
@@ -264,7 +263,6 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 	if (!st) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_MALLOC_FAILED; }
 	app->impl = st;
 	st->sweepEnabled = getenv("VKFFT_MI355X_NO_REVERSE") == nullptr;
-	st->zeroPad = zeroPad;
 
 	VkFFTResult res = VKFFT_SUCCESS;
 	if (!c.makeForwardPlanOnly) {
@@ -274,6 +272,16 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 	if (!c.makeInversePlanOnly) {
 		res = make_direction(app, d, false, &app->localFFTPlan);
 		if (res != VKFFT_SUCCESS) { deleteVkFFT(app); return res; }
+	}
+	if (zeroPad) {
+		// Axes whose passes skip the padded range themselves need nothing here.  The others (plans of several passes, Bluestein, R2R maps) get the
+		// range written with zeros ahead of the transform that reads it — only possible in a buffer this library may write to
+		VkFFTPlan* reader = c.frequencyZeroPadding ? app->localFFTPlan_inverse : app->localFFTPlan;
+		st->zeroPadMask = reader ? ((DirectionPlan*)reader->impl)->padFallbackMask : 0u;
+		if (st->zeroPadMask && (c.frequencyZeroPadding ? c.isOutputFormatted : c.isInputFormatted)) {
+			deleteVkFFT(app);
+			return unsupported("zero-padding of a separate input buffer on an axis whose plan cannot skip the padded range (several passes, Bluestein, R2R)");
+		}
 	}
 	if (c.printMemoryLayout || getenv("VKFFT_MI355X_PRINT_PLAN")) { // one line per launch: which kernel family serves it
 		static const char* kname[] = {"generic", "pow2_row", "pow2_col", "r2c_pair", "?", "mixed_row", "opfft", "pow2_blue", "pow2_col_blue", "pow2_blue_r2r", "pow2_fused", "transpose", "real_map"};
@@ -372,7 +380,7 @@ VKFFT_API VkFFTResult VkFFTAppend(VkFFTApplication* app, int inverse, VkFFTLaunc
 		for (uint32_t i = 0; i < ss.n; i++) ss.s[i] = c.stream[i];
 		if (ss.n > 1) { for (uint32_t i = 0; i < ss.n; i++) ss.ev[i] = st->events[i]; }
 	}
-	if (st->zeroPad && (inverse == 1) == (c.frequencyZeroPadding != 0)) {
+	if (st->zeroPadMask && (inverse == 1) == (c.frequencyZeroPadding != 0)) {
 		VkFFTResult z = zero_padded_ranges(app, inverse == 1, lb.base[ROLE_BUFFER], ss.s[0]);
 		if (z != VKFFT_SUCCESS) return z;
 	}
@@ -422,8 +430,9 @@ namespace {
 
 // Zero padding (VkFFTConfiguration::performZeropadding / fft_zeropad_left / fft_zeropad_right, vkFFT_Structs.h:150-155): the range
 // [left, right) of an axis is taken as zero by the first transform that reads it — the forward one, or the inverse one with
-// frequencyZeroPadding.  The reference skips the reads (vkFFT_Zeropad.h:28); this library writes the zeros and transforms everything, so
-// the padded range of the OUTPUT holds computed values where the reference leaves it untouched.
+// frequencyZeroPadding.  Like the reference (vkFFT_Zeropad.h:28) the single-pass kernels skip the range on the read side, leave it unwritten on the
+// write side of the opposite direction and do not visit sequences inside the padded range of an axis still to come (planner.cpp, "zero padding").
+// This is the fallback for the axes of AppState::zeroPadMask, whose plans cannot skip: the zeros are written, everything is transformed.
 VkFFTResult zero_padded_ranges(VkFFTApplication* app, bool inverse, void* base, hipStream_t stream) {
 	const VkFFTConfiguration& c = app->configuration;
 	const bool r2c = c.performR2C != 0, real = c.performDCT || c.performDST || (r2c && !inverse);
@@ -439,7 +448,7 @@ VkFFTResult zero_padded_ranges(VkFFTApplication* app, bool inverse, void* base, 
 	z.systemStride = (uint64_t)c.bufferStride[c.FFTdim - 1] * unit;
 	z.systems = (uint32_t)(app->actualNumBatches * c.coordinateFeatures);
 	for (pfUINT i = 0; i < c.FFTdim; i++) {
-		if (!c.performZeropadding[i]) continue;
+		if (!c.performZeropadding[i] || !((((AppState*)app->impl)->zeroPadMask >> i) & 1u)) continue;
 		z.axis = (uint32_t)i; z.left = (uint32_t)c.fft_zeropad_left[i]; z.right = (uint32_t)std::min<pfUINT>(c.fft_zeropad_right[i], z.size[i]);
 		if (launch_zero_slab(z, stream)) return VKFFT_ERROR_FAILED_TO_LAUNCH_KERNEL;
 	}

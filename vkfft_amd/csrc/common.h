@@ -161,6 +161,9 @@ struct PassParams {
 	uint32_t tilesPerG0; // ceil(dim[0].count / T)
 	uint32_t reverseTiles; // 1: workgroup i works on tile (grid - 1 - i): inverse plans sweep the buffer back to front
 	uint32_t inElemBytes, outElemBytes; // bytes per global element on each side (real scalar or complex)
+	// zero padding (VkFFTConfiguration::performZeropadding, vkFFT_Zeropad.h:28): elements [padInL, padInL + padInN) of every sub-FFT are taken as zero and NOT
+	// read; elements [padOutL, padOutL + padOutN) of its output are NOT written.  Units: elements of the respective side; N = 0: off
+	uint32_t padInL, padInN, padOutL, padOutN;
 };
 
 // ---- fused Four-Step launch (kernel_pow2_fused.h): both passes of a two-factor transform in one persistent kernel ----

@@ -51,6 +51,7 @@ struct DirectionPlan {
 	uint32_t uploadsPerAxis[4] = {0, 0, 0, 0};
 	uint32_t bigSequenceEvenR2C = 0;
 	uint64_t axisSplit[4][4] = {};
+	uint32_t padFallbackMask = 0;      // zero-padded axes whose passes cannot skip the padded range themselves: the range is written with zeros ahead of the transform
 };
 
 // ---- transform description handed to the planner (derived from VkFFTConfiguration) -------------------
@@ -76,6 +77,9 @@ struct TransformDesc {
 	uint64_t raderMultMin = 17, raderMultMax = 128;
 	uint64_t userTempBytes = 0;  // >0: temp supplied by the caller with this size
 	bool disableFastKernels = false;
+	// zero padding (performZeropadding / fft_zeropad_left / fft_zeropad_right / frequencyZeroPadding): range [padL, padR) of an axis, padR == 0: none
+	uint64_t padL[4] = {0, 0, 0, 0}, padR[4] = {0, 0, 0, 0};
+	bool padFrequency = false;
 	// fused Four-Step (kernel_pow2_fused.h); the numeric fields are tuning knobs, 0 = planner default
 	bool fused = true;
 	int fusedMode = 2;

@@ -22,18 +22,24 @@ namespace vkfft_mi355x {
 // Access to the elements of ONE sub-FFT on the global side; element index j -> j * strideJ from the sub-FFT's base.
 // Io64: plain pointers with 64-bit element offsets (any span).  Io32: CDNA buffer addressing (memops.h), wave-uniform
 // tile base + 32-bit per-lane byte offsets (tile span < 2 GiB, checked by the planner).
+// Zero padding (PassParams::padIn* / padOut*): elements [padInL, padInL + padInN) read as zero without touching memory, elements of the padded output
+// range are not written (unsigned wrap-around makes one compare do for both bounds; N = 0: off).
 template <typename T> struct Io64 {
 	const void* in; void* out; int64_t inBase, outBase, inSj, outSj;
-	__device__ inline cx<T> ldc(uint32_t j) const { return ((const cx<T>*)in)[inBase + (int64_t)j * inSj]; }
-	__device__ inline T ldr(uint32_t j) const { return ((const T*)in)[inBase + (int64_t)j * inSj]; }
-	__device__ inline void stc(uint32_t j, cx<T> v) const { ((cx<T>*)out)[outBase + (int64_t)j * outSj] = v; }
-	__device__ inline void str(uint32_t j, T v) const { ((T*)out)[outBase + (int64_t)j * outSj] = v; }
+	uint32_t padInL = 0, padInN = 0, padOutL = 0, padOutN = 0;
+	__device__ inline void set_pad(const PassParams& p) { padInL = p.padInL; padInN = p.padInN; padOutL = p.padOutL; padOutN = p.padOutN; }
+	__device__ inline cx<T> ldc(uint32_t j) const { if (j - padInL < padInN) return cx<T>{(T)0, (T)0}; return ((const cx<T>*)in)[inBase + (int64_t)j * inSj]; }
+	__device__ inline T ldr(uint32_t j) const { if (j - padInL < padInN) return (T)0; return ((const T*)in)[inBase + (int64_t)j * inSj]; }
+	__device__ inline void stc(uint32_t j, cx<T> v) const { if (j - padOutL < padOutN) return; ((cx<T>*)out)[outBase + (int64_t)j * outSj] = v; }
+	__device__ inline void str(uint32_t j, T v) const { if (j - padOutL < padOutN) return; ((T*)out)[outBase + (int64_t)j * outSj] = v; }
 };
 template <typename T> struct Io32 {
 	GBuf gin, gout; uint32_t inOff, outOff, inSj, outSj; // byte offsets / byte strides; offsets = kGbInvalid for lanes of a partial tile
+	uint32_t padInL = 0, padInN = 0, padOutL = 0, padOutN = 0; // zero padding: an element of the padded range gets an out-of-range offset (loads return 0, stores are dropped)
+	__device__ inline void set_pad(const PassParams& p) { padInL = p.padInL; padInN = p.padInN; padOutL = p.padOutL; padOutN = p.padOutN; }
 	// lanes of a partial tile carry inOff = kGbInvalid: adding j * stride (< 2 GiB, planner span guard) keeps them out of range
-	__device__ inline uint32_t ia(uint32_t j) const { return inOff + j * inSj; }
-	__device__ inline uint32_t oa(uint32_t j) const { return outOff + j * outSj; }
+	__device__ inline uint32_t ia(uint32_t j) const { return (j - padInL < padInN) ? kGbInvalid : inOff + j * inSj; }
+	__device__ inline uint32_t oa(uint32_t j) const { return (j - padOutL < padOutN) ? kGbInvalid : outOff + j * outSj; }
 	__device__ inline cx<T> ldc(uint32_t j) const { return gb_load<T>(gin, ia(j), 0); }
 	__device__ inline T ldr(uint32_t j) const { return gb_load_real<T>(gin, ia(j), 0); }
 	__device__ inline void stc(uint32_t j, cx<T> v) const { gb_store<T>(gout, oa(j), 0, v); }
@@ -514,7 +520,8 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 					const Io64<T> io{p.in, p.out, rowBase, 0, 1, 1};
 					v = pre_gather<T>(p, io, n, 0, p.preOp);
 				} else {
-					const Io64<T> io{p.in, p.out, inBase + (int64_t)f * p.dim[0].inStride, 0, p.inStrideJ, p.outStrideJ};
+					Io64<T> io{p.in, p.out, inBase + (int64_t)f * p.dim[0].inStride, 0, p.inStrideJ, p.outStrideJ};
+					io.set_pad(p);
 					v = pre_gather<T>(p, io, pos, (g0base + f) * p.opStride0 + g1 * p.opStride1, p.preOp);
 				}
 			}
@@ -590,7 +597,8 @@ template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kerne
 				post_scatter<T>(p, io, n, rd(k), 0, 0, p.postOp, p.natOutLen);
 				continue;
 			}
-			const Io64<T> io{p.in, p.out, 0, outBase + (int64_t)f * p.dim[0].outStride, p.inStrideJ, p.outStrideJ};
+			Io64<T> io{p.in, p.out, 0, outBase + (int64_t)f * p.dim[0].outStride, p.inStrideJ, p.outStrideJ};
+			io.set_pad(p);
 			post_store<T>(p, io, k, colIdx, (g0base + f) * p.opStride0 + g1 * p.opStride1, rd, p.postOp);
 		}
 	}

@@ -386,6 +386,7 @@ __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	io.outOff = valid ? f * (uint32_t)p.dim[0].outStride * p.outElemBytes : kGbInvalid;
 	io.inSj = (uint32_t)p.inStrideJ * p.inElemBytes;
 	io.outSj = (uint32_t)p.outStrideJ * p.outElemBytes;
+	io.set_pad(p);
 	const GBuf glut = make_gbuf(p.lut);
 	uint32_t colIdx = 0;
 	if constexpr (POST == OP_TWIDDLE_4STEP && !TRANS) { if (p.fsColFromDim1) colIdx = g1; else { uint32_t rr; p.fsColDiv.divmod(g0, colIdx, rr); } }

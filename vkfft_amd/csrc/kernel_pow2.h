@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_ro
 	constexpr bool STAGED = TPF <= 8;
 	constexpr int SP = N + 1, NT = TPF * FPW, PER = 16 / (int)ES; // staging pitch; elements per 16-byte access
 	__shared__ cx<T> stage[STAGED ? FPW * SP : 1];
-	const bool denseIn = STAGED && p.dim[0].inStride == (int64_t)N, denseOut = STAGED && p.dim[0].outStride == (int64_t)N;
+	const bool denseIn = STAGED && p.dim[0].inStride == (int64_t)N && !p.padInN, denseOut = STAGED && p.dim[0].outStride == (int64_t)N && !p.padOutN;
 	const uint32_t rowsHere = p.dim[0].count - f0 < (uint32_t)FPW ? p.dim[0].count - f0 : (uint32_t)FPW;
 	if (denseIn) {
 #pragma unroll
@@ -48,6 +48,9 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_ro
 		VKFFT_SYNC();
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = stage[f * SP + tau + m * TPF];
+	} else if (p.padInN) { // zero padding: points of the padded range get an out-of-range offset (they read as zero and are not fetched)
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = gb_load<T>(gin, (tau + (uint32_t)(m * TPF) - p.padInL < p.padInN) ? kGbInvalid : laneIn, (uint32_t)(m * TPF) * ES);
 	} else {
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = gb_load<T>(gin, laneIn, (uint32_t)(m * TPF) * ES);
@@ -78,6 +81,9 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_ro
 			if constexpr (PER == 2) gb_store2_x<T, 0>(gout, off, stage[row * SP + col], stage[row * SP + col + 1]);
 			else gb_store<T>(gout, off, 0, stage[row * SP + col]);
 		}
+	} else if (p.padOutN) { // (the padded range of the output is not written)
+#pragma unroll
+		for (int m = 0; m < E; m++) gb_store<T>(gout, (tau + (uint32_t)(m * TPF) - p.padOutL < p.padOutN) ? kGbInvalid : laneOut, (uint32_t)(m * TPF) * ES, v[m]);
 	} else {
 #pragma unroll
 		for (int m = 0; m < E; m++) gb_store<T>(gout, laneOut, (uint32_t)(m * TPF) * ES, v[m]);
@@ -199,8 +205,13 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 	const uint32_t laneIn = valid ? (tau * (uint32_t)p.inStrideJ + c * (uint32_t)p.dim[0].inStride) * ES : kGbInvalid;
 	const uint32_t stepIn = (uint32_t)(TPF * (uint32_t)p.inStrideJ) * ES;
 	cx<T> v[E];
+	if (p.padInN) { // zero padding along this axis: rows of the padded range are not fetched
 #pragma unroll
-	for (int m = 0; m < E; m++) v[m] = gb_load<T>(gin, laneIn, m * stepIn);
+		for (int m = 0; m < E; m++) v[m] = gb_load<T>(gin, (tau + (uint32_t)(m * TPF) - p.padInL < p.padInN) ? kGbInvalid : laneIn, m * stepIn);
+	} else {
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = gb_load<T>(gin, laneIn, m * stepIn);
+	}
 	if (p.swapIn) {
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = cswap(v[m]);
@@ -223,8 +234,13 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 	if (p.colModeOut) {
 		const uint32_t laneOut = valid ? (tau * (uint32_t)p.outStrideJ + c * (uint32_t)p.dim[0].outStride) * ES : kGbInvalid;
 		const uint32_t stepOut = (uint32_t)(TPF * (uint32_t)p.outStrideJ) * ES;
+		if (p.padOutN) {
 #pragma unroll
-		for (int m = 0; m < E; m++) gb_store<T>(gout, laneOut, m * stepOut, v[m]);
+			for (int m = 0; m < E; m++) gb_store<T>(gout, (tau + (uint32_t)(m * TPF) - p.padOutL < p.padOutN) ? kGbInvalid : laneOut, m * stepOut, v[m]);
+		} else {
+#pragma unroll
+			for (int m = 0; m < E; m++) gb_store<T>(gout, laneOut, m * stepOut, v[m]);
+		}
 	} else {
 		// transposed store: column c becomes the contiguous run out[c*dim0.outStride + k*outStrideJ], lanes along k
 		if constexpr (SCH::NS > 1) VKFFT_SYNC(); // the last exchange's reads are complete

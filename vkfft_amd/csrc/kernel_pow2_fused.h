@@ -89,12 +89,10 @@ template <typename T, typename SA, int TCA, typename SB, int TCB, int TWL, int C
 // Publishing an A tile's completion (thread 0, at a point where every wave's vector-memory operations have drained: the ring stores
 // are write-through, so "acknowledged" means "at the memory side").  Write-back stores + an L2 write-back before the signal were tried
 // and are wrong: the writer's L2 keeps the lines, and a later tenant of the ring slot written by another XCD is then read stale.
-template <int MODE> __device__ inline void fused_publish(uint32_t* ctr, uint32_t& pending, uint32_t& flushing) {
+__device__ inline void fused_publish(uint32_t* ctr, uint32_t& pending) {
 	constexpr uint32_t kNone = 0xffffffffu;
-	(void)flushing;
 	if (pending != kNone) { (void)VKFFT_ATOMIC_ADD_U32(ctr + pending, 1u); pending = kNone; }
 }
-template <int MODE> __device__ inline void fused_publish_all(uint32_t* ctr, uint32_t& pending, uint32_t& flushing) { fused_publish<MODE>(ctr, pending, flushing); }
 
 __device__ inline uint32_t fused_xcc_id() {
 #if defined(VKFFT_HOSTEMU)
@@ -143,7 +141,6 @@ pow2_fused_kernel(const FusedParams p) {
 	auto depA = [&](uint32_t s) -> uint32_t { return (s < Cq && s >= p.NS) ? doneB + q + Q * (s - p.NS) : kNone; };
 	auto depB = [&](uint32_t s) -> uint32_t { return (s >= p.D && s - p.D < Cq) ? doneA + q + Q * (s - p.D) : kNone; };
 	uint32_t pending = kNone;  // counter this workgroup still owes a bump: its last A tile's stores are in flight (thread 0 only)
-	uint32_t flushing = kNone; // (MODE bit 0) ... its stores are acknowledged by the L2 and the write-back to memory is in flight
 	if (tid == 0) {
 		const uint32_t t0 = VKFFT_ATOMIC_ADD_U32(p.ctr + kFusedCtrTicket + 32u * q, 1u), s0 = t0 >> logTPC;
 		const uint32_t dA = depA(s0), dB = depB(s0);
@@ -172,7 +169,7 @@ pow2_fused_kernel(const FusedParams p) {
 			Cq = (p.C + Q - 1u - q) / Q;
 			totq = Cq ? (Cq + p.D) << logTPC : 0u;
 			if (tid == 0) {
-				fused_publish_all<MODE>(p.ctr, pending, flushing);
+				fused_publish(p.ctr, pending);
 				const uint32_t t0 = VKFFT_ATOMIC_ADD_U32(p.ctr + kFusedCtrTicket + 32u * q, 1u), s0 = t0 >> logTPC;
 				const uint32_t dA = depA(s0), dB = depB(s0);
 				sTicket[it] = t0;
@@ -288,7 +285,7 @@ pow2_fused_kernel(const FusedParams p) {
 			VKFFT_PROF(3);
 			if (tid == 0) {
 				(void)VKFFT_ATOMIC_ADD_U32(p.ctr + doneB + cB, 1u); // release the ring slot
-				fused_publish<MODE>(p.ctr, pending, flushing);
+				fused_publish(p.ctr, pending);
 			}
 			if (liveB) {
 				if constexpr ((MODE & 8) == 0) fused_stages<T, SB, TPFB, TCPB, TWL, CPT>(vB, lds + cBl, twB, p.lutB, oz, tauB);
@@ -321,7 +318,7 @@ pow2_fused_kernel(const FusedParams p) {
 	VKFFT_VMEM_DRAIN();
 	VKFFT_SYNC();
 	if (tid == 0) {
-		fused_publish_all<MODE>(p.ctr, pending, flushing);
+		fused_publish(p.ctr, pending);
 		VKFFT_VMEM_DRAIN(); // this workgroup's counter updates have been performed
 		sOkA[0] = VKFFT_ATOMIC_ADD_U32(p.ctr + kFusedCtrExit, 1u) == gridDim.x - 1u;
 	}

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
+#include <atomic>
 
 namespace vkfft_mi355x {
 
@@ -113,18 +114,25 @@ int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t st
 	if (pp.variant < 0 || pp.variant >= kNumPow2FusedVariants) return 4039;
 	const Pow2FusedVariant& v = kPow2FusedVariants[pp.variant];
 	// persistent grid: what the chip holds at once (the ticket queue needs no co-residency: any grid is correct)
-	static int occ[kNumPow2FusedVariants] = {};
-	if (!occ[pp.variant]) {
-		int n = 0;
+	// (cached per device and variant; racing first calls compute the same value, so a relaxed atomic is enough)
+	constexpr int kMaxDev = 32;
+	static std::atomic<int> occ[kMaxDev][kNumPow2FusedVariants];
+	int dev = 0, n = 0;
+#if !defined(VKFFT_HOSTEMU)
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+#endif
+	const bool cached = dev < kMaxDev;
+	if (cached) n = occ[dev][pp.variant].load(std::memory_order_relaxed);
+	if (!n) {
 #if defined(VKFFT_HOSTEMU)
 		n = 1;
 #else
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, v.fn, v.threads, 0) != hipSuccess || n < 1) n = 1;
 #endif
-		occ[pp.variant] = n;
+		if (cached) occ[dev][pp.variant].store(n, std::memory_order_relaxed);
 	}
 	const uint64_t tickets = (uint64_t)(prm.C + prm.D * prm.Q) << (prm.logG + prm.logTiles);
-	uint64_t grid = (uint64_t)pow2_num_cus() * (pp.fusedWgPerCu > 0 ? (uint32_t)pp.fusedWgPerCu : (uint32_t)occ[pp.variant]);
+	uint64_t grid = (uint64_t)pow2_num_cus() * (pp.fusedWgPerCu > 0 ? (uint32_t)pp.fusedWgPerCu : (uint32_t)n);
 	if (grid > tickets) grid = tickets;
 	if (grid == 0) return 0;
 #if !defined(VKFFT_HOSTEMU)

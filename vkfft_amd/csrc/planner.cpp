@@ -124,6 +124,7 @@ struct PassBuild {
 	bool allowFast = true;
 	bool allowOp = false;   // op-FFT family (kernel_opfft.h): fused pre/post map kernels
 	bool noCollapse = false;
+	uint32_t padInL = 0, padInN = 0, padOutL = 0, padOutN = 0; // zero padding along J (PassParams::padIn* / padOut*)
 	uint64_t maxLds = 160 * 1024;
 	// tables prepared by the caller (arena offsets)
 	size_t auxOff = (size_t)-1, aux2Off = (size_t)-1;
@@ -165,7 +166,8 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	}
 	// real transforms (fused pre/post map) and strided C2C of curated lengths: op-FFT family
 	const bool fusedBluestein = b.preOp == OP_BLUESTEIN_PRE && b.midOp == OP_BLUESTEIN_MID && b.postOp == OP_BLUESTEIN_POST && !b.colIn && b.auxOff2ForPre == (size_t)-1;
-	if (fusedBluestein && b.allowOp && b.fastKernel == KERNEL_GENERIC && (b.L & (b.L - 1)) == 0 && !b.forceT && b.radices.empty()) { // power-of-two padded length: register-resident persistent kernel
+	const bool padMask = b.padInN || b.padOutN; // (the interpreter, pow2_row / pow2_col and the op-FFT kernels honour the masks: Io64 / Io32 / explicit)
+	if (fusedBluestein && !padMask && b.allowOp && b.fastKernel == KERNEL_GENERIC && (b.L & (b.L - 1)) == 0 && !b.forceT && b.radices.empty()) { // power-of-two padded length: register-resident persistent kernel
 		int variant, bits[4], fpw, thr;
 		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
 		const uint64_t span = (b.L + 64 * (uint64_t)std::max<int64_t>(std::llabs(d0.inStride), std::llabs(d0.outStride))) * (b.dp ? 16 : 8);
@@ -177,7 +179,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	}
 	// ... and its column form for strided axes (tiles of neighbouring columns, one pass)
 	const bool fusedBluesteinCol = b.preOp == OP_BLUESTEIN_PRE && b.midOp == OP_BLUESTEIN_MID && b.postOp == OP_BLUESTEIN_POST && b.colIn && b.colOut && b.auxOff2ForPre == (size_t)-1;
-	if (fusedBluesteinCol && b.allowOp && b.fastKernel == KERNEL_GENERIC && (b.L & (b.L - 1)) == 0 && !b.forceT && b.radices.empty()) {
+	if (fusedBluesteinCol && !padMask && b.allowOp && b.fastKernel == KERNEL_GENERIC && (b.L & (b.L - 1)) == 0 && !b.forceT && b.radices.empty()) {
 		int variant, bits[4], tc, thr;
 		const uint64_t esz = b.dp ? 16 : 8;
 		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
@@ -191,7 +193,10 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	}
 	// (column tile in, per-column contiguous run out = the first Four-Step pass: the transposed-store variant)
 	const bool transOut = b.colIn && !b.colOut && b.preOp == OP_NONE && (b.postOp == OP_NONE || b.postOp == OP_TWIDDLE_4STEP) && b.outStrideJ == 1 && !b.realIn && !b.realOut;
-	if (b.allowOp && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && (b.colIn == b.colOut || transOut) && b.radices.empty()
+	// (op-FFT and zero padding: only the maps that go through Io32::ia / oa element by element — C2C columns, the R2C / C2R forms)
+	const bool opMaskOK = !padMask || ((b.preOp == OP_NONE || b.preOp == OP_C2R_EVEN_PRE || b.preOp == OP_R2C_FULL || b.preOp == OP_C2R_FULL) &&
+	                                 (b.postOp == OP_NONE || b.postOp == OP_R2C_EVEN_POST || b.postOp == OP_R2C_FULL || b.postOp == OP_C2R_FULL));
+	if (b.allowOp && opMaskOK && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && (b.colIn == b.colOut || transOut) && b.radices.empty()
 	    && !(b.preOp == OP_NONE && b.postOp == OP_NONE && !b.colIn)) {
 		const uint64_t ib = (b.realIn ? 1 : 2) * (b.dp ? 8 : 4), ob = (b.realOut ? 1 : 2) * (b.dp ? 8 : 4);
 		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
@@ -349,6 +354,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.fsColDiv = make_fastdiv(b.fsColDiv);
 	p.fsColFromDim1 = b.fsColFromDim1 ? 1 : 0;
 	p.scale = b.scale;
+	p.padInL = b.padInL; p.padInN = b.padInN; p.padOutL = b.padOutL; p.padOutN = b.padOutN;
 	p.divL = make_fastdiv((uint32_t)b.L);
 	p.divOutLen = make_fastdiv(p.outLen);
 	const uint64_t padded = p.padShift >= 31 ? b.L : b.L + (b.L >> p.padShift);
@@ -476,7 +482,9 @@ struct AxisJob {
 	double scale = 1.0;
 	int inRole = ROLE_BUFFER, outRole = ROLE_BUFFER;
 	int axisIndex = 0;
+	uint32_t padInL = 0, padInN = 0, padOutL = 0, padOutN = 0; // zero padding along this axis: elements not read / not written
 };
+constexpr int kPadUnsupported = -77; // (internal) no kernel of the plan this axis needs can skip the padded range: the caller falls back
 
 static uint32_t direct_max(const TransformDesc& d) { return (uint32_t)std::min<uint64_t>(d.raderMultMax, 61); }
 
@@ -856,6 +864,10 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax; b.allowFast = !d.disableFastKernels; b.allowOp = !d.disableFastKernels;
 	b.inRole = j.inRole; b.outRole = j.outRole;
 	out.axisSplit[j.axisIndex][0] = j.N;
+	// zero padding along this axis: served by the single-pass kernels that can skip elements (finish_pass); everything else reports kPadUnsupported
+	const bool padded = j.padInN || j.padOutN;
+	b.padInL = j.padInL; b.padInN = j.padInN; b.padOutL = j.padOutL; b.padOutN = j.padOutN;
+	if (padded && (!smoothOK || j.N > (unit ? rowCap : max_col_len(dp, d.maxLds, 1)))) return kPadUnsupported;
 
 	{ // a supported length that neither fits one pass nor splits into supported factors (large Rader primes) also goes to Bluestein
 		const uint64_t cap1 = unit ? rowCap : max_col_len(dp, d.maxLds, 1);
@@ -880,13 +892,13 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		int v, r5[5], f, t;
 		nativeInstance = unit ? mixed_row_lookup(j.N, dp, &v, r5, &f, &t) : opfft_lookup(j.N, dp, true, false, OP_NONE, OP_NONE, &v, r5, &f, &t);
 	}
-	if (unit && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && (!smooth13(j.N) || smoothNoInstance)) {
+	if (unit && !padded && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && (!smooth13(j.N) || smoothNoInstance)) {
 		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
 		uint64_t Mp = 64; while (Mp < 2 * j.N - 1) Mp *= 2; // measured: the power-of-two padded length wins even at 1.6x the {1,3,5}*2^k one
 		int v, bits[4], fpw, thr;
 		if ((rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && pow2_blue_lookup(ilog2(Mp), dp, &v, bits, &fpw, &thr)) fusedM = Mp;
 	}
-	if (!unit && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !j.others.empty()
+	if (!unit && !padded && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !j.others.empty()
 	    && j.others[0].inStride == 1 && j.others[0].outStride == 1) {
 		// strided axes of non-smooth length (prime x prime planes): the one-pass column Bluestein kernel on the power-of-two padded length beats
 		// the interpreter's Rader / Bluestein stages by 3-6x (measured on the reference's sample-7 systems)
@@ -894,7 +906,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		int v, bits[4], tc, thr;
 		if (pow2_col_blue_lookup(ilog2(Mp), dp, 5, &v, bits, &tc, &thr)) fusedM = Mp;
 	}
-	if (!unit && !fusedM && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !j.others.empty() && j.others.size() <= 3
+	if (!unit && !padded && !fusedM && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !j.others.empty() && j.others.size() <= 3
 	    && j.others[0].inStride == 1 && j.others[0].outStride == 1 && j.inStrideJ > 0 && j.outStrideJ > 0) {
 		// a strided axis of non-smooth length beyond the reach of the column Bluestein kernel (padded length above 2048): transpose it against its
 		// unit-stride companion into a dense scratch copy, run it there as unit-stride rows (the fused Bluestein row kernel) and transpose back.
@@ -1127,12 +1139,14 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		const bool p2 = (j.N & (j.N - 1)) == 0;
 		std::vector<uint64_t> probe;
 		if (!(p2 && pow2_col_lookup(ilog2(j.N), dp, &variant, bits, &tc, &thr)) && !opfft_lookup(j.N, dp, true, false, 0, 0, &variant, rad5, &fpw, &thr) &&
-		    choose_split(j.N, dp, d.maxLds, dmax, true, probe))
+		    choose_split(j.N, dp, d.maxLds, dmax, true, probe)) {
+			if (padded) return kPadUnsupported; // (two passes: no kernel of that plan skips elements)
 			singleCap = 2048;
+		}
 	}
 	if (j.N <= singleCap || (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N <= (dp ? 8192u : 16384u))) {
 		b.L = j.N;
-		if (unit && !d.disableFastKernels && (j.N & (j.N - 1)) != 0) { // curated non-power-of-two lengths: hand-specialised mixed-radix kernel
+		if (unit && !padded && !d.disableFastKernels && (j.N & (j.N - 1)) != 0) { // curated non-power-of-two lengths: hand-specialised mixed-radix kernel
 			int variant, rad5[5], fpw, thr;
 			uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
 			if ((rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && mixed_row_lookup(j.N, dp, &variant, rad5, &fpw, &thr)) {
@@ -1274,12 +1288,19 @@ static int plan_real_by_maps(const TransformDesc& d, const RealMapJob& m, Arena&
 // Here: even N -> one half-length complex FFT per row with the split fused as a post/pre operation of the
 // same kernel; odd N -> full-length complex FFT of the real row.
 static int plan_r2c_axis0_fused(const TransformDesc& d, bool inverse, const std::vector<HostDim>& othersReal, const std::vector<HostDim>& othersCplx,
-                                int realRole, int cplxRole, double scale, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes);
+                                int realRole, int cplxRole, double scale, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes, bool usePad);
 static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vector<HostDim>& othersReal, const std::vector<HostDim>& othersCplx,
                           int realRole, int cplxRole, double scale, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
 	const size_t mark = passes.size();
-	const int r = plan_r2c_axis0_fused(d, inverse, othersReal, othersCplx, realRole, cplxRole, scale, ar, out, passes);
+	const bool padded = d.padR[0] > d.padL[0];
+	int r = plan_r2c_axis0_fused(d, inverse, othersReal, othersCplx, realRole, cplxRole, scale, ar, out, passes, padded);
+	if (r == kPadUnsupported) { // the range is zeroed ahead of the transform instead (api.cpp)
+		passes.resize(mark);
+		out.padFallbackMask |= 1u;
+		r = plan_r2c_axis0_fused(d, inverse, othersReal, othersCplx, realRole, cplxRole, scale, ar, out, passes, false);
+	}
 	if (r != 3003) return r;
+	if (padded) out.padFallbackMask |= 1u;
 	// no fused form (a row length that needs Bluestein beyond the fused kernels' reach): full-length "callback" form (vkFFT_R2C.h:27) as separate map passes
 	passes.resize(mark);
 	const uint64_t N = d.size[0];
@@ -1298,11 +1319,15 @@ static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vecto
 	return r2 == 3002 ? 3003 : r2;
 }
 static int plan_r2c_axis0_fused(const TransformDesc& d, bool inverse, const std::vector<HostDim>& othersReal, const std::vector<HostDim>& othersCplx,
-                                int realRole, int cplxRole, double scale, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
+                                int realRole, int cplxRole, double scale, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes, bool usePad) {
 	const uint64_t N = d.size[0];
 	const bool dp = d.dp;
 	const size_t es = dp ? 16 : 8;
 	const uint32_t dmax = direct_max(d);
+	// zero padding of the real rows (spatial padding: read side of R2C, write side of C2R), in real elements; only the single-pass forms skip elements
+	const bool padReal = usePad && !d.padFrequency;
+	if (usePad && !padReal) return kPadUnsupported; // (padding of the half spectrum along axis 0)
+	const uint32_t padL = padReal ? (uint32_t)d.padL[0] : 0u, padN = padReal ? (uint32_t)(d.padR[0] - d.padL[0]) : 0u;
 	PassBuild b;
 	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax; b.allowFast = false; b.allowOp = !d.disableFastKernels;
 	b.opN = (uint32_t)N; b.scale = scale;
@@ -1310,6 +1335,7 @@ static int plan_r2c_axis0_fused(const TransformDesc& d, bool inverse, const std:
 	b.L = even ? N / 2 : N;
 	uint64_t blueM = 0; // padded length of the Bluestein-wrapped full-length form (kernel_blue_r2r.h), 0: not used
 	int blueVariant = 0, blueBits[4] = {0, 0, 0, 0}, blueFpw = 0, blueThr = 0;
+	if (padReal && (!is_supported_len(b.L, dmax) || b.L > max_row_len(dp, d.maxLds))) return kPadUnsupported;
 	if (!is_supported_len(b.L, dmax)) {
 		// the (half) length has a prime factor outside the radix / Rader stages: full-length "callback" form (real -> (x, 0),
 		// keep the first N/2+1 outputs; vkFFT_R2C.h:27) around a fused Bluestein transform of length N
@@ -1407,6 +1433,11 @@ static int plan_r2c_axis0_fused(const TransformDesc& d, bool inverse, const std:
 	}
 	b.dims = dims;
 	b.inStrideJ = b.outStrideJ = 1;
+	if (padN) { // the even forms move the reals as packed pairs: an odd boundary would cut a pair
+		if (even && ((padL | padN) & 1u)) return kPadUnsupported;
+		const uint32_t pl = even ? padL / 2 : padL, pn = even ? padN / 2 : padN;
+		if (!inverse) { b.padInL = pl; b.padInN = pn; } else { b.padOutL = pl; b.padOutN = pn; }
+	}
 	if (even) {
 		size_t aux = ar.alloc((N / 2 + 1) * es);
 		for (uint64_t k = 0; k <= N / 2; k++) ar.putc(aux, k, unit_root(k, N), dp);
@@ -1659,6 +1690,30 @@ int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
 		}
 	}
 
+	// ---- zero padding (reference: vkFFT_Plan_FFT.h:522-560, vkFFT_Zeropad.h).  Along the padded axis itself the pass skips the range on its read side
+	// (forward transform of a spatially padded system, inverse of a frequency-padded one) or on its write side (the other direction).  Sequences that
+	// lie entirely inside the padded range of ANOTHER axis that is still to come (spatial: axes above this one; frequency: below) are not visited
+	// at all — a tail range [left, size) simply shortens the enumeration of that axis.
+	auto axisPadded = [&](int a) { return d.padR[a] > d.padL[a]; };
+	auto applyPad = [&](int a, AxisJob& j) {
+		if (!axisPadded(a)) return;
+		const uint32_t L = (uint32_t)d.padL[a], N = (uint32_t)(d.padR[a] - d.padL[a]);
+		if (d.inverse == d.padFrequency) { j.padInL = L; j.padInN = N; } else { j.padOutL = L; j.padOutN = N; }
+	};
+	auto rowsOf = [&](int a, int o, uint64_t count) -> uint64_t {
+		if (!axisPadded(o) || d.padR[o] != d.size[o]) return count;
+		return (d.padFrequency ? o < a : o > a) ? d.padL[o] : count;
+	};
+	auto plan_c2c_padded = [&](AxisJob& j) -> int {
+		int r = plan_c2c_axis(d, j, ar, out, out.passes);
+		if (r == kPadUnsupported) { // (a plan of several passes, Bluestein, ...): the range is zeroed ahead of the transform instead (api.cpp)
+			out.padFallbackMask |= 1u << j.axisIndex;
+			j.padInL = j.padInN = j.padOutL = j.padOutN = 0;
+			r = plan_c2c_axis(d, j, ar, out, out.passes);
+		}
+		return r;
+	};
+
 	if (d.kind == 0) {
 		for (size_t oi = 0; oi < order.size(); oi++) {
 			const int a = order[oi];
@@ -1677,13 +1732,14 @@ int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
 			j.scale = (oi + 1 == order.size()) ? scale : 1.0;
 			// other dims, unit-stride axis 0 first (tiled for strided axes); for axis 0 the next axis comes first
 			for (int o = 0; o < nd; o++) if (o != a) {
-				HostDim h; h.count = d.size[o];
+				HostDim h; h.count = rowsOf(a, o, d.size[o]);
 				h.inStride = o == 0 ? 1 : (int64_t)is[o - 1];
 				h.outStride = o == 0 ? 1 : (int64_t)os[o - 1];
 				j.others.push_back(h);
 			}
 			j.others.push_back({d.batch, (int64_t)is[nd - 1], (int64_t)os[nd - 1]});
-			int r = plan_c2c_axis(d, j, ar, out, out.passes);
+			applyPad(a, j);
+			int r = plan_c2c_padded(j);
 			if (r) return r;
 		}
 	} else if (d.kind == 1) {
@@ -1695,7 +1751,7 @@ int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
 		for (int i = 0; i < 5; i++) rStr[i] = realSeparate ? d.inStride[i] : 2 * d.bufStride[i];
 		const uint64_t W = d.size[0] / 2 + 1; // complex row width
 		std::vector<HostDim> oReal, oCplx;
-		for (int o = 1; o < nd; o++) { oReal.push_back({d.size[o], (int64_t)rStr[o - 1], (int64_t)rStr[o - 1]}); oCplx.push_back({d.size[o], (int64_t)d.bufStride[o - 1], (int64_t)d.bufStride[o - 1]}); }
+		for (int o = 1; o < nd; o++) { const uint64_t cnt = rowsOf(0, o, d.size[o]); oReal.push_back({cnt, (int64_t)rStr[o - 1], (int64_t)rStr[o - 1]}); oCplx.push_back({cnt, (int64_t)d.bufStride[o - 1], (int64_t)d.bufStride[o - 1]}); }
 		oReal.push_back({d.batch, (int64_t)rStr[nd - 1], (int64_t)rStr[nd - 1]});
 		oCplx.push_back({d.batch, (int64_t)d.bufStride[nd - 1], (int64_t)d.bufStride[nd - 1]});
 		auto complexAxes = [&](bool inv) -> int {
@@ -1707,12 +1763,13 @@ int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
 				j.inStrideJ = j.outStrideJ = (int64_t)d.bufStride[a - 1];
 				j.scale = 1.0;
 				for (int o = 0; o < nd; o++) if (o != a) {
-					HostDim h; h.count = o == 0 ? W : d.size[o];
+					HostDim h; h.count = o == 0 ? W : rowsOf(a, o, d.size[o]);
 					h.inStride = h.outStride = o == 0 ? 1 : (int64_t)d.bufStride[o - 1];
 					j.others.push_back(h);
 				}
 				j.others.push_back({d.batch, (int64_t)d.bufStride[nd - 1], (int64_t)d.bufStride[nd - 1]});
-				int r = plan_c2c_axis(d, j, ar, out, out.passes);
+				applyPad(a, j);
+				int r = plan_c2c_padded(j);
 				if (r) return r;
 			}
 			return 0;
@@ -1739,8 +1796,9 @@ int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
 			else if (before) { inRole = outRole = srcRole; is = os = sStr; }
 			else { inRole = outRole = dstRole; is = os = dStr; }
 			std::vector<HostDim> others;
-			for (int o = 0; o < nd; o++) if (o != a) others.push_back({d.size[o], o == 0 ? 1 : (int64_t)is[o - 1], o == 0 ? 1 : (int64_t)os[o - 1]});
+			for (int o = 0; o < nd; o++) if (o != a) others.push_back({rowsOf(a, o, d.size[o]), o == 0 ? 1 : (int64_t)is[o - 1], o == 0 ? 1 : (int64_t)os[o - 1]});
 			others.push_back({d.batch, (int64_t)is[nd - 1], (int64_t)os[nd - 1]});
+			if (axisPadded(a)) out.padFallbackMask |= 1u << a; // (the real transforms' maps do not skip elements: the range is zeroed ahead of the transform)
 			int r = plan_r2r_axis(d, type, dst, d.size[a], a == 0 ? 1 : (int64_t)is[a - 1], a == 0 ? 1 : (int64_t)os[a - 1], others, inRole, outRole,
 			                      (oi + 1 == order.size()) ? scale : 1.0, a, ar, out, out.passes);
 			if (r) return r;
