@@ -9,12 +9,17 @@ OBJS := build/obj/api.o build/obj/planner.o build/obj/kernels.o build/obj/kernel
 FUSED_HDRS := $(CSRC)/kernel_pow2_fused.h $(CSRC)/kernel_pow2_fused2.h
 HDRS := $(filter-out $(FUSED_HDRS),$(wildcard $(CSRC)/*.h)) include/vkFFT.h
 
-all: $(LIBDIR)/libvkfft_mi355x.so build/vkfft_mi355x_cli
+all: $(LIBDIR)/libvkfft_mi355x.so build/vkfft_mi355x_cli build/vkfft_mi355x_multi
 
 # caller-side benchmark driver (flag-compatible in spirit with the reference's VkFFT_TestSuite): links the C-ABI only
 build/vkfft_mi355x_cli: tools/vkfft_cli.cpp include/vkFFT.h $(LIBDIR)/libvkfft_mi355x.so
 	@mkdir -p build
 	$(HIPCC) -O2 -std=c++17 -Wno-unused-value -Wno-unused-result -Iinclude tools/vkfft_cli.cpp -L$(LIBDIR) -lvkfft_mi355x -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -o $@
+
+# multi-GPU host drivers (one thread per GPU; batch sharding, slab 3D over RCCL or device-to-device copies): links the C-ABI and librccl
+build/vkfft_mi355x_multi: tools/vkfft_multi.cpp include/vkFFT.h $(LIBDIR)/libvkfft_mi355x.so
+	@mkdir -p build
+	$(HIPCC) -O2 -std=c++17 -pthread -Wno-unused-value -Wno-unused-result -Iinclude tools/vkfft_multi.cpp -L$(LIBDIR) -lvkfft_mi355x -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib -o $@
 
 build/obj/%.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p build/obj

@@ -681,6 +681,76 @@ def test_multi_gpu_drivers_on_one_device(product_lib):
     assert torch.equal(part, whole[shard.lo:shard.hi])
 
 
+def test_multi_gpu_cxx_drivers_with_virtual_ranks(product_lib):
+    """The C++ host drivers (tools/vkfft_multi.cpp: one host thread per rank above the C-ABI).  On a one-GPU box the ranks are "virtual": they share
+    device 0 and the slab exchange runs over device-to-device copies — the same plans, layouts, packing and thread choreography as with RCCL over
+    xGMI.  The slab result is compared with the single-device 3D plan of the library; the batch driver runs two ranks side by side."""
+    import json, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", root, "build/vkfft_mi355x_multi"])
+    exe = os.path.join(root, "build", "vkfft_mi355x_multi")
+    for ranks, n in ((1, 64), (2, 64), (4, 96)):
+        out = subprocess.run([exe, "-slab3d", "-n", str(n), "-g", str(ranks), "-virtual", "-transport", "copy", "-verify", "-reps", "2"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+        assert rec["ranks"] == ranks and rec["rel_l2_vs_single_device_plan"] < 2e-6, rec
+    out = subprocess.run([exe, "-batch", "-X", "65536", "-B", "256", "-g", "2", "-virtual", "-pairs", "5"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["gpus"] == 2 and rec["GFLOPs_all_gpus"] > 100.0 and rec["collectives"] == "none", rec
+
+
+def _nccl_slab_worker(rank, world, port, q):
+    import os
+    import torch, torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        from vkfft_amd.distributed import SlabFFT3D
+        nx, ny, nz = 64, 48, 32
+        g = torch.Generator(device="cpu"); g.manual_seed(11)
+        full = torch.view_as_complex(torch.empty(nz, ny, nx, 2, dtype=torch.float32).uniform_(-1, 1, generator=g))
+        ref = torch.fft.fftn(full.to(torch.complex128), dim=(0, 1, 2))
+        nzl, nyl = nz // world, ny // world
+        errs = []
+        for groups in (1, 2):
+            plan = SlabFFT3D(nx, ny, nz, device_index=rank, groups=groups)
+            x = full[rank * nzl:(rank + 1) * nzl].contiguous().cuda()
+            y = plan.forward(x)
+            torch.cuda.synchronize()
+            want = ref[:, rank * nyl:(rank + 1) * nyl, :]
+            errs.append((torch.linalg.norm(y.cpu().to(torch.complex128) - want) / torch.linalg.norm(want)).item())
+            z = plan.inverse(y)
+            torch.cuda.synchronize()
+            back = full[rank * nzl:(rank + 1) * nzl].to(torch.complex128) * (nx * ny * nz)
+            errs.append((torch.linalg.norm(z.cpu().to(torch.complex128) - back) / torch.linalg.norm(back)).item())
+            plan.delete()
+        q.put((rank, errs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slab_3d_over_rccl_two_ranks():
+    """SlabFFT3D on its real transport: two processes, two GPUs, RCCL grouped sends ordered against the compute stream.  Skipped on a one-GPU box
+    (there the same code runs with gloo on CPU, tests/test_distributed_gloo.py, and with one rank on the device)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_slab_worker, args=(r, 2, 29613, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for _ in range(2):
+        rank, errs = q.get(timeout=10)
+        assert max(errs) < 4e-6, (rank, errs)
+
+
 @pytest.mark.parametrize("N,B", [(1 << 10, 256), (1 << 16, 64), (3 * 5 * 7 * 11, 32), (1009, 16)])
 def test_append_can_be_captured_in_a_hip_graph(product_lib, N, B):
     """VkFFTAppend only enqueues kernels on the caller's stream (no allocation, no synchronisation, no host-side state that depends on the

@@ -61,6 +61,8 @@ class SlabFFT3D:
 
     forward(x): x = local z-slab, torch complex tensor [nz/P, ny, nx] (contiguous; overwritten)  ->  y-slab [nz, ny/P, nx]
     inverse(y): y-slab (overwritten) -> z-slab; unnormalised unless normalize=True.
+    The exchange buffers (2 x the slab) and the inverse's output slab belong to the plan and are allocated once: a result is a view of them and
+    stays valid until the next call of the same direction.
     `groups`: number of plane groups the exchange is pipelined over (must divide nz/P)."""
 
     def __init__(self, nx, ny, nz, group=None, *, dp=False, device_index=0, lib=None, normalize=False, groups=None):
@@ -100,6 +102,16 @@ class SlabFFT3D:
         # z transform: 1-D along the slowest axis of [nz][nyl][nx]
         self.fz = api.App([nx, nyl, nz], 1, dp=dp, device_index=device_index, lib=lib, stream=stream, omitDimension=[1, 1, 0, 0], normalize=int(normalize))
         self.es = 16 if dp else 8
+        self._bufs = None
+
+    def _buffers(self, like):
+        """send / receive layouts [P, nzl, nyl, nx] and the inverse's z-slab [nzl, ny, nx]: allocated on first use, then reused"""
+        if self._bufs is None or self._bufs[0].dtype != like.dtype or self._bufs[0].device != like.device:
+            t = self.torch
+            self._bufs = (t.empty((self.P, self.nzl, self.nyl, self.nx), dtype=like.dtype, device=like.device),
+                          t.empty((self.P, self.nzl, self.nyl, self.nx), dtype=like.dtype, device=like.device),
+                          t.empty((self.nzl, self.ny, self.nx), dtype=like.dtype, device=like.device))
+        return self._bufs
 
     # ---- exchange of one plane group: P-1 contiguous runs each way, one grouped point-to-point call ----
     def _exchange(self, send, recv, g):
@@ -120,8 +132,7 @@ class SlabFFT3D:
         torch = self.torch
         P, nzl, nyl, nx, ny, zg = self.P, self.nzl, self.nyl, self.nx, self.ny, self.zg
         assert tuple(x.shape) == (nzl, ny, nx) and x.is_contiguous()
-        send = torch.empty((P, nzl, nyl, nx), dtype=x.dtype, device=x.device)
-        recv = torch.empty((P, nzl, nyl, nx), dtype=x.dtype, device=x.device)
+        send, recv, _ = self._buffers(x)
         caller = torch.cuda.current_stream() if self.cuda else None
         if self.cuda:
             self.compute.wait_stream(caller)  # x, send and recv are ready for the compute stream
@@ -151,8 +162,8 @@ class SlabFFT3D:
         P, nzl, nyl, nx, ny, zg = self.P, self.nzl, self.nyl, self.nx, self.ny, self.zg
         assert tuple(y.shape) == (self.nz, nyl, nx) and y.is_contiguous()
         caller = torch.cuda.current_stream() if self.cuda else None
-        x = torch.empty((nzl, ny, nx), dtype=y.dtype, device=y.device)
-        recv = torch.empty((P, nzl, nyl, nx), dtype=y.dtype, device=y.device)
+        a, b, x = self._buffers(y)
+        recv = a if y.data_ptr() != a.data_ptr() else b  # (forward returns a view of b: the inverse then receives into a)
         if self.cuda:
             self.compute.wait_stream(caller)
         self.fz.inverse(buffer_ptr=y.data_ptr())
