@@ -152,6 +152,20 @@ CONV_CASES = [
     dict(shape=(128,), m=2, conjugate=2, dp=True),
     dict(shape=(60,), m=1, cf=2, cross=True),
     dict(shape=(24, 20), m=3, symmetric=True, nk=3, dp=True),
+    # a strided power-of-two last axis of 64 .. 1024 points: the merged pass (last axis forward, kernel product, last axis backwards in one kernel)
+    dict(shape=(32, 64), m=1, cf=2, nb=3),
+    dict(shape=(16, 128), m=3, seed=5),
+    dict(shape=(48, 64), m=3, symmetric=True),
+    dict(shape=(64, 64), m=2, r2c=True, nb=2),
+    dict(shape=(8, 6, 64), m=2, conjugate=1),
+    dict(shape=(40, 256), m=2, conjugate=2, dp=True),
+    dict(shape=(20, 1024), m=1, cf=3),
+    # longer last axes: forward first pass, merged pass on the inner factor, first pass backwards (three passes instead of five)
+    dict(shape=(12, 4096), m=1, cf=2, nb=2),
+    dict(shape=(16, 8192), m=2, seed=2),
+    dict(shape=(6, 5, 2048), m=3),
+    dict(shape=(32, 2048), m=1, r2c=True),
+    dict(shape=(24, 1024), m=3, dp=True),
 ]
 ZEROPAD_CASES = [
     dict(shape=(64,), pads={0: (32, 64)}),
@@ -220,6 +234,8 @@ CONV_ZEROPAD_CASES = [
     dict(shape=(32, 32, 32), pads={0: (16, 32), 1: (16, 32), 2: (16, 32)}, m=3, r2c=True),   # the reference's sample 51
     dict(shape=(64, 48), pads={0: (32, 64), 1: (24, 48)}, m=2),
     dict(shape=(128,), pads={0: (64, 128)}, m=1, dp=True),
+    dict(shape=(32, 64), pads={0: (16, 32), 1: (32, 64)}, m=2),                                # merged last axis with both masks
+    dict(shape=(32, 16, 64), pads={0: (16, 32), 1: (8, 16), 2: (32, 64)}, m=3, r2c=True),
 ]
 
 

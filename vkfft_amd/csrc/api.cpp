@@ -29,6 +29,8 @@ struct AppState {
 	// results are the same
 	VkFFTApplication* convFwd = nullptr;
 	VkFFTApplication* convInv = nullptr;
+	VkFFTPlan* convMid = nullptr;  // merged form (strided power-of-two last axis): ONE pass does that axis forward, the kernel product and the axis backwards;
+	                               // convFwd / convInv then omit the axis (planner.cpp build_conv_axis_plan)
 	uint32_t zeroPadMask = 0;      // zero-padded axes whose plan cannot skip the range: it is written with zeros ahead of the transform that reads it
 };
 
@@ -116,6 +118,7 @@ VKFFT_API void deleteVkFFT(VkFFTApplication* app) {
 		if (st->tempOwned) (void)hipFree(st->tempOwned);
 		if (st->convFwd) { deleteVkFFT(st->convFwd); free(st->convFwd); }
 		if (st->convInv) { deleteVkFFT(st->convInv); free(st->convInv); }
+		free_direction(st->convMid);
 		if (app->saveApplicationString) free(app->saveApplicationString);
 		if (st->events) {
 			for (uint32_t i = 0; i < st->numEvents; i++) if (st->events[i]) (void)hipEventDestroy(st->events[i]);
@@ -487,6 +490,37 @@ VkFFTResult initialize_convolution(VkFFTApplication* app, const VkFFTConfigurati
 	b.numberBatches = nb * nk;
 	b.isInputFormatted = 0; b.inverseReturnToInputBuffer = 0; b.inputBuffer = nullptr; b.inputBufferSize = nullptr;
 	if (nk > 1 && in.bufferSize) b.bufferSize = in.bufferSize;
+	// merged last axis (the reference's convolution-merged kernel, vkFFT_Convolution.h:125): when a one-pass merged kernel exists for that axis
+	// the two sub-applications omit it
+	if (in.FFTdim >= 2 && nk == 1 && !in.crossPowerSpectrumNormalization && !in.frequencyZeroPadding && !in.isInputFormatted && !getenv("VKFFT_MI355X_CONV_SEPARATE")) {
+		TransformDesc d;
+		d.fftDim = (int)in.FFTdim;
+		for (int i = 0; i < 4; i++) d.size[i] = in.size[i] ? in.size[i] : 1;
+		d.batch = nb; d.dp = in.doublePrecision != 0; d.kind = in.performR2C ? 1 : 0;
+		{ // default strides of the in-place layout (as the plain path derives them)
+			uint64_t run = in.performR2C ? d.size[0] / 2 + 1 : d.size[0];
+			for (int i = 0; i < 4; i++) { d.bufStride[i] = in.bufferStride[i] ? in.bufferStride[i] : run; if (i + 1 < (int)in.FFTdim) run = d.bufStride[i] * d.size[i + 1]; }
+		}
+		for (pfUINT i = 0; i < in.FFTdim && i < 4; i++) if (in.performZeropadding[i] && in.fft_zeropad_right[i] > in.fft_zeropad_left[i]) { d.padL[i] = in.fft_zeropad_left[i]; d.padR[i] = in.fft_zeropad_right[i]; }
+		if (const char* e = getenv("VKFFT_MI355X_GENERIC_ONLY")) d.disableFastKernels = atoi(e) != 0;
+		if (in.sharedMemorySize && in.sharedMemorySize < 160 * 1024) d.disableFastKernels = true;
+		ConvAxisDesc cd;
+		cd.matrix = (uint32_t)m; cd.coordinates = (uint32_t)c.coordinateFeatures; cd.symmetric = in.symmetricKernel ? 1u : 0u; cd.conjugate = (uint32_t)in.conjugateConvolution;
+		cd.kernelSystems = m > 1 ? (in.symmetricKernel ? m * (m + 1) / 2 : m * m) : c.coordinateFeatures;
+		cd.scale = in.normalize ? 1.0 / (double)d.size[in.FFTdim - 1] : 1.0;
+		VkFFTPlan* pl = (VkFFTPlan*)calloc(1, sizeof(VkFFTPlan));
+		DirectionPlan* dpl = new (std::nothrow) DirectionPlan();
+		if (pl && dpl) {
+			pl->impl = dpl;
+			if (build_conv_axis_plan(d, cd, *dpl) == 0 && !dpl->arena.empty() && hipMalloc(&dpl->dArena, dpl->arena.size()) == hipSuccess &&
+			    hipMemcpy(dpl->dArena, dpl->arena.data(), dpl->arena.size(), hipMemcpyHostToDevice) == hipSuccess &&
+			    (dpl->totalTemp() == 0 || in.userTempBuffer || (hipMalloc(&st->tempOwned, dpl->totalTemp()) == hipSuccess && (st->tempOwnedBytes = dpl->totalTemp(), true)))) {
+				st->convMid = pl;
+				f.omitDimension[in.FFTdim - 1] = 1; b.omitDimension[in.FFTdim - 1] = 1;
+				if (in.printMemoryLayout || getenv("VKFFT_MI355X_PRINT_PLAN")) fprintf(stderr, "[vkfft_mi355x] convolution: axis %d merged (forward, %ux%u kernel product, inverse in one pass of pow2_col_blue_kernel)\n", (int)in.FFTdim - 1, cd.matrix, cd.matrix);
+			} else free_direction(pl);
+		} else { free(pl); delete dpl; }
+	}
 	st->convFwd = (VkFFTApplication*)calloc(1, sizeof(VkFFTApplication));
 	st->convInv = (VkFFTApplication*)calloc(1, sizeof(VkFFTApplication));
 	if (!st->convFwd || !st->convInv) { deleteVkFFT(app); return VKFFT_ERROR_MALLOC_FAILED; }
@@ -513,6 +547,19 @@ VkFFTResult append_convolution(VkFFTApplication* app, int inverse, VkFFTLaunchPa
 	if (c.buffer == nullptr || c.buffer[0] == nullptr) return VKFFT_ERROR_EMPTY_buffer;
 	VkFFTResult r = VkFFTAppend(st->convFwd, -1, lp);
 	if (r != VKFFT_SUCCESS) return r;
+	if (st->convMid) { // last axis forward, kernel product, last axis backwards: one pass
+		LaunchBuffers lb;
+		lb.base[ROLE_BUFFER] = (char*)c.buffer[0] + c.bufferOffset;
+		lb.kernel = (const char*)c.kernel[0] + c.kernelOffset;
+		if (((DirectionPlan*)st->convMid->impl)->totalTemp()) {
+			if (c.userTempBuffer) { if (c.tempBuffer == nullptr || c.tempBuffer[0] == nullptr) return VKFFT_ERROR_EMPTY_tempBuffer; lb.base[ROLE_TEMP] = (char*)c.tempBuffer[0] + c.tempBufferOffset; }
+			else lb.base[ROLE_TEMP] = st->tempOwned;
+		}
+		StreamSet ss;
+		if (c.stream && c.num_streams >= 1) ss.s[0] = c.stream[0];
+		if (execute_direction(*(DirectionPlan*)st->convMid->impl, lb, ss, nullptr)) return VKFFT_ERROR_FAILED_TO_LAUNCH_KERNEL;
+		return VkFFTAppend(st->convInv, 1, lp ? &inv : nullptr);
+	}
 	ConvParams p;
 	p.data = (char*)c.buffer[0] + c.bufferOffset;
 	p.kernel = (const char*)c.kernel[0] + c.kernelOffset;

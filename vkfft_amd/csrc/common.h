@@ -164,7 +164,24 @@ struct PassParams {
 	// zero padding (VkFFTConfiguration::performZeropadding, vkFFT_Zeropad.h:28): elements [padInL, padInL + padInN) of every sub-FFT are taken as zero and NOT
 	// read; elements [padOutL, padOutL + padOutN) of its output are NOT written.  Units: elements of the respective side; N = 0: off
 	uint32_t padInL, padInN, padOutL, padOutN;
+	// merged convolution along this axis (pow2_col_blue_kernel MODE 6; reference vkFFT_Convolution.h:125): convCf coordinate systems convSysStride elements
+	// apart are transformed, multiplied per frequency by the convM x convM kernel matrix (convM <= 1: every coordinate by its own kernel component) and
+	// transformed back.  aux2 = kernel spectra (same layout as one system, convSysStride apart); convKerStride1/2 = kernel strides of dim[1] / dim[2]
+	// (0 for a batch dimension, which the kernel does not follow)
+	uint32_t convM, convCf, convSymmetric, convConj;
+	int64_t convSysStride, convKerStride1, convKerStride2;
+	int64_t convKerStrideJ, convKerSysStride; // kernel strides along the axis and between kernel systems (they differ from the data's when the data sits in the Four-Step scratch)
 };
+
+// index of kernel component (j, l) among the systems of one convolution kernel.  symmetricKernel: the packed upper triangle in the DOCUMENTED order
+// xx, xy, xz, yy, yz, zz (API guide, "symmetricKernel"): row a <= b starts after a*m - a*(a-1)/2 entries.  The reference's generated code uses
+// a*m - a*a + b (vkFFT_Convolution.h:352-358), which is the same for m = 2 but collides for m = 3 ((1,2) and (2,2) both give 4, slot 5 is never read);
+// this library follows the documented layout
+__host__ __device__ inline uint32_t conv_kernel_index(uint32_t j, uint32_t l, uint32_t m, bool symmetric) {
+	if (!symmetric) return j * m + l;
+	const uint32_t a = l < j ? l : j, b = l < j ? j : l;
+	return a * m - a * (a - 1u) / 2u - a + b;
+}
 
 // ---- fused Four-Step launch (kernel_pow2_fused.h): both passes of a two-factor transform in one persistent kernel ----
 constexpr uint32_t kFusedCtrTicket = 0, kFusedCtrExit = 256, kFusedCtrDone = 320; // uint32 indices into FusedParams::ctr (ticket counter of queue q at 32*q)

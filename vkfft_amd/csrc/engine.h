@@ -37,6 +37,7 @@ struct PassPlan {
 	FusedParams fused = {};
 	size_t fusedLutBOff = (size_t)-1, fusedCtrOff = (size_t)-1;
 	int fusedWgPerCu = 0; // 0: what the occupancy query reports
+	bool auxIsKernel = false; // merged convolution pass: aux2 is bound to the caller's kernel buffer at launch (LaunchBuffers::kernel)
 	std::string label;
 };
 
@@ -90,9 +91,16 @@ struct TransformDesc {
 // returns 0 or a VkFFTResult code
 int build_direction_plan(const TransformDesc& d, DirectionPlan& out);
 
+// Merged convolution along the LAST axis of `d` (a strided, power-of-two axis of 64 .. 1024 points): one pass = forward transform of every coordinate
+// system, kernel matrix product per frequency, inverse transform (pow2_col_blue_kernel MODE 6; reference vkFFT_Convolution.h:125, vkFFT_RunApp.h:235-345).
+// d.batch = numberBatches (NOT folded with the coordinates); returns 3002 when no such pass exists for the shape (the caller keeps separate passes)
+struct ConvAxisDesc { uint32_t matrix = 1, coordinates = 1, symmetric = 0, conjugate = 0; double scale = 1.0; uint64_t kernelSystems = 1; };
+int build_conv_axis_plan(const TransformDesc& d, const ConvAxisDesc& c, DirectionPlan& out);
+
 // launchers (kernels.hip)
 struct LaunchBuffers {
 	void* base[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // by BufRole
+	const void* kernel = nullptr; // convolution kernel spectra (merged convolution pass)
 };
 int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 // The caller's streams (VkFFTConfiguration::stream / num_streams).  Everything is ordered on s[0]; a pass that the host has to split

@@ -364,6 +364,82 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 			if (sc != (T)1) y = cscale(y, sc);
 			gb_store<T>(gout, pos < n ? laneOut : kGbInvalid, m * stepOut, y);
 		}
+	} else if constexpr (MODE == 6 || MODE == 7) { // (7: the narrow-tile instance of 1024 points whose 512 threads have the registers for a kernel matrix)
+		// Merged convolution along this (strided) axis — the reference's convolution-merged last axis (vkFFT_Convolution.h:125-447, vkFFT_RunApp.h:235-345):
+		// column FFT of every coordinate system -> per frequency the kernel matrix times the vector of coordinates -> inverse column FFT of every
+		// result (swap identity), in place.  One trip through memory instead of three (last forward pass, element-wise product, first inverse pass).
+		constexpr int MAXM = 3;
+		const uint32_t mm = p.convM, cf = p.convCf;
+		const uint32_t lane = valid ? (tau * (uint32_t)p.inStrideJ + c * (uint32_t)p.dim[0].inStride) * ES : kGbInvalid;
+		const uint32_t step = (uint32_t)(TPF * (uint32_t)p.inStrideJ) * ES;
+		const GBuf gker = make_gbuf((const cx<T>*)p.aux2 + ((int64_t)g1 * p.convKerStride1 + (int64_t)g2 * p.convKerStride2 + (int64_t)col0));
+		const uint32_t klane = valid ? (tau * (uint32_t)p.convKerStrideJ + c) * ES : kGbInvalid, kstep = (uint32_t)(TPF * (uint32_t)p.convKerStrideJ) * ES; // (unit stride along the tile)
+		cx<T> w[MAXM][E];
+#pragma unroll
+		for (int l = 0; l < MAXM; l++) {
+			if ((uint32_t)l < cf) {
+				const GBuf gl = make_gbuf((const cx<T>*)p.in + (inB + (int64_t)l * p.convSysStride));
+#pragma unroll
+				for (int m = 0; m < E; m++) w[l][m] = gb_load<T>(gl, (tau + (uint32_t)(m * TPF) - p.padInL < p.padInN) ? kGbInvalid : lane, m * step);
+				if constexpr (SCH::NS > 1) { if (l > 0) VKFFT_SYNC(); } // the exchange buffer is reused
+				pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(w[l], lds + c, TwGlobal<T>{glut}, tau, false);
+				if (p.convConj == 1) {
+#pragma unroll
+					for (int m = 0; m < E; m++) w[l][m] = cconj(w[l][m]);
+				}
+			}
+		}
+		const bool kconj = p.convConj == 2;
+#pragma unroll
+		for (int j = 0; j < MAXM; j++) {
+			if ((uint32_t)j < cf) {
+				cx<T> acc[E];
+				if (mm <= 1) {
+					const uint32_t ks = (uint32_t)((int64_t)j * p.convKerSysStride) * ES; // (the kernel systems lie within the 2 GiB span of the resource: planner)
+#pragma unroll
+					for (int m = 0; m < E; m++) { cx<T> k = gb_load<T>(gker, klane, m * kstep + ks); if (kconj) k = cconj(k); acc[m] = cmul(k, w[j][m]); }
+				} else {
+#pragma unroll
+					for (int m = 0; m < E; m++) acc[m] = cx<T>{(T)0, (T)0};
+#pragma unroll
+					for (int l = 0; l < MAXM; l++) {
+						if ((uint32_t)l < mm) {
+							const uint32_t ks = (uint32_t)((int64_t)conv_kernel_index((uint32_t)j, (uint32_t)l, mm, p.convSymmetric != 0) * p.convKerSysStride) * ES;
+#pragma unroll
+							for (int m = 0; m < E; m++) { cx<T> k = gb_load<T>(gker, klane, m * kstep + ks); if (kconj) k = cconj(k); acc[m] = cadd(acc[m], cmul(k, w[l][m])); }
+						}
+					}
+				}
+#pragma unroll
+				for (int m = 0; m < E; m++) acc[m] = cswap(acc[m]);
+				if constexpr (SCH::NS > 1) VKFFT_SYNC();
+				pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(acc, lds + c, TwGlobal<T>{glut}, tau, false);
+				const GBuf go = make_gbuf((cx<T>*)p.out + (outB + (int64_t)j * p.convSysStride));
+#pragma unroll
+				for (int m = 0; m < E; m++) {
+					cx<T> y = cswap(acc[m]);
+					if (sc != (T)1) y = cscale(y, sc);
+					gb_store<T>(go, (tau + (uint32_t)(m * TPF) - p.padOutL < p.padOutN) ? kGbInvalid : lane, m * step, y);
+				}
+			}
+		}
+	} else if constexpr (MODE == 8) {
+		// the FIRST pass of a strided two-pass (Four-Step) transform run backwards, scratch -> data: conj twiddle w^(-k * column), inverse column FFT
+		// (closes the merged convolution of a long strided axis: forward pass A, merged pass on the inner factor, this pass)
+		const uint32_t laneI = valid ? (tau * (uint32_t)p.inStrideJ + c * (uint32_t)p.dim[0].inStride) * ES : kGbInvalid;
+		const uint32_t stepI = (uint32_t)(TPF * (uint32_t)p.inStrideJ) * ES;
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = cswap(gb_load<T>(gin, laneI, m * stepI));
+		pow2_col_twiddle<T, LOGE, TPF>(v, p, tau, p.fsColFromDim1 ? g1 : col0 + c); // swap(u conj(w)) = swap(u) w
+		pow2_stages<T, SCH, 0, TPF, TCP, TwGlobal<T>>(v, lds + c, TwGlobal<T>{glut}, tau, false);
+		const uint32_t laneO = valid ? (tau * (uint32_t)p.outStrideJ + c * (uint32_t)p.dim[0].outStride) * ES : kGbInvalid;
+		const uint32_t stepO = (uint32_t)(TPF * (uint32_t)p.outStrideJ) * ES;
+#pragma unroll
+		for (int m = 0; m < E; m++) {
+			cx<T> y = cswap(v[m]);
+			if (sc != (T)1) y = cscale(y, sc);
+			gb_store<T>(gout, laneO, m * stepO, y);
+		}
 	} else if constexpr (MODE == 4) {
 		// middle pass of a three-factor inverse run backwards, in place in the column layout: conj twiddle, inverse column FFT
 		const uint32_t lane = valid ? (tau * (uint32_t)p.inStrideJ + c) * ES : kGbInvalid;
@@ -513,7 +589,7 @@ struct Pow2ColBlueVariant { Pow2Variant v; int mode; };
 #define VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, mode) \
 	{ { (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, tc, (((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (tc)), &pow2_col_blue_launch<T, Pow2Sched<b0, b1, b2, b3>, tc, mode> }, mode }
 #define VKFFT_P2CB(T, dp, b0, b1, b2, b3, tc) VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 1), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 2), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 3), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 4), \
-	VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 5)
+	VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 5), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 6), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 8)
 static const Pow2ColBlueVariant kPow2ColBlueVariants[] = {
 	VKFFT_P2CB(float, false, 3, 3, 0, 0, 32),
 	VKFFT_P2CB(float, false, 4, 3, 0, 0, 32),
@@ -521,6 +597,8 @@ static const Pow2ColBlueVariant kPow2ColBlueVariants[] = {
 	VKFFT_P2CB(float, false, 4, 3, 2, 0, 16),
 	VKFFT_P2CB(float, false, 4, 3, 3, 0, 16),
 	VKFFT_P2CB1(float, false, 4, 4, 3, 0, 8, 5), // one-pass column Bluestein on 2048 padded points (147 KiB tile)
+	VKFFT_P2CB1(float, false, 4, 3, 3, 0, 8, 7), // merged matrix convolution along 1024 points: 8-column tiles, 512 threads (three coordinate systems in registers)
+	VKFFT_P2CB1(double, true, 3, 3, 3, 0, 8, 7), // ... 512 points in double precision
 	VKFFT_P2CB(double, true, 3, 3, 0, 0, 16),
 	VKFFT_P2CB(double, true, 3, 2, 2, 0, 16),
 	VKFFT_P2CB(double, true, 3, 3, 2, 0, 16),

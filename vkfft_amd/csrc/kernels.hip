@@ -209,7 +209,7 @@ static void bind(const DirectionPlan& plan, const PassPlan& pp, const LaunchBuff
 	const char* ar = (const char*)plan.dArena;
 	prm.lut = pp.lutOff != (size_t)-1 ? ar + pp.lutOff : nullptr;
 	prm.aux = pp.auxOff != (size_t)-1 ? ar + pp.auxOff : nullptr;
-	prm.aux2 = pp.aux2Off != (size_t)-1 ? ar + pp.aux2Off : nullptr;
+	prm.aux2 = pp.auxIsKernel ? bufs.kernel : pp.aux2Off != (size_t)-1 ? ar + pp.aux2Off : nullptr;
 	prm.aux3 = pp.aux3Off != (size_t)-1 ? ar + pp.aux3Off : nullptr;
 	prm.rader = pp.raderOff != (size_t)-1 ? ar + pp.raderOff : nullptr;
 }

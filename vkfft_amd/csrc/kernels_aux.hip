@@ -13,16 +13,6 @@ namespace vkfft_mi355x {
 
 constexpr int kConvMaxMatrix = 8;
 
-// index of kernel component (j, l) among the systems of one convolution kernel.  symmetricKernel: the packed upper triangle in the DOCUMENTED order
-// xx, xy, xz, yy, yz, zz (API guide, "symmetricKernel"): row a <= b starts after a*m - a*(a-1)/2 entries.  The reference's generated code uses
-// a*m - a*a + b (vkFFT_Convolution.h:352-358), which is the same for m = 2 but collides for m = 3 ((1,2) and (2,2) both give 4, slot 5 is never read);
-// this library follows the documented layout
-__host__ __device__ inline uint32_t conv_kernel_index(uint32_t j, uint32_t l, uint32_t m, bool symmetric) {
-	if (!symmetric) return j * m + l;
-	const uint32_t a = l < j ? l : j, b = l < j ? j : l;
-	return a * m - a * (a - 1u) / 2u - a + b;
-}
-
 template <typename T> __global__ void __launch_bounds__(256) conv_pointwise_kernel(const ConvParams p) {
 	const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= p.systemStride) return;

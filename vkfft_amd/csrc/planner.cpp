@@ -1652,6 +1652,138 @@ static int plan_r2r_axis_fused(const TransformDesc& d, int type, bool dst, uint6
 	return 0;
 }
 
+// ---- merged convolution along the last axis ------------------------------------------------------------------
+// One pass for an axis of 64 .. 1024 points (512 with a kernel matrix: three coordinate systems stay in registers).  Longer axes (two power-of-two
+// factors n0 x M) take three passes instead of the five of "two forward passes, product, two inverse passes": the forward first pass A (FFT over n0,
+// Four-Step twiddle, data -> scratch), the merged pass on the inner factor M (its outputs k1 of column k0 are the frequencies k0 + n0 k1 of the
+// kernel) in place in the scratch, and pass A run backwards (scratch -> data) — the shape of the multi-pass Bluestein plan (MODE 1 / 2 / 3).
+int build_conv_axis_plan(const TransformDesc& d, const ConvAxisDesc& c, DirectionPlan& out) {
+	out = DirectionPlan();
+	Arena ar(out.arena);
+	const int nd = d.fftDim, a = nd - 1;
+	if (nd < 2 || d.kind > 1 || d.omit[a] || d.padFrequency || d.disableFastKernels || d.inFormatted || d.outFormatted) return 3002;
+	const uint64_t L = d.size[a];
+	if ((L & (L - 1)) != 0 || c.coordinates > 3 || c.coordinates < 1 || (c.matrix > 1 && c.matrix != c.coordinates)) return 3002;
+	const bool dp = d.dp;
+	const uint64_t es = dp ? 16 : 8;
+	const bool padded = d.padR[a] > d.padL[a];
+	const uint64_t matrixCap = dp ? 256 : 512; // (beyond: 1024 threads per tile, 128 registers each — three systems do not fit)
+	uint64_t n0 = 1, M = L;
+	int mode = 6;
+	{ int v, b4[4], t, th; if (c.matrix > 1 && L == 2 * matrixCap && pow2_col_blue_lookup(ilog2(L), dp, 7, &v, b4, &t, &th)) mode = 7; } // (the narrow-tile instance)
+	if (L > 1024 || (c.matrix > 1 && L > matrixCap && mode == 6)) { // two factors, the inner one as large as a merged kernel allows
+		if (padded) return 3002; // (the passes of a split axis address by factor, not by the natural index the padded range is given in)
+		M = c.matrix > 1 ? matrixCap : 1024;
+		while (M > 64 && L / M < 64) M >>= 1;
+		n0 = L / M;
+		if (n0 < 64 || n0 > 1024 || M < 64) return 3002;
+	}
+	int variant, bits[4], tc, thr;
+	if (!pow2_col_blue_lookup(ilog2(M), dp, mode, &variant, bits, &tc, &thr)) return 3002;
+	const int64_t strideJ = (int64_t)d.bufStride[a - 1], sys = (int64_t)d.bufStride[nd - 1];
+	const uint64_t W = d.kind == 1 ? d.size[0] / 2 + 1 : d.size[0];
+	// buffer addressing: a column tile and every kernel system behind it lie within one 2 GiB resource
+	if (((uint64_t)L * (uint64_t)strideJ + 64) * es + c.kernelSystems * (uint64_t)sys * es >= 0x7FFFFF00ull) return 3002;
+	// the other spatial dimensions (between axis 0 and the last axis), then the systems: coordinates (inside the merged kernel) and batches
+	std::vector<HostDim> spatial; // strides in the data buffer
+	for (int o = 1; o < a; o++) spatial.push_back({d.size[o], (int64_t)d.bufStride[o - 1], (int64_t)d.bufStride[o - 1]});
+	uint64_t nother = 1; for (auto& h : spatial) nother *= h.count;
+	const bool split = n0 > 1;
+	// scratch layout of the split form: T[(batch * cf + coordinate)][other spatial, dense][k0 * M + m][x]
+	const int64_t tRow = (int64_t)W, tSub = (int64_t)(L * W), tSys = (int64_t)(nother * L * W);
+	PassPlan pp; memset(&pp.prm, 0, sizeof(pp.prm));
+	{
+		PassParams& q = pp.prm;
+		q.L = (uint32_t)M;
+		std::vector<HostDim> dims; std::vector<int64_t> kstr;
+		dims.push_back({W, 1, 1}); kstr.push_back(1);
+		if (!split) {
+			q.inStrideJ = q.outStrideJ = strideJ; q.convKerStrideJ = strideJ; q.convSysStride = sys;
+			for (auto& h : spatial) { dims.push_back(h); kstr.push_back(h.inStride); }
+			dims.push_back({d.batch, (int64_t)c.coordinates * sys, (int64_t)c.coordinates * sys}); kstr.push_back(0);
+		} else {
+			q.inStrideJ = q.outStrideJ = tRow; q.convKerStrideJ = (int64_t)n0 * strideJ; q.convSysStride = tSys;
+			dims.push_back({n0, (int64_t)M * tRow, (int64_t)M * tRow}); kstr.push_back(strideJ); // column k0: frequencies k0 + n0 k1
+			int64_t run = tSub;
+			for (auto& h : spatial) { dims.push_back({h.count, run, run}); kstr.push_back(h.inStride); run *= (int64_t)h.count; }
+			dims.push_back({d.batch, (int64_t)c.coordinates * tSys, (int64_t)c.coordinates * tSys}); kstr.push_back(0);
+		}
+		while (dims.size() < 3) { dims.push_back({1, 0, 0}); kstr.push_back(0); }
+		if (dims.size() > 3) { // only the batch may go to the host loop (the kernel pointer does not follow it)
+			if (dims.size() > 4) return 3002;
+			pp.hostLoop.push_back(dims.back()); dims.pop_back(); kstr.pop_back();
+		}
+		for (int i = 0; i < 3; i++) q.dim[i] = {(uint32_t)dims[i].count, dims[i].inStride, dims[i].outStride};
+		q.convKerStride1 = kstr[1]; q.convKerStride2 = kstr[2]; q.convKerSysStride = sys;
+		q.convM = c.matrix; q.convCf = c.coordinates; q.convSymmetric = c.symmetric; q.convConj = c.conjugate;
+		q.tilesPerG0 = (uint32_t)((W + (uint64_t)tc - 1) / (uint64_t)tc);
+		q.scale = split ? 1.0 : c.scale;
+		if (padded) { q.padInL = q.padOutL = (uint32_t)d.padL[a]; q.padInN = q.padOutN = (uint32_t)(d.padR[a] - d.padL[a]); } // (spatial padding: read side of the forward half, write side of the inverse half)
+		pp.lutOff = build_pow2_stage_lut(ar, bits, dp);
+		pp.kernel = KERNEL_POW2_COL_BLUE; pp.variant = variant; pp.threads = (uint32_t)thr; pp.dp = dp; pp.auxIsKernel = true;
+		pp.inRole = pp.outRole = split ? ROLE_TEMP : ROLE_BUFFER; pp.inElemBytes = pp.outElemBytes = (int)es;
+		pp.label = "convolution";
+	}
+	if (!split) {
+		out.passes.push_back(pp);
+		out.uploadsPerAxis[a] = 1;
+		return 0;
+	}
+	// ---- pass A: FFT over i0 for every (x, m), twiddle w_L^(k0 m), data -> scratch (the first pass of emit_multipass_strided)
+	std::vector<HostDim> restData, restT; // (other spatial dims, systems): strides in the data buffer / in the scratch
+	{ int64_t run = tSub; for (auto& h : spatial) { restData.push_back(h); restT.push_back({h.count, run, run}); run *= (int64_t)h.count; } }
+	restData.push_back({d.batch * c.coordinates, sys, sys}); restT.push_back({d.batch * c.coordinates, tSys, tSys});
+	{
+		PassBuild b;
+		b.dp = dp; b.maxLds = d.maxLds; b.allowFast = true; b.allowOp = true;
+		b.L = n0; b.inStrideJ = (int64_t)M * strideJ; b.outStrideJ = (int64_t)M * tRow;
+		b.colIn = b.colOut = true;
+		b.dims = {{W, 1, 1}, {M, strideJ, tRow}};
+		for (size_t i = 0; i < restData.size(); i++) b.dims.push_back({restData[i].count, restData[i].inStride, restT[i].inStride});
+		b.postOp = OP_TWIDDLE_4STEP; b.fsN = L; b.fsColFromDim1 = true;
+		b.inRole = ROLE_BUFFER; b.outRole = ROLE_TEMP; b.label = "convolution-A"; b.noCollapse = true;
+		PassPlan pa; int r = finish_pass(b, ar, pa); if (r) return 3002;
+		if (pa.kernel != KERNEL_POW2_COL) return 3002;
+		out.passes.push_back(pa);
+	}
+	out.passes.push_back(pp);
+	{ // ---- pass A backwards (pow2_col_blue_kernel MODE 8): scratch -> data, conj twiddle, inverse FFT over k0, normalisation
+		int v8, b8[4], tc8, thr8;
+		if (!pow2_col_blue_lookup(ilog2(n0), dp, 8, &v8, b8, &tc8, &thr8)) return 3002;
+		PassPlan pc; memset(&pc.prm, 0, sizeof(pc.prm));
+		PassParams& q = pc.prm;
+		q.L = (uint32_t)n0; q.inStrideJ = (int64_t)M * tRow; q.outStrideJ = (int64_t)M * strideJ;
+		std::vector<HostDim> dims = {{W, 1, 1}, {M, tRow, strideJ}};
+		for (size_t i = 0; i < restData.size(); i++) dims.push_back({restData[i].count, restT[i].inStride, restData[i].inStride});
+		{ // collapse what is beyond dim[1] where both sides allow, the rest goes to the host loop
+			std::vector<HostDim> tail(dims.begin() + 2, dims.end());
+			collapse_dims(tail);
+			dims.resize(2); for (auto& h : tail) dims.push_back(h);
+		}
+		while (dims.size() < 3) dims.push_back({1, 0, 0});
+		while (dims.size() > 3) { pc.hostLoop.push_back(dims.back()); dims.pop_back(); }
+		for (int i = 0; i < 3; i++) q.dim[i] = {(uint32_t)dims[i].count, dims[i].inStride, dims[i].outStride};
+		q.fsN = (uint32_t)L; q.fsColFromDim1 = 1; q.scale = c.scale;
+		q.tilesPerG0 = (uint32_t)((W + (uint64_t)tc8 - 1) / (uint64_t)tc8);
+		{ // two-level Four-Step table of w_L (as finish_pass builds it)
+			const uint32_t lo = (ceil_log2(L) + 1) / 2;
+			const uint64_t nlo = 1ull << lo, nhi = (L + nlo - 1) / nlo;
+			const size_t off = ar.alloc((nlo + nhi) * es);
+			for (uint64_t i = 0; i < nlo; i++) ar.putc(off, i, unit_root(i, L), dp);
+			for (uint64_t i = 0; i < nhi; i++) ar.putc(off, nlo + i, unit_root(i * nlo, L), dp);
+			q.fsLoBits = lo; pc.auxOff = off;
+		}
+		pc.lutOff = build_pow2_stage_lut(ar, b8, dp);
+		pc.kernel = KERNEL_POW2_COL_BLUE; pc.variant = v8; pc.threads = (uint32_t)thr8; pc.dp = dp;
+		pc.inRole = ROLE_TEMP; pc.outRole = ROLE_BUFFER; pc.inElemBytes = pc.outElemBytes = (int)es;
+		pc.label = "convolution-A-back";
+		out.passes.push_back(pc);
+	}
+	out.tempBytes = (uint64_t)d.batch * c.coordinates * (uint64_t)tSys * es;
+	out.uploadsPerAxis[a] = 3;
+	return 0;
+}
+
 // ---- top level ----------------------------------------------------------------------------------------
 int build_direction_plan(const TransformDesc& d, DirectionPlan& out) {
 	out = DirectionPlan();
