@@ -360,3 +360,24 @@ def test_fused_fourstep_fp64(run, oracle, monkeypatch, k, batch):
     assert up == [2]
     assert rel_l2(y, oracle.truth_c2c(x, (N,), batch, longdouble=True)) < 3e-15
     assert rel_l2(z, x * N) < 5e-15
+
+
+@pytest.mark.parametrize("shape,dp", [((32, 16, 64), False), ((8, 256), False), ((16, 4, 128), True), ((4, 1 << 13), False)])
+def test_column_kernel_with_64_bit_addresses(oracle, emu_lib, shape, dp):
+    """pow2_col_kernel's wide-span form (tiles of 2 GiB and more: the z axis of a 1024^3 volume on one GPU) forced on small problems
+    (VKFFT_MI355X_FORCE_BIGSPAN is read once per process: own subprocess); the last case runs the Four-Step passes of a strided 8192-point axis"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, os, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))
+from vkfft_amd import api
+import parity, helpers
+from oracle import oracle as O
+lib = api.load_test_double(os.path.join({root!r}, 'tests', 'hostemu', '_build', 'libvkfft_hostemu.so'))
+run = helpers.Runner(lib, 'emu')
+parity.check_c2c(run, O, {tuple(shape)!r}, 2, {dp!r}, use_c_oracle=False)
+print('OK')
+"""
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VKFFT_MI355X_FORCE_BIGSPAN="1"), capture_output=True, text=True)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -949,3 +949,24 @@ def test_zero_padding_against_live_reference(run, shape, pads, kind, inverse, fr
     if kind == 1:
         got, r_ = got.view(np.complex64), r_.view(np.complex64)
     assert rel_l2(got, r_) < 2e-6
+
+
+def test_volume_whose_column_tiles_span_two_gib(product_lib):
+    """1024 x 512 x 512 complex64 (2 GiB): the tiles of the z pass are 512 rows of 4 MiB pitch = 2 GiB, beyond one buffer resource — they run on the
+    64-bit form of pow2_col_kernel instead of the interpreter (the reference switches its index type: vkFFT_InitializeApp.h:1190-1221)"""
+    import torch, ctypes as C
+    nx, ny, nz = 1024, 512, 512
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    x = torch.view_as_complex(torch.empty(nz, ny, nx, 2, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g))
+    buf = x.clone()
+    app = api.App([nx, ny, nz], 1, buffer_ptr=buf.data_ptr(), lib=product_lib)
+    names = C.create_string_buffer(1024)
+    product_lib.vkfftMI355XDescribePlan(C.byref(app.app), 0, names, 1024)
+    assert "generic_pass_kernel" not in names.value.decode(), names.value
+    app.forward(); torch.cuda.synchronize()
+    ref = torch.fft.fftn(x, dim=(0, 1, 2))
+    err = (torch.linalg.norm((buf - ref).flatten()) / torch.linalg.norm(ref.flatten())).item()
+    assert err < 1e-6, err
+    app.inverse(); torch.cuda.synchronize(); app.delete()
+    err = (torch.linalg.norm((buf / (nx * ny * nz) - x).flatten()) / torch.linalg.norm(x.flatten())).item()
+    assert err < 2e-6, err

@@ -182,7 +182,9 @@ __device__ inline void pow2_col_twiddle(cx<T>* v, const PassParams& p, const uin
 // Stockham core as the row kernel; the LDS exchange is [element][column] with an odd pitch, conflict-free
 // in both directions.  Optional fused epilogue: Four-Step twiddle (two-level LUT) and a transposed store
 // (each column written out as one contiguous run) for the first Four-Step pass.
-template <typename T, typename SCH, int TC>
+// BIG: tiles whose rows are so far apart that the tile spans 2 GiB or more (the z axis of a 1024^3 volume on one GPU: 8 MiB x 1024 rows): 64-bit
+// per-lane addresses instead of one buffer resource per tile (the reference switches its index type the same way, vkFFT_InitializeApp.h:1190-1221)
+template <typename T, typename SCH, int TC, bool BIG = false>
 __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col_kernel(const PassParams p) {
 	constexpr int LOGN = SCH::LOGN, L = 1 << LOGN, LOGE = SCH::LOGE, E = 1 << LOGE, TPF = L / E;
 	constexpr int TCP = TC + 1, NT = TPF * TC;
@@ -205,7 +207,11 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 	const uint32_t laneIn = valid ? (tau * (uint32_t)p.inStrideJ + c * (uint32_t)p.dim[0].inStride) * ES : kGbInvalid;
 	const uint32_t stepIn = (uint32_t)(TPF * (uint32_t)p.inStrideJ) * ES;
 	cx<T> v[E];
-	if (p.padInN) { // zero padding along this axis: rows of the padded range are not fetched
+	if constexpr (BIG) {
+		const cx<T>* pin = (const cx<T>*)p.in + (inB + (int64_t)tau * p.inStrideJ + (int64_t)c * p.dim[0].inStride);
+#pragma unroll
+		for (int m = 0; m < E; m++) v[m] = (valid && !(tau + (uint32_t)(m * TPF) - p.padInL < p.padInN)) ? pin[(int64_t)(m * TPF) * p.inStrideJ] : cx<T>{(T)0, (T)0};
+	} else if (p.padInN) { // zero padding along this axis: rows of the padded range are not fetched
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m] = gb_load<T>(gin, (tau + (uint32_t)(m * TPF) - p.padInL < p.padInN) ? kGbInvalid : laneIn, m * stepIn);
 	} else {
@@ -234,7 +240,11 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 	if (p.colModeOut) {
 		const uint32_t laneOut = valid ? (tau * (uint32_t)p.outStrideJ + c * (uint32_t)p.dim[0].outStride) * ES : kGbInvalid;
 		const uint32_t stepOut = (uint32_t)(TPF * (uint32_t)p.outStrideJ) * ES;
-		if (p.padOutN) {
+		if constexpr (BIG) {
+			cx<T>* pout = (cx<T>*)p.out + (outB + (int64_t)tau * p.outStrideJ + (int64_t)c * p.dim[0].outStride);
+#pragma unroll
+			for (int m = 0; m < E; m++) if (valid && !(tau + (uint32_t)(m * TPF) - p.padOutL < p.padOutN)) pout[(int64_t)(m * TPF) * p.outStrideJ] = v[m];
+		} else if (p.padOutN) {
 #pragma unroll
 			for (int m = 0; m < E; m++) gb_store<T>(gout, (tau + (uint32_t)(m * TPF) - p.padOutL < p.padOutN) ? kGbInvalid : laneOut, m * stepOut, v[m]);
 		} else {
@@ -252,8 +262,11 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 		for (int i = 0; i < E; i++) {
 			const uint32_t idx = tid + i * NT;
 			const uint32_t k = idx % L, cc = idx / L;
-			const uint32_t off = cc < nvalid ? (cc * (uint32_t)p.dim[0].outStride + k * (uint32_t)p.outStrideJ) * ES : kGbInvalid;
-			gb_store<T>(gout, off, 0, lds[k * TCP + cc]);
+			if constexpr (BIG) { if (cc < nvalid) ((cx<T>*)p.out)[outB + (int64_t)cc * p.dim[0].outStride + (int64_t)k * p.outStrideJ] = lds[k * TCP + cc]; }
+			else {
+				const uint32_t off = cc < nvalid ? (cc * (uint32_t)p.dim[0].outStride + k * (uint32_t)p.outStrideJ) * ES : kGbInvalid;
+				gb_store<T>(gout, off, 0, lds[k * TCP + cc]);
+			}
 		}
 	}
 }
@@ -489,7 +502,8 @@ template <typename T, typename SCH, int FPW> void pow2_row_launch(const PassPara
 
 template <typename T, typename SCH, int TC> void pow2_col_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
 	constexpr int threads = ((1 << SCH::LOGN) >> SCH::LOGE) * TC;
-	hipLaunchKernelGGL((pow2_col_kernel<T, SCH, TC>), grid, dim3(threads), 0, s, prm);
+	if (prm.bigSpan) hipLaunchKernelGGL((pow2_col_kernel<T, SCH, TC, true>), grid, dim3(threads), 0, s, prm);
+	else hipLaunchKernelGGL((pow2_col_kernel<T, SCH, TC, false>), grid, dim3(threads), 0, s, prm);
 }
 
 #define VKFFT_P2C(T, dp, b0, b1, b2, b3, tc) \

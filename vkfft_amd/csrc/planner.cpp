@@ -125,6 +125,7 @@ struct PassBuild {
 	bool allowOp = false;   // op-FFT family (kernel_opfft.h): fused pre/post map kernels
 	bool noCollapse = false;
 	uint32_t padInL = 0, padInN = 0, padOutL = 0, padOutN = 0; // zero padding along J (PassParams::padIn* / padOut*)
+	bool bigSpan = false;
 	uint64_t maxLds = 160 * 1024;
 	// tables prepared by the caller (arena offsets)
 	size_t auxOff = (size_t)-1, aux2Off = (size_t)-1;
@@ -158,7 +159,9 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
 		const uint64_t spanIn = (b.L * (uint64_t)std::llabs(b.inStrideJ) + 64 * (uint64_t)std::llabs(d0.inStride)) * esz;
 		const uint64_t spanOut = (b.L * (uint64_t)std::llabs(b.outStrideJ) + 64 * (uint64_t)std::llabs(d0.outStride)) * esz;
-		if (spanIn < 0x7FFFFF00ull && spanOut < 0x7FFFFF00ull && pow2_col_lookup(ilog2(b.L), b.dp, &variant, bits, &tc, &thr)) {
+		if (pow2_col_lookup(ilog2(b.L), b.dp, &variant, bits, &tc, &thr)) {
+			static const bool forceBig = getenv("VKFFT_MI355X_FORCE_BIGSPAN") != nullptr; // (tests: the 64-bit form on small problems)
+			b.bigSpan = forceBig || !(spanIn < 0x7FFFFF00ull && spanOut < 0x7FFFFF00ull); // (then the kernel's 64-bit form: DESIGN 7, the z axis of 1024^3 on one GPU)
 			b.fastKernel = KERNEL_POW2_COL; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)tc;
 			b.radices.clear();
 			for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
@@ -355,6 +358,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.fsColFromDim1 = b.fsColFromDim1 ? 1 : 0;
 	p.scale = b.scale;
 	p.padInL = b.padInL; p.padInN = b.padInN; p.padOutL = b.padOutL; p.padOutN = b.padOutN;
+	p.bigSpan = b.bigSpan ? 1u : 0u;
 	p.divL = make_fastdiv((uint32_t)b.L);
 	p.divOutLen = make_fastdiv(p.outLen);
 	const uint64_t padded = p.padShift >= 31 ? b.L : b.L + (b.L >> p.padShift);
