@@ -177,13 +177,21 @@ def main():
                     launches_per_transform=per_size[kd]["launches"], launch_ms=round(launch_ms, 5),
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
                     copy_GBps_same_box=round(copy_GBps, 1), frac_of_copy=round(achieved / copy_GBps, 4), traffic=None)
-    prof = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if os.path.exists(prof):
+    # HBM-side bytes per launch from the PMC passes (tools/pmc_probe.py -> tools/summarize_profiles.py); valid only for the build they were
+    # collected on, so the newest summary is used only when its source hash is the one of the sources this library was built from
+    import glob
+    for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
-            roofline["traffic"] = json.load(open(prof)).get(dom.split("<")[0], {}).get("bytes_per_launch")
-            roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc, separate passes; L2<->fabric requests: Infinity-Cache hits included)"
+            pj = json.load(open(prof))
         except Exception:
-            pass
+            continue
+        if pj.get("source_hash") != api.source_hash():
+            roofline["traffic_source"] = f"null: {os.path.basename(prof)} was collected on other sources ({pj.get('source_hash')} vs {api.source_hash()})"
+            break
+        roofline["traffic"] = pj.get(dom.split("<")[0], {}).get("bytes_per_launch")
+        roofline["traffic_source"] = (f"profiles/{os.path.basename(prof)} (rocprofv3 --pmc, separate passes, sources {pj.get('source_hash')}; "
+                                      "L2<->fabric requests: Infinity-Cache hits included)")
+        break
 
     # ---- CPU baseline (rank 0, N=1 only) ------------------------------------------------------------------------
     cpu = None

@@ -23,8 +23,9 @@
  *     (saveApplicationToString, loadApplicationFromString, keepShaderCode, maxCodeLength, ...) are
  *     accepted and ignored;
  *   - only the HIP backend exists: defining VKFFT_BACKEND to anything but 2 is an error;
- *   - convolution and zero-padding fields are accepted in the struct for layout compatibility but a
- *     plan that enables them is rejected (out of scope).
+ *   - convolution and zero padding are supported with the restrictions listed in INTEGRATION.md
+ *     (DESIGN.md section 4.11); half / double-double precision and buffers split over several
+ *     allocations are accepted in the struct for layout compatibility and rejected at plan creation.
  */
 #ifndef VKFFT_H
 #define VKFFT_H
@@ -98,7 +99,7 @@ typedef struct {
 	void** tempBuffer;   /* scratch for multi-pass (Four-Step) and Bluestein plans */
 	void** inputBuffer;  /* used when isInputFormatted */
 	void** outputBuffer; /* used when isOutputFormatted */
-	void** kernel;       /* convolution kernel (out of scope) */
+	void** kernel;       /* convolution kernel spectra (performConvolution plans) */
 
 	pfUINT bufferOffset; /* byte offsets of the first element */
 	pfUINT tempBufferOffset;
@@ -166,12 +167,12 @@ typedef struct {
 	pfUINT fixMinRaderPrimeFFT;
 	pfUINT fixMaxRaderPrimeFFT;
 
-	pfUINT performZeropadding[VKFFT_MAX_FFT_DIMENSIONS]; /* out of scope: rejected when set */
+	pfUINT performZeropadding[VKFFT_MAX_FFT_DIMENSIONS]; /* vkFFT_Structs.h; semantics in INTEGRATION.md */
 	pfUINT fft_zeropad_left[VKFFT_MAX_FFT_DIMENSIONS];
 	pfUINT fft_zeropad_right[VKFFT_MAX_FFT_DIMENSIONS];
 	pfUINT frequencyZeroPadding;
 
-	pfUINT performConvolution; /* out of scope: rejected when set */
+	pfUINT performConvolution; /* forward -> product with `kernel` -> inverse in one VkFFTAppend(-1) */
 	pfUINT conjugateConvolution;
 	pfUINT crossPowerSpectrumNormalization;
 	pfUINT coordinateFeatures; /* C of WHDCN */

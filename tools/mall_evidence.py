@@ -7,14 +7,25 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vkfft_amd import api
 
+import re, tempfile
+
 def pair_ms(k, env):
+    """-> (best pair time in ms, ring size in MiB as the planner reports it under VKFFT_MI355X_PRINT_PLAN, or None for separate passes)"""
     for key in list(os.environ):
         if key.startswith("VKFFT_MI355X_"):
             del os.environ[key]
     os.environ.update(env)
+    os.environ["VKFFT_MI355X_PRINT_PLAN"] = "1"
     N = 1 << k
     t = torch.empty(2 << 27, dtype=torch.float32, device="cuda").uniform_(-1, 1)
-    app = api.App([N], (1 << 27) // N, buffer_ptr=t.data_ptr(), normalize=True)
+    with tempfile.TemporaryFile() as tf:           # the library prints the plan on the C stderr
+        sys.stderr.flush(); saved = os.dup(2); os.dup2(tf.fileno(), 2)
+        try:
+            app = api.App([N], (1 << 27) // N, buffer_ptr=t.data_ptr(), normalize=True)
+        finally:
+            os.dup2(saved, 2); os.close(saved)
+        tf.seek(0); m = re.search(r"ring \d+ \(([0-9.]+) MiB\)", tf.read().decode(errors="replace"))
+    ring = float(m.group(1)) if m else None
     for _ in range(2):
         app.forward(); app.inverse()
     torch.cuda.synchronize()
@@ -27,14 +38,15 @@ def pair_ms(k, env):
         e1.record(); e1.synchronize()
         best = min(best, e0.elapsed_time(e1) / 6)
     app.delete()
-    return best
+    return best, ring
 
-for k in (16, 18):
+# (lag, ring) in slots per queue; the chunk is about 1 MiB or one transform (8 MiB at 2^20, 32 MiB at 2^22)
+SWEEP = {16: ((13, 26), (26, 52), (52, 104), (100, 128)), 18: ((13, 26), (26, 52), (52, 104), (100, 128)),
+         20: ((2, 4), (4, 8), (8, 16)), 22: ((1, 2), (2, 4))}
+for k in (16, 18, 20, 22):
     rows = [("separate passes (VKFFT_MI355X_FUSED=0)", {"VKFFT_MI355X_FUSED": "0"}), ("fused, default ring", {})]
-    for lag, ring in ((13, 26), (26, 52), (52, 104), (100, 128)):
+    for lag, ring in SWEEP[k]:
         rows.append((f"fused, lag {lag} ring {ring} slots/queue", {"VKFFT_MI355X_FUSED_LAG": str(lag), "VKFFT_MI355X_FUSED_RING": str(ring)}))
     for name, env in rows:
-        ms = pair_ms(k, env)
-        chunk_mib = max(1.0, (8 << k) / 2.0 ** 20)  # the planner's chunk: about 1 MiB, at least one transform
-        ring_mib = None if "ring" not in name or "default" in name else 8 * int(env["VKFFT_MI355X_FUSED_RING"]) * chunk_mib
+        ms, ring_mib = pair_ms(k, env)
         print(json.dumps(dict(log2N=k, config=name, ring_MiB=ring_mib, pair_ms=round(ms, 4), alg_GBps=round(4 * (8 << 27) / (ms * 1e-3) / 1e9, 1))), flush=True)

@@ -4,6 +4,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vkfft_amd import api
+if os.environ.get("VKFFT_PMC_HASH_FILE"):
+    open(os.environ["VKFFT_PMC_HASH_FILE"], "w").write(api.source_hash() + "\n")
 buf = torch.empty(2 << 27, dtype=torch.float32, device="cuda").uniform_(-1, 1)
 dst = torch.empty_like(buf)
 for _ in range(2):

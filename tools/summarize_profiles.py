@@ -1,9 +1,14 @@
 """Turns the rocprofv3 CSVs that a gpurun call left under gpurun_out/ into the tracked summaries in profiles/.
-usage: summarize_profiles.py <round-tag> <gpurun_out subdir>   (e.g. r02 r2prof)"""
+usage: summarize_profiles.py <round-tag> <gpurun_out subdir> [name of the kernel-stats summary] [command line it came from]
+(e.g. r03 r03/prof_bench bench_kernel_stats "python bench.py --steps 3 --warmup 1 --no-cpu-baseline")"""
 import csv, collections, json, os, sys, glob
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 sub = sys.argv[2] if len(sys.argv) > 2 else "r2prof"
+ksname = sys.argv[3] if len(sys.argv) > 3 else "bench_kernel_stats"
+kscmd = sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+sys.path.insert(0, ROOT)
+from vkfft_amd import api
 base = os.path.join(ROOT, "gpurun_out", sub)
 out = os.path.join(ROOT, "profiles"); os.makedirs(out, exist_ok=True)
 
@@ -14,8 +19,8 @@ def find(pattern):
 ks = find("*kernel_stats.csv")
 if ks:
     rows = list(csv.DictReader(open(ks)))
-    with open(os.path.join(out, f"{tag}_bench_kernel_stats.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (1x MI355X)\n")
+    with open(os.path.join(out, f"{tag}_{ksname}.csv"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- {kscmd} (1x MI355X; sources {api.source_hash()})\n")
         w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows:
             w.writerow([r["Name"][:150], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
@@ -34,7 +39,8 @@ for p in sorted(glob.glob(os.path.join(base, "**", "*counter_collection.csv"), r
 summ = {"note": "rocprofv3 --pmc <one set per pass> on tools/pmc_probe.py, 1 GiB buffer per launch, averages per launch.  FETCH_SIZE / WRITE_SIZE unit = KiB; "
                 "gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 1/2 of wide coalesced reads -> doubled in fetch_bytes_corrected.  "
                 "These are requests at the L2<->fabric boundary: hits in the memory-side Infinity Cache are included (no HBM-level counter is exposed; "
-                "see r02_mall_evidence.jsonl for the HBM-level argument).",
+                f"see {tag}_mall_evidence.jsonl for the HBM-level argument).",
+        "source_hash": api.source_hash(),
         "kernels": {}}
 for kname, c in cnt.items():
     if "vkfft" not in kname and "copy" not in kname.lower() and "elementwise" not in kname.lower(): continue
@@ -47,5 +53,8 @@ for fam in ("pow2_fused_kernel", "pow2_row_kernel", "pow2_col_kernel"):
     ks_ = [k for k in summ["kernels"] if fam in k and "bytes_per_launch" in summ["kernels"][k]]
     if ks_:
         summ[fam] = {"bytes_per_launch": max(summ["kernels"][k]["bytes_per_launch"] for k in ks_), "algorithmic_bytes_per_transform": 2.0 * (1 << 30)}
-json.dump(summ, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-print(json.dumps(summ, indent=1)[:3000])
+hf = find("pmc_source_hash.txt")
+if hf: summ["source_hash"] = open(hf).read().strip()   # what the probe itself saw on the GPU box
+if cnt:
+    json.dump(summ, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(summ, indent=1)[:3000])

@@ -97,6 +97,18 @@ def lib_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvkfft_mi355x.so")
 
 
+def source_hash():
+    """Identifies the build the profiles were taken on: sha1 over the kernel / planner sources (csrc/*, sorted by name).  The .so itself is
+    not hashed (46 MB, and a rebuild from the same sources must keep the key)."""
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha1()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip", ".cpp")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _bind(p):
     # torch ships its own copy of the HIP runtime: import it first so that this process ends up with ONE
     # libamdhip64 (the one torch's tensors live in) — device pointers are not shared between two runtimes.
