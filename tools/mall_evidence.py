@@ -40,13 +40,16 @@ def pair_ms(k, env):
     app.delete()
     return best, ring
 
-# (lag, ring) in slots per queue; the chunk is about 1 MiB or one transform (8 MiB at 2^20, 32 MiB at 2^22)
-SWEEP = {16: ((13, 26), (26, 52), (52, 104), (100, 128)), 18: ((13, 26), (26, 52), (52, 104), (100, 128)),
-         20: ((2, 4), (4, 8), (8, 16)), 22: ((1, 2), (2, 4))}
+# (queues, lag, ring slots per queue): the queue count is FIXED per size (the planner would otherwise fall back to one queue when the ring
+# exceeds its cache budget, which changes the ticket rate as well); the chunk is about 1 MiB or one transform (8 MiB at 2^20, 32 MiB at 2^22),
+# ring bytes = queues x slots x chunk.  A longer lag only relaxes dependencies, so what slows the larger rings down is where their bytes live.
+SWEEP = {16: ((8, 13, 26), (8, 26, 52), (8, 52, 104), (8, 64, 128)), 18: ((8, 6, 13), (8, 13, 26), (8, 26, 52), (8, 32, 64)),
+         20: ((8, 1, 2), (8, 2, 4), (8, 4, 8), (8, 8, 16)), 22: ((2, 1, 2), (2, 2, 4), (2, 4, 8), (2, 8, 16))}
 for k in (16, 18, 20, 22):
     rows = [("separate passes (VKFFT_MI355X_FUSED=0)", {"VKFFT_MI355X_FUSED": "0"}), ("fused, default ring", {})]
-    for lag, ring in SWEEP[k]:
-        rows.append((f"fused, lag {lag} ring {ring} slots/queue", {"VKFFT_MI355X_FUSED_LAG": str(lag), "VKFFT_MI355X_FUSED_RING": str(ring)}))
+    for q, lag, ring in SWEEP[k]:
+        rows.append((f"fused, {q} queues, lag {lag}, ring {ring} slots/queue",
+                     {"VKFFT_MI355X_FUSED_QUEUES": str(q), "VKFFT_MI355X_FUSED_LAG": str(lag), "VKFFT_MI355X_FUSED_RING": str(ring)}))
     for name, env in rows:
         ms, ring_mib = pair_ms(k, env)
         print(json.dumps(dict(log2N=k, config=name, ring_MiB=ring_mib, pair_ms=round(ms, 4), alg_GBps=round(4 * (8 << 27) / (ms * 1e-3) / 1e9, 1))), flush=True)
