@@ -33,7 +33,15 @@ def product_lib():
 def emu_lib():
     """CPU-emulated build of the same sources (tests/hostemu) — test double for host logic / index maps."""
     from vkfft_amd import api
-    subprocess.check_call([os.path.join(ROOT, "tests", "hostemu", "build.sh")])
+    # one build at a time: pytest-xdist workers would otherwise compile into the same object files concurrently
+    import fcntl
+    os.makedirs(os.path.join(ROOT, "tests", "hostemu", "_build"), exist_ok=True)
+    with open(os.path.join(ROOT, "tests", "hostemu", "_build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call([os.path.join(ROOT, "tests", "hostemu", "build.sh")])
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return api.load_test_double(os.path.join(ROOT, "tests", "hostemu", "_build", "libvkfft_hostemu.so"))
 
 

@@ -127,3 +127,27 @@ def check_opfft_case(runner, oracle, fam, L, col, dp, load_elems=0, max_points=1
         for s, b in zip(small[:2], big[:2]):
             bad = np.flatnonzero(np.tile(s, reps).view(np.uint8) != b.view(np.uint8))
             assert bad.size == 0, (fam, L, col, dp, bad[:8])
+
+
+def mixconv_entries():
+    """(dp, rader, col, p or M) of every instance of kernel_mixconv.h (generated tables)"""
+    import os, re, glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(root, "vkfft_amd", "csrc", "mixconv_table_*.inc"))))
+    out = []
+    for m in re.finditer(r"VKFFT_MC\((float|double), \w+, (\d), (\d),[^\n]*=(\d+)\n", txt):
+        out.append((m.group(1) == "double", int(m.group(2)) == 1, int(m.group(3)) == 1, int(m.group(4))))
+    return sorted(set(out))
+
+
+def mixconv_length_for(rader, v):
+    """a transform length that the instance serves: the Rader prime itself; for a Bluestein padded length M the largest prime <= (M+1)/2 that has no
+    radix-kernel instance (> 31) — None when there is none (the shortest ladder lengths)"""
+    if rader:
+        return v
+    n = (v + 1) // 2
+    while n > 31:
+        if all(n % q for q in range(2, int(n ** 0.5) + 1)):
+            return n
+        n -= 1
+    return None

@@ -167,8 +167,10 @@ def test_r2r_whose_embedding_length_needs_bluestein(run, oracle, N, dp, type, ds
 
 @pytest.mark.parametrize("shape", [(53, 53), (41, 43, 5), (37, 37, 37), (8, 947), (33, 83), (16, 2, 257)])
 @pytest.mark.parametrize("dp", [False, True])
-def test_prime_planes_use_the_column_bluestein_kernel(run, oracle, shape, dp):
-    """strided axes of non-smooth length (the reference's sample-7 systems): one pass of pow2_col_blue_kernel (MODE 5) per axis"""
+def test_prime_planes_use_the_column_bluestein_kernel(run, oracle, shape, dp, monkeypatch):
+    """strided axes of non-smooth length (the reference's sample-7 systems): one pass of pow2_col_blue_kernel (MODE 5) per axis (the Rader / smooth-length
+    family of kernel_mixconv.h, which takes most of these since round 3, is switched off here: it has its own tests)"""
+    monkeypatch.setenv("VKFFT_MI355X_MIXCONV", "0")
     up = parity.check_c2c(run, oracle, shape, 2, dp, kind="bluestein", use_c_oracle=False)
     assert up == [1] * len(shape)
     if dp and max(shape[1:]) > 512:
@@ -381,3 +383,51 @@ print('OK')
 """
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VKFFT_MI355X_FORCE_BIGSPAN="1"), capture_output=True, text=True)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def _mixconv_cases():
+    """(N, dp) over the row instances of kernel_mixconv.h: every 7th Rader prime and every 5th Bluestein ladder length (the longest prime row it serves)"""
+    ent = [e for e in parity.mixconv_entries() if not e[2]]
+    cases = []
+    for dp in (False, True):
+        primes = [v for d, r, c, v in ent if d == dp and r]
+        ladder = [v for d, r, c, v in ent if d == dp and not r]
+        cases += [(p, dp) for p in primes[::7] + primes[-1:]]
+        cases += [(parity.mixconv_length_for(False, m), dp) for m in ladder[::5] + ladder[-1:] if parity.mixconv_length_for(False, m)]
+    return cases
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_one_kernel_cyclic_convolution_rows(run, oracle, chunk, monkeypatch):
+    """Rader (prime p, transform length p-1) and Bluestein on a smooth padded length, forward and round trip, dense rows and a partial last tile"""
+    monkeypatch.setenv("VKFFT_MI355X_MIXCONV", "2")  # always prefer the family: the cost model would give some of these lengths to the power-of-two kernel
+    for N, dp in _mixconv_cases()[chunk::4]:
+        batch = 3 if N > 512 else 37
+        x = parity.seeded_complex(N * batch, dp, N)
+        y, z, _ = run.transform(x, (N,), batch, both=True)
+        e = rel_l2(y, oracle.truth_c2c(x, (N,), batch, longdouble=dp))
+        assert e < (3e-15 if dp else 1.5e-6), (N, dp, e)
+        e2 = rel_l2(z, x.astype(np.complex128) * N)
+        assert e2 < (6e-15 if dp else 3e-6), (N, dp, e2)
+
+
+def test_one_kernel_cyclic_convolution_is_chosen(run, monkeypatch):
+    """the plan of a Rader prime / of a length just above a power of two is ONE launch of the family (not the interpreter, not the power-of-two kernel)"""
+    monkeypatch.setenv("VKFFT_MI355X_MIXCONV", "2")
+    for N in (257, 8191, 1046, 47):
+        x = parity.seeded_complex(N * 2, False, N)
+        h, ptr = run._alloc(x)
+        app = api.App([N], 2, buffer_ptr=ptr, lib=run.lib)
+        try:
+            n, names = app.launch_info()
+            assert n == 1 and "mixconv" in names, (N, n, names)
+        finally:
+            app.delete()
+
+
+@pytest.mark.parametrize("shape", [(37, 37), (6, 73), (40, 47), (3, 547), (5, 1009), (12, 257, 3), (67, 67, 2)])
+@pytest.mark.parametrize("dp", [False, True])
+def test_one_kernel_cyclic_convolution_columns(run, oracle, shape, dp, monkeypatch):
+    """strided axes: tiles of neighbouring columns (Rader primes 37, 73, 257, 547, 1009; Bluestein on a smooth length for 47), partial tiles"""
+    monkeypatch.setenv("VKFFT_MI355X_MIXCONV", "2")
+    parity.check_c2c(run, oracle, shape, 2, dp, kind="bluestein")

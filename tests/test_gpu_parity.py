@@ -970,3 +970,39 @@ def test_volume_whose_column_tiles_span_two_gib(product_lib):
     app.inverse(); torch.cuda.synchronize(); app.delete()
     err = (torch.linalg.norm((buf / (nx * ny * nz) - x).flatten()) / torch.linalg.norm(x.flatten())).item()
     assert err < 2e-6, err
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_every_cyclic_convolution_table_entry(run, oracle, chunk, monkeypatch):
+    """kernel_mixconv.h: every ahead-of-time instance — Rader primes and Bluestein ladder lengths, rows and column tiles, fp32 and fp64 — against the
+    oracle on a few sequences, then with the chip full against its own small-batch output (same input repeated)."""
+    monkeypatch.setenv("VKFFT_MI355X_MIXCONV", "2")
+    for dp, rader, col, v in parity.mixconv_entries()[chunk::4]:
+        N = parity.mixconv_length_for(rader, v)
+        if N is None:
+            continue
+        if col:
+            C = 37  # companion (unit-stride) axis: one full tile and a partial one
+            shape, batch = (C, N), 1
+            x = parity.seeded_complex(C * N, dp, N)
+            want = oracle.truth_c2c(x, shape, batch, longdouble=dp)
+        else:
+            shape, batch = (N,), 5
+            x = parity.seeded_complex(N * batch, dp, N)
+            want = oracle.truth_c2c(x, shape, batch, longdouble=dp)
+        app_x = x.copy()
+        h, ptr = run._alloc(app_x)
+        app = api.App(list(shape), batch, dp=dp, buffer_ptr=ptr, lib=run.lib)
+        try:
+            n, names = app.launch_info()
+            assert "mixconv" in names or (col and n == 2), (dp, rader, col, v, n, names)
+            app.forward()
+            y = run._fetch(h, x.dtype)
+        finally:
+            app.delete()
+        e = rel_l2(y, want)
+        assert e < (6e-15 if dp else 2e-6), (dp, rader, col, v, e)
+        if not col:
+            reps = max(1, (1 << 20) // (batch * N))
+            yb, _ = run.transform(np.tile(x, reps), shape, batch * reps)
+            assert np.array_equal(yb.view(np.uint8), np.tile(y, reps).view(np.uint8)), (dp, rader, col, v)

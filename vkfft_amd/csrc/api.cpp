@@ -91,7 +91,7 @@ VKFFT_API void vkfftMI355XStructSizes(pfUINT out[4]) {
 
 VKFFT_API int vkfftMI355XDescribePlan(const VkFFTApplication* app, int inverse, char* names, pfUINT cap) {
 	static const char* kname[] = {"generic_pass_kernel", "pow2_row_kernel", "pow2_col_kernel", "r2c_even_pair_kernel", "?", "mixed_row_kernel", "opfft_kernel", "pow2_blue_kernel",
-	                              "pow2_col_blue_kernel", "pow2_blue_r2r_kernel", "pow2_fused_kernel", "transpose_kernel", "real_map_kernel"};
+	                              "pow2_col_blue_kernel", "pow2_blue_r2r_kernel", "pow2_fused_kernel", "transpose_kernel", "real_map_kernel", "mixconv_row_kernel"};
 	if (names && cap) names[0] = 0;
 	if (!app) return 0;
 	const VkFFTPlan* pl = inverse == 1 ? app->localFFTPlan_inverse : app->localFFTPlan;
@@ -104,7 +104,7 @@ VKFFT_API int vkfftMI355XDescribePlan(const VkFFTApplication* app, int inverse, 
 		for (const HostDim& h : q.hostLoop) rep *= h.count;
 		launches += (int)rep;
 		if (!names || !cap) continue;
-		const char* nm = kname[q.kernel >= 0 && q.kernel < 13 ? q.kernel : 4];
+		const char* nm = kname[q.kernel >= 0 && q.kernel < 14 ? q.kernel : 4];
 		int w = snprintf(names + pos, pos < cap ? (size_t)cap - pos : 0, "%s%s<%s>", pos ? "," : "", nm, q.dp ? "double" : "float");
 		if (w > 0) pos = std::min<size_t>(pos + (size_t)w, (size_t)cap - 1);
 	}
@@ -287,7 +287,7 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 		}
 	}
 	if (c.printMemoryLayout || getenv("VKFFT_MI355X_PRINT_PLAN")) { // one line per launch: which kernel family serves it
-		static const char* kname[] = {"generic", "pow2_row", "pow2_col", "r2c_pair", "?", "mixed_row", "opfft", "pow2_blue", "pow2_col_blue", "pow2_blue_r2r", "pow2_fused", "transpose", "real_map"};
+		static const char* kname[] = {"generic", "pow2_row", "pow2_col", "r2c_pair", "?", "mixed_row", "opfft", "pow2_blue", "pow2_col_blue", "pow2_blue_r2r", "pow2_fused", "transpose", "real_map", "mixconv_row"};
 		for (int dir = 0; dir < 2; dir++) {
 			VkFFTPlan* pl = dir ? app->localFFTPlan_inverse : app->localFFTPlan;
 			if (!pl) continue;
@@ -300,7 +300,7 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 					continue;
 				}
 				fprintf(stderr, "[vkfft_mi355x] %s pass %zu: %-10s kernel=%s variant=%d L=%u threads=%u tile=%u grid=%llu\n", dir ? "inverse" : "forward", i, q.label.c_str(),
-				        kname[q.kernel < 13 ? q.kernel : 4], q.variant, q.prm.L, q.threads, q.prm.T,
+				        kname[q.kernel < 14 ? q.kernel : 4], q.variant, q.prm.L, q.threads, q.prm.T,
 				        (unsigned long long)q.prm.tilesPerG0 * q.prm.dim[1].count * q.prm.dim[2].count);
 			}
 		}

@@ -12,7 +12,7 @@ namespace vkfft_mi355x {
 
 // ROLE_TEMP2: a second scratch region behind ROLE_TEMP in the same allocation, for plans that wrap an inner plan which uses ROLE_TEMP itself
 enum BufRole : int { ROLE_BUFFER = 0, ROLE_TEMP = 1, ROLE_INPUT = 2, ROLE_OUTPUT = 3, ROLE_TEMP2 = 4 };
-enum KernelKind : int { KERNEL_GENERIC = 0, KERNEL_POW2_ROW = 1, KERNEL_POW2_COL = 2, KERNEL_R2C_PAIR = 3, KERNEL_MIXED_ROW = 5, KERNEL_OPFFT = 6, KERNEL_POW2_BLUE = 7, KERNEL_POW2_COL_BLUE = 8, KERNEL_POW2_BLUE_R2R = 9, KERNEL_POW2_FUSED = 10, KERNEL_TRANSPOSE = 11, KERNEL_REAL_MAP = 12 };
+enum KernelKind : int { KERNEL_GENERIC = 0, KERNEL_POW2_ROW = 1, KERNEL_POW2_COL = 2, KERNEL_R2C_PAIR = 3, KERNEL_MIXED_ROW = 5, KERNEL_OPFFT = 6, KERNEL_POW2_BLUE = 7, KERNEL_POW2_COL_BLUE = 8, KERNEL_POW2_BLUE_R2R = 9, KERNEL_POW2_FUSED = 10, KERNEL_TRANSPOSE = 11, KERNEL_REAL_MAP = 12, KERNEL_MIXCONV = 13 };
 
 struct HostDim {
 	uint64_t count;
@@ -126,6 +126,10 @@ bool pow2_fused_lookup(uint32_t log2n, bool dp, int mode, int* variant, int* la,
 int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t stream);
 bool mixed_row_lookup(uint64_t n, bool dp, int* variant, int rad[5], int* fpw, int* threads);
 int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
+// one-kernel cyclic convolution (kernel_mixconv.h), unit-stride rows or (col) tiles of neighbouring columns of a strided axis.  rader: the instance of prime p (transform length p - 1); otherwise the Bluestein instance with
+// the smallest padded length >= minLen.  *len = transform length
+bool mixconv_lookup(bool rader, bool col, uint64_t pOrMinLen, bool dp, int* variant, uint64_t* len, int rad[5], int* fpw, int* threads);
+int launch_mixconv(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 // op-FFT family (kernel_opfft.h): pre/post are the DCT member of their family (DST variants share the instance)
 bool opfft_lookup(uint64_t n, bool dp, bool col, bool trans, uint32_t pre, uint32_t post, int* variant, int rad[5], int* fpw, int* threads); // trans: column tile in, transposed (per-column contiguous) store out
 int launch_opfft(const PassPlan& pp, const PassParams& prm, hipStream_t stream);

@@ -1,0 +1,189 @@
+// Cyclic convolution through a mixed-radix transform pair in ONE kernel: rows and strided axes whose length has a prime factor above 13.
+//   BLUESTEIN (RADER = 0): x[j] conj(chirp[j]), zero padded to M -> FFT_M -> * FFT(chirp)/M -> inverse FFT_M -> * conj(chirp[k]), k < n, for ANY
+//     13-smooth padded length M >= 2n-1 (the power-of-two form is pow2_blue_kernel; the reference picks its padded length from the same kind of
+//     list, vkFFT_Scheduler.h:2406-2578, and runs the two transforms as separate kernels, vkFFT_Bluestein.h:32,201).
+//   RADER (RADER = 1): a prime length p with 13-smooth p-1.  With g a primitive root, X[g^-q] = x[0] + sum_a x[g^a] w^(g^(a-q)): a cyclic convolution
+//     of length L = p-1 EXACTLY — no chirp, no padding, half the points of the Bluestein form or less (reference: the FFT-Rader stage of
+//     vkFFT_RaderKernels.h:1278, generator tables of vkFFT_RecursiveFFTGenerators.h:1021-1048).
+// Structure: the compile-time radix schedule and the single padded LDS exchange buffer of kernel_mixed.h; the transform's first stage takes its inputs
+// from a functor and its last stage hands its outputs to one.  A second LDS row per transform carries the row between the phases: (Rader) the row as it
+// arrives, read through the generator permutation; the spectrum times the kernel spectrum, written in natural order by the forward transform's last
+// stage and read by the inverse transform's first stage; (Rader) the result, scattered through the inverse permutation so that the global store is as
+// coalesced as the load.  The inverse transform is the forward one between two re/im swaps.
+#pragma once
+#include "engine.h"
+#include "butterflies.h"
+#include "memops.h"
+#include "mix_sched.h"
+
+namespace vkfft_mi355x {
+
+// LS / PADDED: the exchange buffer of a row transform is dense with a per-exchange padding (MixPad); a column tile interleaves its FPW columns
+// (element pitch LS = FPW + 1, lanes along the columns: conflict-free without padding).
+// SF / SL: in() reads / out() writes the exchange buffer itself (the carrier row of the convolution lives there between the phases).
+// one transform of SCH::N points: in(t, c) delivers input t + c, out(t, c, v) receives output t + c (natural order on both sides); t is the lane's
+// butterfly index, c a compile-time multiple of the butterfly count / stride (so that c can ride in the scalar offset of a buffer access)
+template <typename T, typename SCH, int SI, int TPF, int LS, bool PADDED, bool SF, bool SL, typename IN, typename OUT>
+__device__ inline void mc_stage(cx<T>* ldsf, const GBuf glut, const uint32_t tau, const bool waveOnly, const IN& in, const OUT& out) {
+	constexpr int N = SCH::N, R = SCH::rad[SI], NB = N / R, P = (NB + TPF - 1) / TPF, S = SCH::S(SI);
+	constexpr bool first = SI == 0, last = SI == SCH::NS - 1;
+	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
+	using PAD = MixPad<SCH, TPF, (int)sizeof(cx<T>)>;
+	cx<T> x[P][R];
+#pragma unroll
+	for (int b = 0; b < P; b++) {
+		const uint32_t t = tau + b * TPF;
+		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
+#pragma unroll
+			for (int i = 0; i < R; i++) {
+				if constexpr (first) x[b][i] = in(t, (uint32_t)(i * NB));
+				else x[b][i] = ldsf[mix_slot<PADDED ? PAD::shift(SI - 1) : 0>(t + i * NB) * LS];
+			}
+		}
+	}
+	// every input is in registers before the buffer is overwritten: middle stages always; the first stage when in() reads the buffer (SF), the last
+	// stage when out() writes it (SL)
+	if constexpr ((!first && !last) || (first && SF) || (last && SL)) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); }
+#pragma unroll
+	for (int b = 0; b < P; b++) {
+		const uint32_t t = tau + b * TPF;
+		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
+			const uint32_t s = t % (uint32_t)S;
+			if constexpr (!first) {
+				constexpr int LO = SCH::lutOff(SI);
+#pragma unroll
+				for (int i = 1; i < R; i++) x[b][i] = cmul(x[b][i], gb_load<T>(glut, s * ES, (uint32_t)(LO + (i - 1) * S) * ES));
+			}
+			dft<R, T>(x[b]);
+			if constexpr (last) {
+#pragma unroll
+				for (int k = 0; k < R; k++) out(t, (uint32_t)(k * S), x[b][k]); // last stage: s = t
+			} else {
+				const uint32_t ob = (t - s) * (uint32_t)R + s;
+#pragma unroll
+				for (int k = 0; k < R; k++) ldsf[mix_slot<PADDED ? PAD::shift(SI) : 0>(ob + k * S) * LS] = x[b][k];
+			}
+		}
+	}
+	if constexpr (!last) {
+		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
+		mc_stage<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, LS, PADDED, SF, SL>(ldsf, glut, tau, waveOnly, in, out);
+	}
+}
+
+// lut = stage twiddles of SCH; aux2 = FFT of the convolution kernel / L, natural order; Bluestein: aux = chirp (opN entries), opN = n;
+// Rader: rader = uint32 g^a mod p (a < L) followed by g^-k mod p (k < L).
+// COL = 0: FPW unit-stride rows per workgroup, TPF threads each.  COL = 1: a tile of FPW neighbouring columns of a strided axis, lanes along the
+// columns (every global access is an FPW-element segment), element j of column c at j*inStrideJ + c*dim[0].inStride.
+template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL>
+__global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) {
+	constexpr int L = SCH::N, NT = TPF * FPW;
+	constexpr int LS = COL ? FPW + 1 : 1;                 // LDS pitch between consecutive elements of one transform
+	// ONE buffer per transform: the exchange buffer of the stages, which between the phases carries the row in natural order (Rader: the row as it
+	// arrives; the spectrum times the kernel spectrum; Rader: the result before the coalesced store)
+	constexpr int EXPF = SCH::NS > 1 ? (COL ? L : MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems()) : 1;
+	constexpr int SPN = L + (RADER ? 1 : 0);
+	constexpr int SP = COL ? (EXPF > SPN ? EXPF : SPN) : ((EXPF > SPN ? EXPF : SPN) | 1); // rows of a tile: odd pitch
+	constexpr int EXN = COL ? SP * LS : FPW * SP;
+	constexpr bool waveOnly = COL ? NT <= 64 : ((TPF <= 64) && (64 % TPF == 0)); // a transform never straddles wavefronts
+	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
+	static_assert((size_t)(EXN + FPW) * sizeof(cx<T>) <= 160 * 1024, "LDS");
+	__shared__ cx<T> lds[EXN];
+	cx<T>* const rows = lds;
+	__shared__ cx<T> sDc[FPW];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t f = COL ? tid % FPW : tid / TPF, tau = COL ? tid / FPW : tid % TPF;
+	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+	const uint32_t tile = wg % p.tilesPerG0;
+	wg /= p.tilesPerG0;
+	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
+	const uint32_t f0 = tile * FPW;
+	const bool valid = f0 + f < p.dim[0].count;
+	const GBuf gin = make_gbuf((const cx<T>*)p.in + ((int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride));
+	const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride));
+	const GBuf glut = make_gbuf(p.lut), gbh = make_gbuf(p.aux2);
+	// element j of this thread's transform: byte offset laneIn + j*sJin (rows: sJin = ES); guarded by `valid` at every use
+	const uint32_t sJin = COL ? (uint32_t)p.inStrideJ * ES : ES, sJout = COL ? (uint32_t)p.outStrideJ * ES : ES;
+	const uint32_t laneIn = (f * (uint32_t)p.dim[0].inStride) * ES, laneOut = (f * (uint32_t)p.dim[0].outStride) * ES;
+	cx<T>* const ex = COL ? lds + f : lds + f * SP;
+	cx<T>* const row = ex;
+	const bool swI = p.bluesteinSwapIn != 0, swO = p.bluesteinSwapOut != 0;
+	const T sc = (T)p.scale;
+	auto fsync = [&]() { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); };
+	auto fromRow = [&](uint32_t t, uint32_t c) -> cx<T> { return row[(t + c) * LS]; };
+
+	if constexpr (RADER) {
+		constexpr uint32_t n = (uint32_t)L + 1u;
+		const uint32_t* const gp = (const uint32_t*)p.rader;
+		const uint32_t rowsHere = p.dim[0].count - f0 < (uint32_t)FPW ? p.dim[0].count - f0 : (uint32_t)FPW;
+		const bool denseIn = !COL && p.dim[0].inStride == (int64_t)n, denseOut = !COL && p.dim[0].outStride == (int64_t)n;
+		// ---- the row as it lies in memory -> LDS (dense rows: the tile is one contiguous run)
+		if (denseIn) {
+			for (uint32_t e = tid; e < rowsHere * n; e += (uint32_t)NT) {
+				const cx<T> v = gb_load<T>(gin, e * ES, 0);
+				rows[(e / n) * SP + e % n] = swI ? cswap(v) : v;
+			}
+		} else {
+			for (uint32_t j = tau; j < n; j += (uint32_t)TPF) {
+				const cx<T> v = gb_load<T>(gin, valid ? laneIn + j * sJin : kGbInvalid, 0);
+				row[j * LS] = swI ? cswap(v) : v;
+			}
+		}
+		VKFFT_SYNC();
+		const cx<T> x0 = row[0];
+		// ---- forward transform of x[g^a]; spectrum * FFT(w^(g^-q)) / L, + x0 on the zero frequency (= x0 added to every output)
+		mc_stage<T, SCH, 0, TPF, LS, !COL, true, true>(ex, glut, tau, waveOnly, [&](uint32_t t, uint32_t c) -> cx<T> { return row[gp[t + c] * LS]; },
+		                                   [&](uint32_t t, uint32_t c, cx<T> v) {
+			                                   const uint32_t k = t + c;
+			                                   cx<T> w = cmul(v, gb_load<T>(gbh, t * ES, c * ES));
+			                                   if (k == 0u) { sDc[f] = cadd(x0, v); w = cadd(w, x0); } // X[0] = x0 + sum of the others
+			                                   row[k * LS] = cswap(w);
+		                                   });
+		fsync();
+		// ---- inverse transform; result q belongs to output index g^-q
+		mc_stage<T, SCH, 0, TPF, LS, !COL, true, true>(ex, glut, tau, waveOnly, fromRow, [&](uint32_t t, uint32_t c, cx<T> v) { row[gp[(uint32_t)L + t + c] * LS] = cswap(v); });
+		VKFFT_SYNC();
+		auto fin = [&](cx<T> v) { if (swO) v = cswap(v); if (sc != (T)1) v = cscale(v, sc); return v; };
+		if (denseOut) {
+			for (uint32_t e = tid; e < rowsHere * n; e += (uint32_t)NT) {
+				const uint32_t r = e / n, j = e % n;
+				gb_store<T>(gout, e * ES, 0, fin(j == 0u ? sDc[r] : rows[r * SP + j]));
+			}
+		} else {
+			for (uint32_t j = tau; j < n; j += (uint32_t)TPF) gb_store<T>(gout, valid ? laneOut + j * sJout : kGbInvalid, 0, fin(j == 0u ? sDc[f] : row[j * LS]));
+		}
+	} else {
+		const uint32_t n = p.opN;
+		const GBuf gch = make_gbuf(p.aux);
+		mc_stage<T, SCH, 0, TPF, LS, !COL, false, true>(ex, glut, tau, waveOnly,
+		                                   [&](uint32_t t, uint32_t c) -> cx<T> {
+			                                   const bool in = t + c < n; // the rest is the zero padding: nothing is read
+			                                   cx<T> v = gb_load<T>(gin, in && valid ? laneIn + t * sJin : kGbInvalid, c * sJin);
+			                                   if (swI) v = cswap(v);
+			                                   return cmulc(v, gb_load<T>(gch, in ? t * ES : kGbInvalid, c * ES));
+		                                   },
+		                                   [&](uint32_t t, uint32_t c, cx<T> v) { row[(t + c) * LS] = cswap(cmul(v, gb_load<T>(gbh, t * ES, c * ES))); });
+		fsync();
+		mc_stage<T, SCH, 0, TPF, LS, !COL, true, false>(ex, glut, tau, waveOnly, fromRow, [&](uint32_t t, uint32_t c, cx<T> v) {
+			if (t + c < n) {
+				cx<T> y = cmulc(cswap(v), gb_load<T>(gch, t * ES, c * ES));
+				if (swO) y = cswap(y);
+				if (sc != (T)1) y = cscale(y, sc);
+				gb_store<T>(gout, valid ? laneOut + t * sJout : kGbInvalid, c * sJout, y);
+			}
+		});
+	}
+}
+
+// ---- registry ---------------------------------------------------------------------------------------------------
+struct MixConvVariant {
+	int l; bool dp; int rader; int col; int rad[5]; int tpf; int fpw;
+	void (*launch)(const PassParams&, dim3, hipStream_t);
+};
+template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> void mixconv_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
+	hipLaunchKernelGGL((mixconv_kernel<T, SCH, TPF, FPW, RADER, COL>), grid, dim3(TPF * FPW), 0, s, prm);
+}
+#define VKFFT_MC(T, dp, rader, col, r0, r1, r2, r3, r4, tpf, fpw) \
+	{ (r0) * (r1) * (r2) * (r3) * (r4), dp, rader, col, {r0, r1, r2, r3, r4}, tpf, fpw, &mixconv_launch<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, rader, col> },
+
+} // namespace vkfft_mi355x

@@ -5,6 +5,7 @@
 #include "kernel_pow2.h"
 #include "kernel_opfft.h"
 #include "kernel_mixed.h"
+#include "kernel_mixconv.h"
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -36,6 +37,8 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 		return launch_pow2_blue_r2r(pp, prm, stream);
 	case KERNEL_MIXED_ROW:
 		return launch_mixed(pp, prm, stream);
+	case KERNEL_MIXCONV:
+		return launch_mixconv(pp, prm, stream);
 	case KERNEL_OPFFT:
 		return launch_opfft(pp, prm, stream);
 	case KERNEL_R2C_PAIR: {
@@ -95,6 +98,50 @@ int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream) 
 	if (grid64 == 0) return 0;
 	int cnt = 0;
 	const MixedVariant* tab = mixed_part((pp.variant >> 16) % kMixedParts, &cnt);
+	const int idx = pp.variant & 0xffff;
+	if (grid64 > 0x7fffffffull || pp.variant < 0 || idx >= cnt) return 4039;
+	tab[idx].launch(prm, dim3((uint32_t)grid64), stream);
+	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
+
+// ---- one-kernel cyclic convolution registry: six table parts (kernels_mixconv_*.hip) ---------------------------------
+constexpr int kMixConvParts = 6;
+const MixConvVariant* mixconv_table_0(int*);
+const MixConvVariant* mixconv_table_1(int*);
+const MixConvVariant* mixconv_table_2(int*);
+const MixConvVariant* mixconv_table_3(int*);
+const MixConvVariant* mixconv_table_4(int*);
+const MixConvVariant* mixconv_table_5(int*);
+static const MixConvVariant* mixconv_part(int part, int* count) {
+	typedef const MixConvVariant* (*Fn)(int*);
+	static const Fn fns[kMixConvParts] = {&mixconv_table_0, &mixconv_table_1, &mixconv_table_2, &mixconv_table_3, &mixconv_table_4, &mixconv_table_5};
+	return fns[part % kMixConvParts](count);
+}
+bool mixconv_lookup(bool rader, bool col, uint64_t pOrMinLen, bool dp, int* variant, uint64_t* len, int rad[5], int* fpw, int* threads) {
+	const MixConvVariant* best = nullptr;
+	int bestId = -1;
+	for (int part = 0; part < kMixConvParts; part++) {
+		int cnt = 0;
+		const MixConvVariant* tab = mixconv_part(part, &cnt);
+		for (int i = 0; i < cnt; i++) {
+			const MixConvVariant& v = tab[i];
+			if (v.dp != dp || (v.rader != 0) != rader || (v.col != 0) != col) continue;
+			if (rader ? (uint64_t)v.l + 1 != pOrMinLen : (uint64_t)v.l < pOrMinLen) continue;
+			if (best && best->l <= v.l) continue;
+			best = &v; bestId = (part << 16) | i;
+		}
+	}
+	if (!best) return false;
+	*variant = bestId; *len = (uint64_t)best->l;
+	for (int k = 0; k < 5; k++) rad[k] = best->rad[k];
+	*fpw = best->fpw; *threads = best->tpf * best->fpw;
+	return true;
+}
+int launch_mixconv(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
+	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
+	if (grid64 == 0) return 0;
+	int cnt = 0;
+	const MixConvVariant* tab = mixconv_part((pp.variant >> 16) % kMixConvParts, &cnt);
 	const int idx = pp.variant & 0xffff;
 	if (grid64 > 0x7fffffffull || pp.variant < 0 || idx >= cnt) return 4039;
 	tab[idx].launch(prm, dim3((uint32_t)grid64), stream);

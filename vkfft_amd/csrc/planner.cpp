@@ -910,6 +910,75 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		int v, bits[4], tc, thr;
 		if (pow2_col_blue_lookup(ilog2(Mp), dp, 5, &v, bits, &tc, &thr)) fusedM = Mp;
 	}
+	// ... or the one-kernel cyclic convolution on a smooth transform length (kernel_mixconv.h), unit-stride rows and tiles of neighbouring columns of a
+	// strided axis: Rader for a prime with 13-smooth p-1 (p-1 points, no padding), Bluestein on the smallest ladder length >= 2N-1.  Against the
+	// register-resident power-of-two kernels a point of these costs kCostRader / kCostBlue times as much (an LDS round trip more per transform, table
+	// look-ups through L2); VKFFT_MI355X_MIXCONV=0 turns the family off, =2 always prefers it (tests, tuning)
+	struct { bool use = false, rader = false, col = false; int variant = -1; uint64_t len = 0; int rad[5] = {1, 1, 1, 1, 1}; int fpw = 0, thr = 0; } mc;
+	const bool colTile = !unit && !j.others.empty() && j.others[0].inStride == 1 && j.others[0].outStride == 1;
+	if ((unit || colTile) && !padded && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && (!smooth13(j.N) || (unit && smoothNoInstance))) {
+		const int mode = getenv("VKFFT_MI355X_MIXCONV") ? atoi(getenv("VKFFT_MI355X_MIXCONV")) : 1; // (read per plan: tests switch it)
+		// measured (tools/tune_mixconv.py, profiles/r03_mixconv_*): time per point relative to the power-of-two kernels
+		const double kCostRader = getenv("VKFFT_MI355X_MIXCONV_COST_RADER") ? atof(getenv("VKFFT_MI355X_MIXCONV_COST_RADER")) : 1.9;
+		const double kCostBlue = getenv("VKFFT_MI355X_MIXCONV_COST_BLUE") ? atof(getenv("VKFFT_MI355X_MIXCONV_COST_BLUE")) : 1.6;
+		const double kPow2Big = 1.9; // the power-of-two kernel at its longest padded length (128 KiB per row, one workgroup per CU) costs that much more per point
+		const uint64_t esz = dp ? 16 : 8;
+		bool spanOK;
+		if (unit) {
+			const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
+			spanOK = (rowPitch * 64 + j.N) * esz < 0x7FFFFF00ull;
+		} else spanOK = (2 * j.N * (uint64_t)std::max<int64_t>(std::llabs(j.inStrideJ), std::llabs(j.outStrideJ)) + 64) * esz < 0x7FFFFF00ull;
+		if (mode && spanOK) {
+			double best = fusedM && mode < 2 ? (double)fusedM * (fusedM * esz >= (128ull << 10) ? kPow2Big : 1.0) : 1e300;
+			int v, r5[5], f, t; uint64_t len;
+			if (is_prime_u(j.N) && mixconv_lookup(true, !unit, j.N, dp, &v, &len, r5, &f, &t) && kCostRader * (double)len < best) {
+				best = kCostRader * (double)len;
+				mc.use = true; mc.rader = true; mc.variant = v; mc.len = len; mc.fpw = f; mc.thr = t; for (int k = 0; k < 5; k++) mc.rad[k] = r5[k];
+			}
+			if (mixconv_lookup(false, !unit, 2 * j.N - 1, dp, &v, &len, r5, &f, &t) && kCostBlue * (double)len < best) {
+				best = kCostBlue * (double)len;
+				mc.use = true; mc.rader = false; mc.variant = v; mc.len = len; mc.fpw = f; mc.thr = t; for (int k = 0; k < 5; k++) mc.rad[k] = r5[k];
+			}
+			mc.col = !unit;
+		}
+	}
+	if (mc.use) {
+		const uint64_t N = j.N;
+		b.L = mc.len; b.inLen = b.outLen = (uint32_t)N; b.opN = (uint32_t)N;
+		for (int k = 0; k < 5; k++) if (mc.rad[k] > 1) b.radices.push_back((uint32_t)mc.rad[k]);
+		b.fastKernel = KERNEL_MIXCONV; b.fastVariant = mc.variant; b.fastThreads = mc.thr; b.forceT = (uint32_t)mc.fpw;
+		b.bsSwapIn = b.bsSwapOut = j.inverse; b.scale = j.scale;
+		b.inStrideJ = j.inStrideJ; b.outStrideJ = j.outStrideJ; b.dims = j.others;
+		b.colIn = b.colOut = mc.col;
+		size_t tabOff = (size_t)-1;
+		if (mc.rader) {
+			// generator tables g^a, g^-k mod N and FFT of b_q = exp(-2 pi i g^-q / N) scaled by 1/L (vkFFT_RecursiveFFTGenerators.h:1021-1048)
+			const uint64_t L = N - 1, g = primitive_root(N), gi = powmod(g, N - 2, N);
+			tabOff = ar.alloc(2 * (size_t)L * sizeof(uint32_t));
+			std::vector<cld> bk(L);
+			{
+				uint32_t* tab = (uint32_t*)(ar.b.data() + tabOff);
+				uint64_t gp = 1, gm = 1;
+				for (uint64_t q = 0; q < L; q++) { tab[q] = (uint32_t)gp; tab[L + q] = (uint32_t)gm; bk[q] = unit_root(gm, N); gp = gp * g % N; gm = gm * gi % N; }
+			}
+			host_fft(bk);
+			const size_t bhatOff = ar.alloc(L * (dp ? 16 : 8));
+			for (uint64_t m = 0; m < L; m++) ar.putc(bhatOff, m, bk[m] / (ld)L, dp);
+			b.aux2Off = bhatOff;
+			b.label = "rader";
+		} else {
+			size_t chirpOff, bhatOff;
+			make_bluestein_tables(N, mc.len, dp, ar, chirpOff, bhatOff);
+			b.preOp = OP_BLUESTEIN_PRE; b.midOp = OP_BLUESTEIN_MID; b.postOp = OP_BLUESTEIN_POST;
+			b.auxOff = chirpOff; b.aux2Off = bhatOff;
+			b.label = "bluestein";
+		}
+		PassPlan pp; int r = finish_pass(b, ar, pp); if (r) return r;
+		pp.raderOff = tabOff;
+		passes.push_back(pp);
+		out.uploadsPerAxis[j.axisIndex] = 1;
+		return 0;
+	}
 	if (!unit && !padded && !fusedM && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !j.others.empty() && j.others.size() <= 3
 	    && j.others[0].inStride == 1 && j.others[0].outStride == 1 && j.inStrideJ > 0 && j.outStrideJ > 0) {
 		// a strided axis of non-smooth length beyond the reach of the column Bluestein kernel (padded length above 2048): transpose it against its
