@@ -87,8 +87,8 @@ def sizes():
         if n & (n - 1) and smooth(n, (2, 3, 5, 7, 11, 13)): s.add(n)
     s.update([1001, 1287, 7000])
     s.update(DIRECT_PRIMES)
-    # lengths whose largest prime factor is 17 .. 31 (the direct butterflies as radices of a mixed schedule): up to 2048 (fp64: 1024, see main)
-    for n in range(34, 2049):
+    # lengths whose largest prime factor is 17 .. 31 (the direct butterflies as radices of a mixed schedule): up to 4096 (fp64: 1024, see main)
+    for n in range(34, 4097):
         m = n
         for q in (2, 3, 5, 7, 11, 13) + tuple(DIRECT_PRIMES):
             while m % q == 0: m //= q

@@ -890,9 +890,9 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		smoothNoInstance = !mixed_row_lookup(j.N, dp, &v, r5, &f, &t);
 	}
 	// lengths with a direct prime butterfly (17 .. 31: tools/gen_mixed_table.py DIRECT_PRIMES) among their radices stay on the radix kernels where an
-	// instance exists (rows: every such length up to 2048; strided axes: the pure primes)
+	// instance exists (rows: every such length up to 4096; strided axes: the pure primes)
 	bool nativeInstance = false;
-	if (!d.disableFastKernels && !smooth13(j.N) && j.N <= 2048) {
+	if (!d.disableFastKernels && !smooth13(j.N) && j.N <= 4096) {
 		int v, r5[5], f, t;
 		nativeInstance = unit ? mixed_row_lookup(j.N, dp, &v, r5, &f, &t) : opfft_lookup(j.N, dp, true, false, OP_NONE, OP_NONE, &v, r5, &f, &t);
 	}
