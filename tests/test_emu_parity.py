@@ -425,7 +425,7 @@ def test_one_kernel_cyclic_convolution_is_chosen(run, monkeypatch):
             app.delete()
 
 
-@pytest.mark.parametrize("shape", [(37, 37), (6, 73), (40, 47), (3, 547), (5, 1009), (12, 257, 3), (67, 67, 2)])
+@pytest.mark.parametrize("shape", [(37, 37), (6, 73), (40, 47), (3, 547), (5, 1009), (12, 257, 3), (67, 67, 2), (37, 41, 3), (33, 37, 37)])
 @pytest.mark.parametrize("dp", [False, True])
 def test_one_kernel_cyclic_convolution_columns(run, oracle, shape, dp, monkeypatch):
     """strided axes: tiles of neighbouring columns (Rader primes 37, 73, 257, 547, 1009; Bluestein on a smooth length for 47), partial tiles"""

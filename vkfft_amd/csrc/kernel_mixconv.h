@@ -96,15 +96,29 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
-	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
+	const bool merge = COL && p.colMerge != 0;
+	const uint32_t g1 = merge ? 0u : wg % p.dim[1].count, g2 = merge ? wg : wg / p.dim[1].count;
 	const uint32_t f0 = tile * FPW;
-	const bool valid = f0 + f < p.dim[0].count;
-	const GBuf gin = make_gbuf((const cx<T>*)p.in + ((int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride));
-	const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride));
 	const GBuf glut = make_gbuf(p.lut), gbh = make_gbuf(p.aux2);
 	// element j of this thread's transform: byte offset laneIn + j*sJin (rows: sJin = ES); guarded by `valid` at every use
 	const uint32_t sJin = COL ? (uint32_t)p.inStrideJ * ES : ES, sJout = COL ? (uint32_t)p.outStrideJ * ES : ES;
-	const uint32_t laneIn = (f * (uint32_t)p.dim[0].inStride) * ES, laneOut = (f * (uint32_t)p.dim[0].outStride) * ES;
+	bool valid;
+	uint32_t laneIn, laneOut;
+	int64_t baseIn = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride, baseOut = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride;
+	if (merge) {
+		// column g = f0 + f of the merged index space: (g % c0) along dim[0], (g / c0) along dim[1]; the tile's first dim[1] index goes into the (uniform) base
+		const uint32_t c0 = p.dim[0].count, q0 = f0 / c0, g = f0 + f, q = g / c0, r = g - q * c0;
+		valid = q < p.dim[1].count;
+		baseIn += (int64_t)q0 * p.dim[1].inStride; baseOut += (int64_t)q0 * p.dim[1].outStride;
+		laneIn = (uint32_t)((int64_t)r * p.dim[0].inStride + (int64_t)(q - q0) * p.dim[1].inStride) * ES;
+		laneOut = (uint32_t)((int64_t)r * p.dim[0].outStride + (int64_t)(q - q0) * p.dim[1].outStride) * ES;
+	} else {
+		valid = f0 + f < p.dim[0].count;
+		baseIn += (int64_t)f0 * p.dim[0].inStride; baseOut += (int64_t)f0 * p.dim[0].outStride;
+		laneIn = (f * (uint32_t)p.dim[0].inStride) * ES; laneOut = (f * (uint32_t)p.dim[0].outStride) * ES;
+	}
+	const GBuf gin = make_gbuf((const cx<T>*)p.in + baseIn);
+	const GBuf gout = make_gbuf((cx<T>*)p.out + baseOut);
 	cx<T>* const ex = COL ? lds + f : lds + f * SP;
 	cx<T>* const row = ex;
 	const bool swI = p.bluesteinSwapIn != 0, swO = p.bluesteinSwapOut != 0;

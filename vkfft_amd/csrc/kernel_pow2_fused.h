@@ -119,6 +119,7 @@ pow2_fused_kernel(const FusedParams p) {
 	constexpr int AUX_SC = 16;                   // ring loads: agent scope, served from the memory side
 	constexpr int AUX_ST = (MODE & 32) ? 0 : 16;  // ring stores: write-through (no XCD's L2 ever holds a ring line); (development, MODE bit 5: plain — wrong across XCDs, timing only)
 	constexpr int AUX_HBM = (MODE & 2) ? 2 : 0;
+	constexpr int AUX_HBM_LD = (MODE & 128) ? 0 : AUX_HBM, AUX_HBM_ST = (MODE & 64) ? 0 : AUX_HBM; // (development: the hint on one side only)
 	constexpr int LDSN = LA * TCPA > LB * TCPB ? LA * TCPA : LB * TCPB;
 	constexpr int LUTA = TWL ? SA::lutTotal() : 0, LUTB = TWL ? SB::lutTotal() : 0;
 	__shared__ cx<T> lds[LDSN + LUTA + LUTB];
@@ -213,8 +214,8 @@ pow2_fused_kernel(const FusedParams p) {
 				cx<T> v[CPT * EA];
 #pragma unroll
 				for (int m = 0; m < EA; m++) {
-					if constexpr (CPT == 1) v[m] = gb_load_x<T, AUX_HBM>(gin, laneIn, m * stepIn);
-					else gb_load2_x<T, AUX_HBM>(gin, laneIn, m * stepIn, v[m], v[EA + m]);
+					if constexpr (CPT == 1) v[m] = gb_load_x<T, AUX_HBM_LD>(gin, laneIn, m * stepIn);
+					else gb_load2_x<T, AUX_HBM_LD>(gin, laneIn, m * stepIn, v[m], v[EA + m]);
 				}
 				VKFFT_VMEM_DRAIN(); // this tile's loads have landed, the previous ticket's stores are acknowledged, the next ticket is here
 				if (tid == 0) {
@@ -300,8 +301,8 @@ pow2_fused_kernel(const FusedParams p) {
 				}
 #pragma unroll
 				for (int m = 0; m < EB; m++) {
-					if constexpr (CPT == 1) gb_store_x<T, AUX_HBM>(gout, laneB, m * stepB, vB[m]);
-					else gb_store2_x<T, AUX_HBM>(gout, laneB + m * stepB, vB[m], vB[EB + m]);
+					if constexpr (CPT == 1) gb_store_x<T, AUX_HBM_ST>(gout, laneB, m * stepB, vB[m]);
+					else gb_store2_x<T, AUX_HBM_ST>(gout, laneB + m * stepB, vB[m], vB[EB + m]);
 				}
 			}
 		}

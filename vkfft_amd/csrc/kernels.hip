@@ -138,7 +138,7 @@ bool mixconv_lookup(bool rader, bool col, uint64_t pOrMinLen, bool dp, int* vari
 	return true;
 }
 int launch_mixconv(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
-	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
+	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * (prm.colMerge ? 1u : prm.dim[1].count) * prm.dim[2].count;
 	if (grid64 == 0) return 0;
 	int cnt = 0;
 	const MixConvVariant* tab = mixconv_part((pp.variant >> 16) % kMixConvParts, &cnt);

@@ -17,10 +17,11 @@ namespace vkfft_mi355x {
 	  &pow2_fused_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt>, \
 	  (const void*)&pow2_fused_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt>, 1 }
 // mode 2 = product (non-temporal hint on the streamed side); the others exist only in development builds (-DVKFFT_MI355X_DEV):
-// 0 = no hint, 6 = per-phase cycle profile, 8 / 16 / 24 = without the FFT arithmetic / without the ring traffic / without both
+// 0 = no hint, 66 / 130 = hint on the loads / on the stores only, 6 = per-phase cycle profile, 8 / 16 / 24 = without the FFT arithmetic / without the ring traffic / without both
 #if defined(VKFFT_MI355X_DEV)
 #define VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, cpt) \
-	VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 0, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 8, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 16, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 24, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 34, twl, cpt)
+	VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 0, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 8, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 16, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 24, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 34, twl, cpt), \
+	VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 66, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 130, twl, cpt)
 #else
 #define VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, cpt) VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, cpt)
 #endif

@@ -364,6 +364,17 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	const uint64_t padded = p.padShift >= 31 ? b.L : b.L + (b.L >> p.padShift);
 	p.ldsElems = (uint32_t)((padded + 1) * p.Tp);
 	p.tilesPerG0 = (uint32_t)((dims[0].count + T - 1) / T);
+	if (b.fastKernel == KERNEL_MIXCONV && b.colIn && dims[1].count > 1 && dims[0].count % T != 0 && (uint64_t)dims[0].count * dims[1].count < (1ull << 31)) {
+		// column tiles of kernel_mixconv.h over dim[0] x dim[1]: a companion axis that is not a multiple of the tile width (37 columns, tiles of 32) would
+		// leave the last tile of every plane mostly empty
+		const uint64_t esz = dp ? 16 : 8;
+		const uint64_t reach = ((uint64_t)T / dims[0].count + 2) * (uint64_t)std::max<int64_t>(std::llabs(dims[1].inStride), std::llabs(dims[1].outStride))
+		                     + (b.L + 1) * (uint64_t)std::max<int64_t>(std::llabs(b.inStrideJ), std::llabs(b.outStrideJ)) + dims[0].count;
+		if (reach * esz < 0x7FFFFF00ull && dims[1].inStride > 0 && dims[1].outStride > 0) {
+			p.colMerge = 1;
+			p.tilesPerG0 = (uint32_t)(((uint64_t)dims[0].count * dims[1].count + T - 1) / T);
+		}
+	}
 	if (p.rd.P) { p.rd.tailElems = (uint32_t)((b.L / p.rd.P) * T + 1); p.rd.divU = make_fastdiv((uint32_t)((b.L / p.rd.P) * T)); }
 	pp.ldsBytes = (2 * (size_t)p.ldsElems + p.rd.tailElems) * es;
 	if (pp.ldsBytes > b.maxLds && b.fastKernel == KERNEL_GENERIC) return 3002;
