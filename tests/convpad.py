@@ -71,6 +71,8 @@ def conv_case(run, shape, *, m=1, cf=1, nk=1, nb=1, symmetric=False, conjugate=0
     ca = api.App(list(shape), nb, buffer_ptr=pd, coordinateFeatures=nsys, performConvolution=1, matrixConvolution=m, numberKernels=nk,
                  symmetricKernel=int(symmetric), conjugateConvolution=conjugate, crossPowerSpectrumNormalization=int(cross), kernel=pk, **common)
     ca.forward()
+    n_launch, _ = ca.launch_info()  # the extension describes a convolution application as well: forward part, product (merged or separate), inverse part
+    assert n_launch >= 1, n_launch
     got = run._fetch(hd, rt if r2c else ct).reshape(dbuf.shape)
     ka.delete(); ca.delete()
     if r2c:
@@ -220,6 +222,8 @@ def conv_zeropad_case(run, shape, pads, *, m=1, r2c=False, dp=False, seed=0):
     ca = api.App(list(shape), 1, buffer_ptr=pd, coordinateFeatures=nsys, performConvolution=1, matrixConvolution=m, kernel=pk,
                  performZeropadding=flag, fft_zeropad_left=left, fft_zeropad_right=right, **common)
     ca.forward()
+    n_launch, _ = ca.launch_info()  # the extension describes a convolution application as well: forward part, product (merged or separate), inverse part
+    assert n_launch >= 1, n_launch
     got = run._fetch(hd, rt if r2c else ct).reshape(dbuf.shape)
     ka.delete(); ca.delete()
     if r2c:

@@ -89,16 +89,11 @@ VKFFT_API void vkfftMI355XStructSizes(pfUINT out[4]) {
 	out[3] = sizeof(VkFFTApplication);
 }
 
-VKFFT_API int vkfftMI355XDescribePlan(const VkFFTApplication* app, int inverse, char* names, pfUINT cap) {
+static void describe_passes(const VkFFTPlan* pl, char* names, pfUINT cap, size_t& pos, int& launches) {
 	static const char* kname[] = {"generic_pass_kernel", "pow2_row_kernel", "pow2_col_kernel", "r2c_even_pair_kernel", "?", "mixed_row_kernel", "opfft_kernel", "pow2_blue_kernel",
-	                              "pow2_col_blue_kernel", "pow2_blue_r2r_kernel", "pow2_fused_kernel", "transpose_kernel", "real_map_kernel", "mixconv_row_kernel"};
-	if (names && cap) names[0] = 0;
-	if (!app) return 0;
-	const VkFFTPlan* pl = inverse == 1 ? app->localFFTPlan_inverse : app->localFFTPlan;
-	if (!pl || !pl->impl) return 0;
+	                              "pow2_col_blue_kernel", "pow2_blue_r2r_kernel", "pow2_fused_kernel", "transpose_kernel", "real_map_kernel", "mixconv_kernel"};
+	if (!pl || !pl->impl) return;
 	const DirectionPlan* dp = (const DirectionPlan*)pl->impl;
-	size_t pos = 0;
-	int launches = 0;
 	for (const PassPlan& q : dp->passes) {
 		uint64_t rep = 1;
 		for (const HostDim& h : q.hostLoop) rep *= h.count;
@@ -108,6 +103,28 @@ VKFFT_API int vkfftMI355XDescribePlan(const VkFFTApplication* app, int inverse, 
 		int w = snprintf(names + pos, pos < cap ? (size_t)cap - pos : 0, "%s%s<%s>", pos ? "," : "", nm, q.dp ? "double" : "float");
 		if (w > 0) pos = std::min<size_t>(pos + (size_t)w, (size_t)cap - 1);
 	}
+}
+
+VKFFT_API int vkfftMI355XDescribePlan(const VkFFTApplication* app, int inverse, char* names, pfUINT cap) {
+	if (names && cap) names[0] = 0;
+	if (!app) return 0;
+	size_t pos = 0;
+	int launches = 0;
+	const AppState* st = (const AppState*)app->impl;
+	if (st && st->convFwd) {
+		// convolution application: what VkFFTAppend(app, -1) launches — forward transform (without the merged axis), the merged axis or the separate
+		// element-wise product, inverse transform of the results
+		if (inverse == 1) return 0;
+		describe_passes(st->convFwd->localFFTPlan, names, cap, pos, launches);
+		if (st->convMid) describe_passes(st->convMid, names, cap, pos, launches);
+		else {
+			launches += 1;
+			if (names && cap) { int w = snprintf(names + pos, pos < cap ? (size_t)cap - pos : 0, "%sconv_pointwise_kernel", pos ? "," : ""); if (w > 0) pos = std::min<size_t>(pos + (size_t)w, (size_t)cap - 1); }
+		}
+		if (st->convInv) describe_passes(st->convInv->localFFTPlan_inverse, names, cap, pos, launches);
+		return launches;
+	}
+	describe_passes(inverse == 1 ? app->localFFTPlan_inverse : app->localFFTPlan, names, cap, pos, launches);
 	return launches;
 }
 
@@ -287,7 +304,7 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 		}
 	}
 	if (c.printMemoryLayout || getenv("VKFFT_MI355X_PRINT_PLAN")) { // one line per launch: which kernel family serves it
-		static const char* kname[] = {"generic", "pow2_row", "pow2_col", "r2c_pair", "?", "mixed_row", "opfft", "pow2_blue", "pow2_col_blue", "pow2_blue_r2r", "pow2_fused", "transpose", "real_map", "mixconv_row"};
+		static const char* kname[] = {"generic", "pow2_row", "pow2_col", "r2c_pair", "?", "mixed_row", "opfft", "pow2_blue", "pow2_col_blue", "pow2_blue_r2r", "pow2_fused", "transpose", "real_map", "mixconv"};
 		for (int dir = 0; dir < 2; dir++) {
 			VkFFTPlan* pl = dir ? app->localFFTPlan_inverse : app->localFFTPlan;
 			if (!pl) continue;

@@ -374,16 +374,26 @@ __global__ void __launch_bounds__(TPF * FPW) opfft_kernel(const PassParams p) {
 	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
-	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
+	// plain strided C2C: the tile index may run over dim[0] x dim[1] (PassParams::colMerge: companion axes that are not a multiple of the tile width)
+	constexpr bool canMerge = COL && !TRANS && PRE == OP_NONE && POST == OP_NONE;
+	const bool merge = canMerge && p.colMerge != 0;
+	const uint32_t g1 = merge ? 0u : wg % p.dim[1].count, g2 = merge ? wg : wg / p.dim[1].count;
 	const uint32_t f0 = tile * FPW, g0 = f0 + f;
-	const bool valid = g0 < p.dim[0].count;
-	const int64_t inBase = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride;
-	const int64_t outBase = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride;
+	bool valid = g0 < p.dim[0].count;
+	int64_t inBase = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride, outBase = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride;
+	int64_t inLane = (int64_t)f * p.dim[0].inStride, outLane = (int64_t)f * p.dim[0].outStride;
+	if (merge) {
+		const uint32_t c0 = p.dim[0].count, q0 = f0 / c0, q = g0 / c0, r = g0 - q * c0;
+		valid = q < p.dim[1].count;
+		inBase += (int64_t)q0 * p.dim[1].inStride; outBase += (int64_t)q0 * p.dim[1].outStride;
+		inLane = (int64_t)r * p.dim[0].inStride + (int64_t)(q - q0) * p.dim[1].inStride;
+		outLane = (int64_t)r * p.dim[0].outStride + (int64_t)(q - q0) * p.dim[1].outStride;
+	} else { inBase += (int64_t)f0 * p.dim[0].inStride; outBase += (int64_t)f0 * p.dim[0].outStride; }
 	Io32<T> io;
 	io.gin = make_gbuf((const char*)p.in + inBase * (int64_t)p.inElemBytes);
 	io.gout = make_gbuf((char*)p.out + outBase * (int64_t)p.outElemBytes);
-	io.inOff = valid ? f * (uint32_t)p.dim[0].inStride * p.inElemBytes : kGbInvalid;
-	io.outOff = valid ? f * (uint32_t)p.dim[0].outStride * p.outElemBytes : kGbInvalid;
+	io.inOff = valid ? (uint32_t)inLane * p.inElemBytes : kGbInvalid;
+	io.outOff = valid ? (uint32_t)outLane * p.outElemBytes : kGbInvalid;
 	io.inSj = (uint32_t)p.inStrideJ * p.inElemBytes;
 	io.outSj = (uint32_t)p.outStrideJ * p.outElemBytes;
 	io.set_pad(p);

@@ -195,16 +195,26 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
-	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
+	// plain column passes of small systems: the tile index may run over dim[0] x dim[1] (PassParams::colMerge: a companion axis of 16 columns would leave
+	// every 32-column tile half empty)
+	const bool merge = !BIG && p.colMerge != 0;
+	const uint32_t g1 = merge ? 0u : wg % p.dim[1].count, g2 = merge ? wg : wg / p.dim[1].count;
 	const uint32_t col0 = tile * TC;
-	const bool valid = col0 + c < p.dim[0].count;
-	const int64_t inB = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)col0 * p.dim[0].inStride;
-	const int64_t outB = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)col0 * p.dim[0].outStride;
+	bool valid = col0 + c < p.dim[0].count;
+	int64_t inB = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride, outB = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride;
+	uint32_t cIn = c * (uint32_t)p.dim[0].inStride, cOut = c * (uint32_t)p.dim[0].outStride; // this lane's column, in elements from the tile base
+	if (merge) {
+		const uint32_t c0 = p.dim[0].count, q0 = col0 / c0, g = col0 + c, q = g / c0, r = g - q * c0;
+		valid = q < p.dim[1].count;
+		inB += (int64_t)q0 * p.dim[1].inStride; outB += (int64_t)q0 * p.dim[1].outStride;
+		cIn = (uint32_t)((int64_t)r * p.dim[0].inStride + (int64_t)(q - q0) * p.dim[1].inStride);
+		cOut = (uint32_t)((int64_t)r * p.dim[0].outStride + (int64_t)(q - q0) * p.dim[1].outStride);
+	} else { inB += (int64_t)col0 * p.dim[0].inStride; outB += (int64_t)col0 * p.dim[0].outStride; }
 	// wave-uniform tile bases + one 32-bit lane offset per side, uniform step between a thread's elements (memops.h)
 	const GBuf gin = make_gbuf((const cx<T>*)p.in + inB);
 	const GBuf gout = make_gbuf((cx<T>*)p.out + outB);
 	const GBuf glut = make_gbuf(p.lut);
-	const uint32_t laneIn = valid ? (tau * (uint32_t)p.inStrideJ + c * (uint32_t)p.dim[0].inStride) * ES : kGbInvalid;
+	const uint32_t laneIn = valid ? (tau * (uint32_t)p.inStrideJ + cIn) * ES : kGbInvalid;
 	const uint32_t stepIn = (uint32_t)(TPF * (uint32_t)p.inStrideJ) * ES;
 	cx<T> v[E];
 	if constexpr (BIG) {
@@ -238,7 +248,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 		for (int m = 0; m < E; m++) v[m] = cscale(v[m], sc);
 	}
 	if (p.colModeOut) {
-		const uint32_t laneOut = valid ? (tau * (uint32_t)p.outStrideJ + c * (uint32_t)p.dim[0].outStride) * ES : kGbInvalid;
+		const uint32_t laneOut = valid ? (tau * (uint32_t)p.outStrideJ + cOut) * ES : kGbInvalid;
 		const uint32_t stepOut = (uint32_t)(TPF * (uint32_t)p.outStrideJ) * ES;
 		if constexpr (BIG) {
 			cx<T>* pout = (cx<T>*)p.out + (outB + (int64_t)tau * p.outStrideJ + (int64_t)c * p.dim[0].outStride);
@@ -638,7 +648,7 @@ inline int launch_pow2_blue(const PassPlan& pp, const PassParams& prm, hipStream
 }
 
 inline int launch_pow2(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
-	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
+	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * (prm.colMerge ? 1u : prm.dim[1].count) * prm.dim[2].count;
 	if (grid64 == 0) return 0;
 	const bool col = pp.kernel == KERNEL_POW2_COL;
 	if (grid64 > 0x7fffffffull || pp.variant < 0 || pp.variant >= (col ? kNumPow2ColVariants : kNumPow2Variants)) return 4039;

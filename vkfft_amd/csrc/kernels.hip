@@ -13,7 +13,7 @@
 namespace vkfft_mi355x {
 
 int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
-	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
+	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * (prm.colMerge ? 1u : prm.dim[1].count) * prm.dim[2].count;
 	if (grid64 == 0) return 0;
 	if (grid64 > 0x7fffffffull) return 4039;
 	const dim3 grid((uint32_t)grid64), block(pp.threads);
@@ -187,7 +187,7 @@ bool opfft_lookup(uint64_t n, bool dp, bool col, bool trans, uint32_t pre, uint3
 	return false;
 }
 int launch_opfft(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
-	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
+	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * (prm.colMerge ? 1u : prm.dim[1].count) * prm.dim[2].count;
 	if (grid64 == 0) return 0;
 	int cnt = 0;
 	const OpfftVariant* tab = opfft_part(pp.variant >> 16, &cnt);

@@ -364,8 +364,11 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	const uint64_t padded = p.padShift >= 31 ? b.L : b.L + (b.L >> p.padShift);
 	p.ldsElems = (uint32_t)((padded + 1) * p.Tp);
 	p.tilesPerG0 = (uint32_t)((dims[0].count + T - 1) / T);
-	if (b.fastKernel == KERNEL_MIXCONV && b.colIn && dims[1].count > 1 && dims[0].count % T != 0 && (uint64_t)dims[0].count * dims[1].count < (1ull << 31)) {
-		// column tiles of kernel_mixconv.h over dim[0] x dim[1]: a companion axis that is not a multiple of the tile width (37 columns, tiles of 32) would
+	const bool mergeable = (b.fastKernel == KERNEL_MIXCONV && b.colIn) ||
+	                       ((b.fastKernel == KERNEL_OPFFT || (b.fastKernel == KERNEL_POW2_COL && !b.bigSpan)) && b.colIn && b.colOut && b.preOp == OP_NONE && b.midOp == OP_NONE &&
+	                        b.postOp == OP_NONE && !b.realIn && !b.realOut);
+	if (mergeable && dims[1].count > 1 && dims[0].count % T != 0 && dims[0].count < 4 * T && (uint64_t)dims[0].count * dims[1].count < (1ull << 31)) {
+		// column tiles of kernel_mixconv.h and of the plain strided C2C kernels (kernel_opfft.h, pow2_col_kernel) over dim[0] x dim[1]: a companion axis that is not a multiple of the tile width (37 columns, tiles of 32) would
 		// leave the last tile of every plane mostly empty
 		const uint64_t esz = dp ? 16 : 8;
 		const uint64_t reach = ((uint64_t)T / dims[0].count + 2) * (uint64_t)std::max<int64_t>(std::llabs(dims[1].inStride), std::llabs(dims[1].outStride))
