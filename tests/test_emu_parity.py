@@ -431,3 +431,15 @@ def test_one_kernel_cyclic_convolution_columns(run, oracle, shape, dp, monkeypat
     """strided axes: tiles of neighbouring columns (Rader primes 37, 73, 257, 547, 1009; Bluestein on a smooth length for 47), partial tiles"""
     monkeypatch.setenv("VKFFT_MI355X_MIXCONV", "2")
     parity.check_c2c(run, oracle, shape, 2, dp, kind="bluestein")
+
+
+@pytest.mark.parametrize("N", [6, 14, 28, 37, 46, 61, 74, 90, 112, 175, 242, 1001, 1046 // 2 * 2 - 2, 2 * 257])
+@pytest.mark.parametrize("dp", [False, True])
+def test_real_rows_between_the_interpreters_maps_and_an_instance_transform(run, oracle, N, dp):
+    """R2C / C2R and DCT / DST I-IV of lengths whose complex transform has a mixed-radix or Rader instance but no fused-map kernel: the ahead-of-time
+    transform runs between the interpreter's gather-load and gather-store (mixed_row_kernel / mixconv_kernel OPS = 1), one launch"""
+    parity.check_r2c(run, oracle, (N,), 5, dp)
+    for type in (1, 2, 3, 4):
+        parity.check_r2r(run, oracle, (N,), 3, dp, type, False)
+    parity.check_r2r(run, oracle, (N,), 3, dp, 2, True)
+    parity.check_r2r(run, oracle, (N,), 3, dp, 4, True)

@@ -87,6 +87,7 @@ def sizes():
         if n & (n - 1) and smooth(n, (2, 3, 5, 7, 11, 13)): s.add(n)
     s.update([1001, 1287, 7000])
     s.update(DIRECT_PRIMES)
+    s.add(2)  # (the power-of-two row kernels start at 4 points)
     # lengths whose largest prime factor is 17 .. 31 (the direct butterflies as radices of a mixed schedule): up to 4096 (fp64: 1024, see main)
     for n in range(34, 4097):
         m = n

@@ -215,6 +215,8 @@ class App:
 
     def uploads(self, inverse=False):
         pl = self.app.localFFTPlan_inverse if inverse else self.app.localFFTPlan
+        if not pl:  # convolution applications keep their plans in two inner applications; use launch_info()
+            return []
         return [int(pl.contents.numAxisUploads[i]) for i in range(int(self.app.configuration.FFTdim))]
 
     def launch_info(self, inverse=False):

@@ -316,9 +316,9 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 					        q.label.c_str(), q.variant, q.fused.n0, q.fused.n1, q.threads, 1u << q.fused.logG, q.fused.C, q.fused.Q, q.fused.D, q.fused.NS, (double)dpn->tempBytes / 1048576.0);
 					continue;
 				}
-				fprintf(stderr, "[vkfft_mi355x] %s pass %zu: %-10s kernel=%s variant=%d L=%u threads=%u tile=%u grid=%llu\n", dir ? "inverse" : "forward", i, q.label.c_str(),
-				        kname[q.kernel < 14 ? q.kernel : 4], q.variant, q.prm.L, q.threads, q.prm.T,
-				        (unsigned long long)q.prm.tilesPerG0 * q.prm.dim[1].count * q.prm.dim[2].count);
+				fprintf(stderr, "[vkfft_mi355x] %s pass %zu: %-10s kernel=%s variant=%d L=%u threads=%u tile=%u%s grid=%llu\n", dir ? "inverse" : "forward", i, q.label.c_str(),
+				        kname[q.kernel < 14 ? q.kernel : 4], q.variant, q.prm.L, q.threads, q.prm.T, q.prm.colMerge ? " (tiles over two dimensions)" : "",
+				        (unsigned long long)q.prm.tilesPerG0 * (q.prm.colMerge ? 1u : q.prm.dim[1].count) * q.prm.dim[2].count);
 			}
 		}
 	}

@@ -15,68 +15,21 @@
 #include "butterflies.h"
 #include "memops.h"
 #include "mix_sched.h"
+#include "mix_stage.h"
+#include "kernel_generic.h"
 
 namespace vkfft_mi355x {
-
-// LS / PADDED: the exchange buffer of a row transform is dense with a per-exchange padding (MixPad); a column tile interleaves its FPW columns
-// (element pitch LS = FPW + 1, lanes along the columns: conflict-free without padding).
-// SF / SL: in() reads / out() writes the exchange buffer itself (the carrier row of the convolution lives there between the phases).
-// one transform of SCH::N points: in(t, c) delivers input t + c, out(t, c, v) receives output t + c (natural order on both sides); t is the lane's
-// butterfly index, c a compile-time multiple of the butterfly count / stride (so that c can ride in the scalar offset of a buffer access)
-template <typename T, typename SCH, int SI, int TPF, int LS, bool PADDED, bool SF, bool SL, typename IN, typename OUT>
-__device__ inline void mc_stage(cx<T>* ldsf, const GBuf glut, const uint32_t tau, const bool waveOnly, const IN& in, const OUT& out) {
-	constexpr int N = SCH::N, R = SCH::rad[SI], NB = N / R, P = (NB + TPF - 1) / TPF, S = SCH::S(SI);
-	constexpr bool first = SI == 0, last = SI == SCH::NS - 1;
-	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
-	using PAD = MixPad<SCH, TPF, (int)sizeof(cx<T>)>;
-	cx<T> x[P][R];
-#pragma unroll
-	for (int b = 0; b < P; b++) {
-		const uint32_t t = tau + b * TPF;
-		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
-#pragma unroll
-			for (int i = 0; i < R; i++) {
-				if constexpr (first) x[b][i] = in(t, (uint32_t)(i * NB));
-				else x[b][i] = ldsf[mix_slot<PADDED ? PAD::shift(SI - 1) : 0>(t + i * NB) * LS];
-			}
-		}
-	}
-	// every input is in registers before the buffer is overwritten: middle stages always; the first stage when in() reads the buffer (SF), the last
-	// stage when out() writes it (SL)
-	if constexpr ((!first && !last) || (first && SF) || (last && SL)) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); }
-#pragma unroll
-	for (int b = 0; b < P; b++) {
-		const uint32_t t = tau + b * TPF;
-		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
-			const uint32_t s = t % (uint32_t)S;
-			if constexpr (!first) {
-				constexpr int LO = SCH::lutOff(SI);
-#pragma unroll
-				for (int i = 1; i < R; i++) x[b][i] = cmul(x[b][i], gb_load<T>(glut, s * ES, (uint32_t)(LO + (i - 1) * S) * ES));
-			}
-			dft<R, T>(x[b]);
-			if constexpr (last) {
-#pragma unroll
-				for (int k = 0; k < R; k++) out(t, (uint32_t)(k * S), x[b][k]); // last stage: s = t
-			} else {
-				const uint32_t ob = (t - s) * (uint32_t)R + s;
-#pragma unroll
-				for (int k = 0; k < R; k++) ldsf[mix_slot<PADDED ? PAD::shift(SI) : 0>(ob + k * S) * LS] = x[b][k];
-			}
-		}
-	}
-	if constexpr (!last) {
-		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
-		mc_stage<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, LS, PADDED, SF, SL>(ldsf, glut, tau, waveOnly, in, out);
-	}
-}
 
 // lut = stage twiddles of SCH; aux2 = FFT of the convolution kernel / L, natural order; Bluestein: aux = chirp (opN entries), opN = n;
 // Rader: rader = uint32 g^a mod p (a < L) followed by g^-k mod p (k < L).
 // COL = 0: FPW unit-stride rows per workgroup, TPF threads each.  COL = 1: a tile of FPW neighbouring columns of a strided axis, lanes along the
 // columns (every global access is an FPW-element segment), element j of column c at j*inStrideJ + c*dim[0].inStride.
-template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL>
+// OPS = 1 (Rader rows only): the row enters through the interpreter's gather-load and leaves through its gather-store (kernel_generic.h pre_gather /
+// post_store): real transforms whose complex length is a Rader prime (R2C of 2 x 37 points, DCT-II of 61 ...).  The kernel spectrum then comes from aux3
+// (aux / aux2 belong to the real transform's own tables), the swaps are the pass's swapIn / swapOut and post_store applies the scale.
+template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL, int OPS = 0>
 __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) {
+	static_assert(OPS == 0 || (RADER != 0 && COL == 0), "pre / post maps: Rader rows");
 	constexpr int L = SCH::N, NT = TPF * FPW;
 	constexpr int LS = COL ? FPW + 1 : 1;                 // LDS pitch between consecutive elements of one transform
 	// ONE buffer per transform: the exchange buffer of the stages, which between the phases carries the row in natural order (Rader: the row as it
@@ -99,7 +52,7 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 	const bool merge = COL && p.colMerge != 0;
 	const uint32_t g1 = merge ? 0u : wg % p.dim[1].count, g2 = merge ? wg : wg / p.dim[1].count;
 	const uint32_t f0 = tile * FPW;
-	const GBuf glut = make_gbuf(p.lut), gbh = make_gbuf(p.aux2);
+	const GBuf glut = make_gbuf(p.lut), gbh = make_gbuf(OPS ? p.aux3 : p.aux2);
 	// element j of this thread's transform: byte offset laneIn + j*sJin (rows: sJin = ES); guarded by `valid` at every use
 	const uint32_t sJin = COL ? (uint32_t)p.inStrideJ * ES : ES, sJout = COL ? (uint32_t)p.outStrideJ * ES : ES;
 	bool valid;
@@ -121,8 +74,8 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 	const GBuf gout = make_gbuf((cx<T>*)p.out + baseOut);
 	cx<T>* const ex = COL ? lds + f : lds + f * SP;
 	cx<T>* const row = ex;
-	const bool swI = p.bluesteinSwapIn != 0, swO = p.bluesteinSwapOut != 0;
-	const T sc = (T)p.scale;
+	const bool swI = OPS ? p.swapIn != 0 : p.bluesteinSwapIn != 0, swO = OPS ? p.swapOut != 0 : p.bluesteinSwapOut != 0;
+	const T sc = OPS ? (T)1 : (T)p.scale;
 	auto fsync = [&]() { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); };
 	auto fromRow = [&](uint32_t t, uint32_t c) -> cx<T> { return row[(t + c) * LS]; };
 
@@ -132,7 +85,19 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 		const uint32_t rowsHere = p.dim[0].count - f0 < (uint32_t)FPW ? p.dim[0].count - f0 : (uint32_t)FPW;
 		const bool denseIn = !COL && p.dim[0].inStride == (int64_t)n, denseOut = !COL && p.dim[0].outStride == (int64_t)n;
 		// ---- the row as it lies in memory -> LDS (dense rows: the tile is one contiguous run)
-		if (denseIn) {
+		if constexpr (OPS != 0) {
+			const int64_t inB = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride;
+			for (uint32_t idx = tid; idx < (uint32_t)FPW * n; idx += (uint32_t)NT) {
+				const uint32_t fi = idx / n, pos = idx % n;
+				cx<T> v = {(T)0, (T)0};
+				if (fi < rowsHere) {
+					Io64<T> io{p.in, p.out, inB + (int64_t)fi * p.dim[0].inStride, 0, p.inStrideJ, p.outStrideJ};
+					io.set_pad(p);
+					v = pre_gather<T>(p, io, pos, (f0 + fi) * p.opStride0 + g1 * p.opStride1, p.preOp);
+				}
+				rows[fi * SP + pos] = swI ? cswap(v) : v;
+			}
+		} else if (denseIn) {
 			for (uint32_t e = tid; e < rowsHere * n; e += (uint32_t)NT) {
 				const cx<T> v = gb_load<T>(gin, e * ES, 0);
 				rows[(e / n) * SP + e % n] = swI ? cswap(v) : v;
@@ -158,7 +123,19 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 		mc_stage<T, SCH, 0, TPF, LS, !COL, true, true>(ex, glut, tau, waveOnly, fromRow, [&](uint32_t t, uint32_t c, cx<T> v) { row[gp[(uint32_t)L + t + c] * LS] = cswap(v); });
 		VKFFT_SYNC();
 		auto fin = [&](cx<T> v) { if (swO) v = cswap(v); if (sc != (T)1) v = cscale(v, sc); return v; };
-		if (denseOut) {
+		if constexpr (OPS != 0) {
+			const int64_t outB = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride;
+			const uint32_t total = p.outLen * (uint32_t)FPW;
+			for (uint32_t idx = tid; idx < total; idx += (uint32_t)NT) {
+				uint32_t fi, k;
+				p.divOutLen.divmod(idx, fi, k);
+				if (fi >= rowsHere) continue;
+				auto rd = [&](uint32_t a) -> cx<T> { const cx<T> v = a == 0u ? sDc[fi] : rows[fi * SP + a]; return swO ? cswap(v) : v; };
+				Io64<T> io{p.in, p.out, 0, outB + (int64_t)fi * p.dim[0].outStride, p.inStrideJ, p.outStrideJ};
+				io.set_pad(p);
+				post_store<T>(p, io, k, 0u, (f0 + fi) * p.opStride0 + g1 * p.opStride1, rd, p.postOp);
+			}
+		} else if (denseOut) {
 			for (uint32_t e = tid; e < rowsHere * n; e += (uint32_t)NT) {
 				const uint32_t r = e / n, j = e % n;
 				gb_store<T>(gout, e * ES, 0, fin(j == 0u ? sDc[r] : rows[r * SP + j]));
@@ -193,11 +170,17 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 struct MixConvVariant {
 	int l; bool dp; int rader; int col; int rad[5]; int tpf; int fpw;
 	void (*launch)(const PassParams&, dim3, hipStream_t);
+	void (*launchOps)(const PassParams&, dim3, hipStream_t); // Rader rows: the form with the interpreter's pre / post maps (nullptr otherwise)
 };
-template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> void mixconv_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
-	hipLaunchKernelGGL((mixconv_kernel<T, SCH, TPF, FPW, RADER, COL>), grid, dim3(TPF * FPW), 0, s, prm);
+template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL, int OPS> void mixconv_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
+	hipLaunchKernelGGL((mixconv_kernel<T, SCH, TPF, FPW, RADER, COL, OPS>), grid, dim3(TPF * FPW), 0, s, prm);
+}
+template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> constexpr auto mixconv_ops_ptr() -> void (*)(const PassParams&, dim3, hipStream_t) {
+	if constexpr (RADER != 0 && COL == 0) return &mixconv_launch<T, SCH, TPF, FPW, RADER, COL, 1>;
+	else return nullptr;
 }
 #define VKFFT_MC(T, dp, rader, col, r0, r1, r2, r3, r4, tpf, fpw) \
-	{ (r0) * (r1) * (r2) * (r3) * (r4), dp, rader, col, {r0, r1, r2, r3, r4}, tpf, fpw, &mixconv_launch<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, rader, col> },
+	{ (r0) * (r1) * (r2) * (r3) * (r4), dp, rader, col, {r0, r1, r2, r3, r4}, tpf, fpw, &mixconv_launch<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, rader, col, 0>, \
+	  mixconv_ops_ptr<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, rader, col>() },
 
 } // namespace vkfft_mi355x

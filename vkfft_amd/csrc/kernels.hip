@@ -100,7 +100,8 @@ int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream) 
 	const MixedVariant* tab = mixed_part((pp.variant >> 16) % kMixedParts, &cnt);
 	const int idx = pp.variant & 0xffff;
 	if (grid64 > 0x7fffffffull || pp.variant < 0 || idx >= cnt) return 4039;
-	tab[idx].launch(prm, dim3((uint32_t)grid64), stream);
+	if (prm.preOp != OP_NONE || prm.postOp != OP_NONE) tab[idx].launchOps(prm, dim3((uint32_t)grid64), stream);
+	else tab[idx].launch(prm, dim3((uint32_t)grid64), stream);
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
 }
 
@@ -144,6 +145,11 @@ int launch_mixconv(const PassPlan& pp, const PassParams& prm, hipStream_t stream
 	const MixConvVariant* tab = mixconv_part((pp.variant >> 16) % kMixConvParts, &cnt);
 	const int idx = pp.variant & 0xffff;
 	if (grid64 > 0x7fffffffull || pp.variant < 0 || idx >= cnt) return 4039;
+	if ((prm.preOp != OP_NONE || prm.postOp != OP_NONE) && prm.preOp != OP_BLUESTEIN_PRE) { // (the Bluestein form handles its chirp itself: not the interpreter's maps)
+		if (!tab[idx].launchOps) return 4039;
+		tab[idx].launchOps(prm, dim3((uint32_t)grid64), stream);
+		return hipGetLastError() == hipSuccess ? 0 : 4039;
+	}
 	tab[idx].launch(prm, dim3((uint32_t)grid64), stream);
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
 }

@@ -148,8 +148,25 @@ static void collapse_dims(std::vector<HostDim>& d) {
 	d = r;
 }
 
+// Tables of the one-kernel Rader transform of prime length P (kernel_mixconv.h): uint32 g^a, g^-k mod P (a, k < P-1) and the FFT of
+// b_q = exp(-2 pi i g^-q / P) scaled by 1/(P-1)  (vkFFT_RecursiveFFTGenerators.h:1021-1048)
+static void make_mixconv_rader_tables(uint64_t P, bool dp, Arena& ar, size_t& tabOff, size_t& bhatOff) {
+	const uint64_t L = P - 1, g = primitive_root(P), gi = powmod(g, P - 2, P);
+	tabOff = ar.alloc(2 * (size_t)L * sizeof(uint32_t));
+	std::vector<cld> bk(L);
+	{
+		uint32_t* tab = (uint32_t*)(ar.b.data() + tabOff);
+		uint64_t gp = 1, gm = 1;
+		for (uint64_t q = 0; q < L; q++) { tab[q] = (uint32_t)gp; tab[L + q] = (uint32_t)gm; bk[q] = unit_root(gm, P); gp = gp * g % P; gm = gm * gi % P; }
+	}
+	host_fft(bk);
+	bhatOff = ar.alloc(L * (dp ? 16 : 8));
+	for (uint64_t m = 0; m < L; m++) ar.putc(bhatOff, m, bk[m] / (ld)L, dp);
+}
+
 static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	PassBuild b = bIn;
+	size_t mixconvTabOff = (size_t)-1;
 	// strided-tile passes of power-of-two length run on the hand-specialised column kernel
 	if (b.allowFast && b.fastKernel == KERNEL_GENERIC && b.colIn && b.L >= 2 && b.L <= 1024 && (b.L & (b.L - 1)) == 0 && b.preOp == OP_NONE
 	    && b.midOp == OP_NONE && (b.postOp == OP_NONE || b.postOp == OP_TWIDDLE_4STEP) && !b.realIn && !b.realOut && !b.forceT) {
@@ -210,6 +227,35 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		if (spanIn < 0x7FFFFF00ull && spanOut < 0x7FFFFF00ull && opfft_lookup(b.L, b.dp, b.colIn, transOut, b.preOp, b.postOp, &variant, rad5, &fpw, &thr)) {
 			b.fastKernel = KERNEL_OPFFT; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
 			for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
+		}
+	}
+	// real transforms on unit-stride rows whose complex length has a mixed-radix instance but no fused-map kernel above: the ahead-of-time transform
+	// between the interpreter's gather-load and gather-store (mixed_row_kernel OPS = 1) instead of the interpreter's own stages
+	{
+		auto realOp = [](uint32_t op) {
+			return op == OP_NONE || (op >= OP_R2C_EVEN_POST && op <= OP_DST4_POST) || (op >= OP_DCT2H_PRE && op <= OP_DST3H_POST) || op == OP_DCT1H_PRE || op == OP_DCT1H_POST;
+		};
+		if (b.allowOp && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && !b.colIn && !b.colOut && b.radices.empty() && !b.preNat && !b.postNat &&
+		    b.auxOff2ForPre == (size_t)-1 && (b.preOp != OP_NONE || b.postOp != OP_NONE) && realOp(b.preOp) && realOp(b.postOp) && b.inStrideJ == 1 && b.outStrideJ == 1 &&
+		    !getenv("VKFFT_MI355X_NO_MIXED_OPS")) {
+			int variant, rad5[5], fpw, thr;
+			uint64_t len = 0;
+			if (mixed_row_lookup(b.L, b.dp, &variant, rad5, &fpw, &thr)) {
+				b.fastKernel = KERNEL_MIXED_ROW; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
+				for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
+			} else if (b.L >= 37 && is_prime_u(b.L) && mixconv_lookup(true, false, b.L, b.dp, &variant, &len, rad5, &fpw, &thr)) {
+				// the complex length is a Rader prime: mixconv_kernel OPS = 1 (transform length P - 1; kernel spectrum through aux3)
+				const uint64_t P = b.L;
+				if (!b.inLen) b.inLen = (uint32_t)P;
+				if (!b.outLen) b.outLen = (uint32_t)P;
+				if (!b.blueN) b.blueN = (uint32_t)P; // (the maps tell the half-length forms from the full-length ones by the complex length)
+				size_t bhatOff;
+				make_mixconv_rader_tables(P, b.dp, ar, mixconvTabOff, bhatOff);
+				b.auxOff2ForPre = bhatOff;
+				b.L = len;
+				b.fastKernel = KERNEL_MIXCONV; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
+				for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
+			}
 		}
 	}
 	PassParams& p = pp.prm;
@@ -410,6 +456,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		p.fsLoBits = lo;
 		pp.auxOff = off;
 	}
+	if (mixconvTabOff != (size_t)-1) pp.raderOff = mixconvTabOff;
 	return 0;
 }
 
@@ -966,18 +1013,8 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		b.colIn = b.colOut = mc.col;
 		size_t tabOff = (size_t)-1;
 		if (mc.rader) {
-			// generator tables g^a, g^-k mod N and FFT of b_q = exp(-2 pi i g^-q / N) scaled by 1/L (vkFFT_RecursiveFFTGenerators.h:1021-1048)
-			const uint64_t L = N - 1, g = primitive_root(N), gi = powmod(g, N - 2, N);
-			tabOff = ar.alloc(2 * (size_t)L * sizeof(uint32_t));
-			std::vector<cld> bk(L);
-			{
-				uint32_t* tab = (uint32_t*)(ar.b.data() + tabOff);
-				uint64_t gp = 1, gm = 1;
-				for (uint64_t q = 0; q < L; q++) { tab[q] = (uint32_t)gp; tab[L + q] = (uint32_t)gm; bk[q] = unit_root(gm, N); gp = gp * g % N; gm = gm * gi % N; }
-			}
-			host_fft(bk);
-			const size_t bhatOff = ar.alloc(L * (dp ? 16 : 8));
-			for (uint64_t m = 0; m < L; m++) ar.putc(bhatOff, m, bk[m] / (ld)L, dp);
+			size_t bhatOff;
+			make_mixconv_rader_tables(N, dp, ar, tabOff, bhatOff);
 			b.aux2Off = bhatOff;
 			b.label = "rader";
 		} else {
@@ -1233,7 +1270,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	}
 	if (j.N <= singleCap || (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N <= (dp ? 8192u : 16384u))) {
 		b.L = j.N;
-		if (unit && !padded && !d.disableFastKernels && (j.N & (j.N - 1)) != 0) { // curated non-power-of-two lengths: hand-specialised mixed-radix kernel
+		if (unit && !padded && !d.disableFastKernels && ((j.N & (j.N - 1)) != 0 || j.N == 2)) { // curated non-power-of-two lengths (and N = 2): hand-specialised mixed-radix kernel
 			int variant, rad5[5], fpw, thr;
 			uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
 			if ((rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && mixed_row_lookup(j.N, dp, &variant, rad5, &fpw, &thr)) {
