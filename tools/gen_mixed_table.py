@@ -88,6 +88,7 @@ def sizes():
     s.update([1001, 1287, 7000])
     s.update(DIRECT_PRIMES)
     s.add(2)  # (the power-of-two row kernels start at 4 points)
+    s.update([4, 8, 16, 32, 64, 128])  # short power-of-two lengths: only for real transforms between the interpreter's maps (mixed_row_kernel OPS = 1)
     # lengths whose largest prime factor is 17 .. 31 (the direct butterflies as radices of a mixed schedule): up to 4096 (fp64: 1024, see main)
     for n in range(34, 4097):
         m = n

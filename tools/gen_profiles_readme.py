@@ -36,6 +36,10 @@ what = {
  "r03_fused_gen1_small_xcd_local_ring_experiment.jsonl": "generation 1 with plain ring stores and rings of 2–6 MiB per XCD: 1.35–2.33 TB/s (dependency stalls) | `tools/exp_fused2.py`",
  "r03_fused_nt_hint_per_side.jsonl": "the non-temporal hint on both sides (product) / neither / loads only / stores only, 2^15 … 2^22: both is best everywhere | `VKFFT_MI355X_LIB=build/libvkfft_mi355x_dev.so python tools/ab_nt.py 15 22`",
  "r03_mixconv_rows_family_on_vs_off.jsonl, r03_mixconv_columns_family_on_vs_off.jsonl": "the Rader / smooth-Bluestein kernel family forced on vs off (the planner's cost factors come from these) | `python tools/tune_mixconv.py rows` / `cols`",
+ "r03_all_lengths_2_320_with_reference_same_call.jsonl, r03_all_lengths_2_320_before_single_buffer_rows.jsonl": "1-D C2C of EVERY length 2 … 320 beside the reference (2^25 points): 0.99× after / 0.90× before the short rows shared one LDS buffer | `python tools/perf_all_short.py 2 320`",
+ "r03_r2c_rows_4_400_with_reference_same_call.jsonl, r03_dct2_rows_4_400_with_reference_same_call.jsonl, r03_dct4_rows_5_400_with_reference_same_call.jsonl, r03_r2c_rows_4_400_before_*, r03_dct2_rows_4_400_before_*": "real rows of arbitrary length beside the reference: R2C 0.44× (0.25× before the instance transform ran between the interpreter's maps), DCT-II 0.37× (0.22×), DCT-IV 0.40× | `python tools/perf_all_short.py 4 400 1 3` (12, 14: DCT-II, DCT-IV)",
+ "r03_short_real_rows_fused_maps_vs_instance_between_maps.jsonl": "fused-map kernels vs the instance transform between the interpreter's maps on short real rows (the planner's threshold) | `python tools/tune_mixed_ops.py`",
+ "r03_short_rows_with_reference_same_call.jsonl": "1-D rows of 4 … 128 points and small planes / cubes | `python tools/perf_small_rows.py`",
  "r03_zero_padding_with_reference_same_call.jsonl": "zero-padded 3-D / 2-D systems, padded vs unpadded, reference in the same process | `python tools/perf_zeropad.py`",
  "r03_convolution_with_reference_same_call.jsonl": "convolution plans with the merged last axis, reference's merged kernels in the same process | `python tools/perf_conv.py`",
  "r03_multi_gpu_cxx_drivers_one_gpu_box.jsonl": "C++ drivers: 4 virtual ranks verified against a single-device plan, one rank over RCCL, batch sharding | `build/vkfft_mi355x_multi …`",

@@ -216,7 +216,18 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	// (op-FFT and zero padding: only the maps that go through Io32::ia / oa element by element — C2C columns, the R2C / C2R forms)
 	const bool opMaskOK = !padMask || ((b.preOp == OP_NONE || b.preOp == OP_C2R_EVEN_PRE || b.preOp == OP_R2C_FULL || b.preOp == OP_C2R_FULL) &&
 	                                 (b.postOp == OP_NONE || b.postOp == OP_R2C_EVEN_POST || b.postOp == OP_R2C_FULL || b.postOp == OP_C2R_FULL));
-	if (b.allowOp && opMaskOK && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && (b.colIn == b.colOut || transOut) && b.radices.empty()
+	// (short real rows: the instance transform between the interpreter's maps moves the tile as one contiguous run; measured against the fused-map
+	// kernels, whose threads read a short row 4 or 8 bytes at a time — VKFFT_MI355X_MIXED_OPS_MAX = longest complex length that prefers it)
+	bool preferMixedOps = false;
+	{
+		// measured (tools/tune_mixed_ops.py, profiles/r03_short_real_rows_fused_maps_vs_instance_between_maps.jsonl): complex lengths 8 and 16 (R2C / DCT of 16 and
+		// 32 reals) run 1.1-5x faster between the maps; from 20 on the fused-map kernels win
+		const uint64_t lim = getenv("VKFFT_MI355X_MIXED_OPS_MAX") ? (uint64_t)atoll(getenv("VKFFT_MI355X_MIXED_OPS_MAX")) : 16;
+		int v, r5[5], f, t;
+		preferMixedOps = lim && b.L >= 8 && b.L <= lim && !b.colIn && !b.colOut && !padMask && b.inStrideJ == 1 && b.outStrideJ == 1 && (b.preOp != OP_NONE || b.postOp != OP_NONE) &&
+		                 mixed_row_lookup(b.L, b.dp, &v, r5, &f, &t);
+	}
+	if (b.allowOp && opMaskOK && !preferMixedOps && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && (b.colIn == b.colOut || transOut) && b.radices.empty()
 	    && !(b.preOp == OP_NONE && b.postOp == OP_NONE && !b.colIn)) {
 		const uint64_t ib = (b.realIn ? 1 : 2) * (b.dp ? 8 : 4), ob = (b.realOut ? 1 : 2) * (b.dp ? 8 : 4);
 		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
