@@ -37,6 +37,18 @@ FOURSTEP_EXTRA = [9, 27, 81, 25, 49, 11, 121, 1331, 13, 169, 2197]
 ODD_EXTRA = [15, 25, 27, 45, 75, 81, 105, 135, 225, 315, 375, 405, 675, 945, 1125, 1215, 2025, 3375]
 
 
+def smooth13(n):
+    for q in (2, 3, 5, 7, 11, 13):
+        while n % q == 0: n //= q
+    return n == 1
+
+
+# strided C2C (plain column passes: the second / third axis of planes and volumes, incl. the complex side of multi-dimensional real transforms): every
+# 13-smooth length up to 1024 (fp64: 512) — round 3: such axes of a length outside the curated list ran on the interpreter
+COL_C2C_EXTRA = [n for n in range(3, 1025) if smooth13(n) and n & (n - 1)]
+COL_C2C_EXTRA_DP = [n for n in COL_C2C_EXTRA if n <= 512]
+
+
 def pitch(n, fpw, col):
     p = n + (n >> 4) + 1
     if col:
@@ -137,7 +149,8 @@ def main():
                 if (col and not col_ok) or (not col and not row_ok): continue
                 fourstep = fam in ("c2c", "c2c4", "c2cT")
                 oddreal = fam in ("r2cf", "c2rf")
-                for n in sorted(set(lens) | (set(FOURSTEP_EXTRA) if fourstep and not dp else set()) | (set(ODD_EXTRA) if oddreal else set()) | (set(DIRECT_PRIMES) if fam == "c2c" else set())):
+                for n in sorted(set(lens) | (set(FOURSTEP_EXTRA) if fourstep and not dp else set()) | (set(ODD_EXTRA) if oddreal else set()) | (set(DIRECT_PRIMES) if fam == "c2c" else set())
+                                | (set(COL_C2C_EXTRA_DP if dp else COL_C2C_EXTRA) if (fam == "c2c" and col) else set())):
                     ispow2 = n & (n - 1) == 0
                     if oddreal and n % 2 == 0: continue
                     if pow2only and not ispow2: continue

@@ -40,6 +40,7 @@ what = {
  "r03_r2c_rows_4_400_with_reference_same_call.jsonl, r03_dct2_rows_4_400_with_reference_same_call.jsonl, r03_dct4_rows_5_400_with_reference_same_call.jsonl, r03_r2c_rows_4_400_before_*, r03_dct2_rows_4_400_before_*": "real rows of arbitrary length beside the reference: R2C 0.44× (0.25× before the instance transform ran between the interpreter's maps), DCT-II 0.37× (0.22×), DCT-IV 0.40× | `python tools/perf_all_short.py 4 400 1 3` (12, 14: DCT-II, DCT-IV)",
  "r03_short_real_rows_fused_maps_vs_instance_between_maps.jsonl": "fused-map kernels vs the instance transform between the interpreter's maps on short real rows (the planner's threshold) | `python tools/tune_mixed_ops.py`",
  "r03_short_rows_with_reference_same_call.jsonl": "1-D rows of 4 … 128 points and small planes / cubes | `python tools/perf_small_rows.py`",
+ "r03_planes_of_smooth_lengths_outside_the_curated_lists_with_reference_same_call.jsonl": "84², 168², 252², 84³ … C2C 0.94–1.09× after the plain column kernels got an instance for every 13-smooth length ≤ 1024; R2C / DCT planes of such lengths 0.4–0.8× (real rows between the generic maps, strided DCT axes on the interpreter) | `python tools/perf_odd_planes.py`",
  "r03_zero_padding_with_reference_same_call.jsonl": "zero-padded 3-D / 2-D systems, padded vs unpadded, reference in the same process | `python tools/perf_zeropad.py`",
  "r03_convolution_with_reference_same_call.jsonl": "convolution plans with the merged last axis, reference's merged kernels in the same process | `python tools/perf_conv.py`",
  "r03_multi_gpu_cxx_drivers_one_gpu_box.jsonl": "C++ drivers: 4 virtual ranks verified against a single-device plan, one rank over RCCL, batch sharding | `build/vkfft_mi355x_multi …`",
