@@ -49,6 +49,17 @@ COL_C2C_EXTRA = [n for n in range(3, 1025) if smooth13(n) and n & (n - 1)]
 COL_C2C_EXTRA_DP = [n for n in COL_C2C_EXTRA if n <= 512]
 
 
+def smooth7(n):
+    for q in (2, 3, 5, 7):
+        while n % q == 0: n //= q
+    return n == 1
+
+
+# real rows of SHORT arbitrary 7-smooth lengths (fp32): every complex length up to 256 for the even forms (R2C / C2R / DCT-II/III half-length / DCT-IV of
+# N = 2L reals) and every odd one for the full-length forms — the lengths outside the curated list run between the interpreter's generic maps at about half the speed
+ROW_REAL_EXTRA = [n for n in range(3, 257) if smooth7(n) and n & (n - 1)]
+
+
 def pitch(n, fpw, col):
     p = n + (n >> 4) + 1
     if col:
@@ -150,7 +161,8 @@ def main():
                 fourstep = fam in ("c2c", "c2c4", "c2cT")
                 oddreal = fam in ("r2cf", "c2rf")
                 for n in sorted(set(lens) | (set(FOURSTEP_EXTRA) if fourstep and not dp else set()) | (set(ODD_EXTRA) if oddreal else set()) | (set(DIRECT_PRIMES) if fam == "c2c" else set())
-                                | (set(COL_C2C_EXTRA_DP if dp else COL_C2C_EXTRA) if (fam == "c2c" and col) else set())):
+                                | (set(COL_C2C_EXTRA_DP if dp else COL_C2C_EXTRA) if (fam == "c2c" and col) else set())
+                                | (set(ROW_REAL_EXTRA) if (not col and not dp and fam in ("r2c", "c2r", "dct2h", "dct3h", "dct4", "r2cf", "c2rf", "dct2", "dct3")) else set())):
                     ispow2 = n & (n - 1) == 0
                     if oddreal and n % 2 == 0: continue
                     if pow2only and not ispow2: continue

@@ -221,10 +221,10 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	bool preferMixedOps = false;
 	{
 		// measured (tools/tune_mixed_ops.py, profiles/r03_short_real_rows_fused_maps_vs_instance_between_maps.jsonl): complex lengths 8 and 16 (R2C / DCT of 16 and
-		// 32 reals) run 1.1-5x faster between the maps; from 20 on the fused-map kernels win
+		// 32 reals) run 1.1-5x faster between the maps; from 20 on the fused-map kernels win (only the powers of two were measured: the others keep their fused-map kernel)
 		const uint64_t lim = getenv("VKFFT_MI355X_MIXED_OPS_MAX") ? (uint64_t)atoll(getenv("VKFFT_MI355X_MIXED_OPS_MAX")) : 16;
 		int v, r5[5], f, t;
-		preferMixedOps = lim && b.L >= 8 && b.L <= lim && !b.colIn && !b.colOut && !padMask && b.inStrideJ == 1 && b.outStrideJ == 1 && (b.preOp != OP_NONE || b.postOp != OP_NONE) &&
+		preferMixedOps = lim && b.L >= 8 && b.L <= lim && (b.L & (b.L - 1)) == 0 && !b.colIn && !b.colOut && !padMask && b.inStrideJ == 1 && b.outStrideJ == 1 && (b.preOp != OP_NONE || b.postOp != OP_NONE) &&
 		                 mixed_row_lookup(b.L, b.dp, &v, r5, &f, &t);
 	}
 	if (b.allowOp && opMaskOK && !preferMixedOps && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && (b.colIn == b.colOut || transOut) && b.radices.empty()
