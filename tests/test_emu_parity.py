@@ -443,3 +443,12 @@ def test_real_rows_between_the_interpreters_maps_and_an_instance_transform(run, 
         parity.check_r2r(run, oracle, (N,), 3, dp, type, False)
     parity.check_r2r(run, oracle, (N,), 3, dp, 2, True)
     parity.check_r2r(run, oracle, (N,), 3, dp, 4, True)
+
+
+@pytest.mark.parametrize("shape", [(84, 84), (42, 90), (28, 36, 10), (75, 45)])
+def test_real_planes_of_smooth_lengths_outside_the_curated_list(run, oracle, shape):
+    """R2C and DCT / DST planes whose axis lengths got fused-map instances late in round 3 (rows of every short 7-smooth length, strided DCT axes up to 256 reals)"""
+    parity.check_r2c(run, oracle, shape, 2, False)
+    for type in (2, 3, 4):
+        parity.check_r2r(run, oracle, shape, 2, False, type, False)
+    parity.check_r2r(run, oracle, shape, 2, False, 2, True)

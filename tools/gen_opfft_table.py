@@ -162,7 +162,9 @@ def main():
                 oddreal = fam in ("r2cf", "c2rf")
                 for n in sorted(set(lens) | (set(FOURSTEP_EXTRA) if fourstep and not dp else set()) | (set(ODD_EXTRA) if oddreal else set()) | (set(DIRECT_PRIMES) if fam == "c2c" else set())
                                 | (set(COL_C2C_EXTRA_DP if dp else COL_C2C_EXTRA) if (fam == "c2c" and col) else set())
-                                | (set(ROW_REAL_EXTRA) if (not col and not dp and fam in ("r2c", "c2r", "dct2h", "dct3h", "dct4", "r2cf", "c2rf", "dct2", "dct3")) else set())):
+                                | (set(ROW_REAL_EXTRA) if (not col and not dp and fam in ("r2c", "c2r", "dct2h", "dct3h", "dct4", "r2cf", "c2rf", "dct2", "dct3")) else set())
+                                # ... and the DCT / DST families on strided axes (planes and volumes of such lengths), complex lengths up to 128
+                                | (set(n for n in ROW_REAL_EXTRA if n <= 128) if (col and not dp and fam in ("dct2h", "dct3h", "dct4", "dct2", "dct3")) else set())):
                     ispow2 = n & (n - 1) == 0
                     if oddreal and n % 2 == 0: continue
                     if pow2only and not ispow2: continue
