@@ -27,7 +27,11 @@ def _smooth(rnd, maxn):
             return n
 
 
-@pytest.mark.parametrize("seed", range(6))
+import os as _os
+_EXTRA_1D = int(_os.environ.get("VKFFT_FUZZ_EXTRA_SEEDS", "0"))  # (development: more seeds for a longer hunt)
+
+
+@pytest.mark.parametrize("seed", range(6 + _EXTRA_1D))
 def test_random_plans_against_the_oracle(run, oracle, seed):
     rnd = random.Random(1000 + seed)
     unsupported = 0
@@ -106,3 +110,46 @@ def test_random_padded_strides_and_out_of_place(emu_lib, seed):
         if oop:
             assert np.array_equal(src, orig)
         app.delete()
+
+
+def _any_len(rnd, maxn):
+    """smooth, prime or arbitrary: the three planner classes"""
+    c = rnd.random()
+    if c < 0.4:
+        return _smooth(rnd, maxn)
+    n = rnd.randint(2, maxn)
+    if c < 0.7:
+        while any(n % q == 0 for q in range(2, int(n ** 0.5) + 1)):
+            n -= 1
+    return max(2, n)
+
+
+import os
+_EXTRA = int(os.environ.get("VKFFT_FUZZ_EXTRA_SEEDS", "0"))  # (development: more seeds for a longer hunt)
+
+
+@pytest.mark.parametrize("seed", range(4 + _EXTRA))
+def test_random_planes_and_volumes_of_any_length(run, oracle, seed):
+    """2-D / 3-D C2C, R2C and DCT systems whose axes are smooth, prime or arbitrary, small batches: the column-tile kernels (merged tiles over two dimensions,
+    Rader / Bluestein column tiles, transposed rows) and the real-row forms of round 3 behind every combination the planner can produce"""
+    rnd = random.Random(5000 + seed)
+    unsupported = 0
+    cases = 20
+    for _ in range(cases):
+        dp = rnd.random() < 0.3
+        nd = rnd.choice([2, 2, 3])
+        lim = 120 if nd == 2 else 40
+        shape = tuple(_any_len(rnd, lim) for _ in range(nd))
+        batch = rnd.randint(1, 5)
+        kind = rnd.choice(["c2c", "c2c", "r2c", "dct"])
+        try:
+            if kind == "c2c":
+                parity.check_c2c(run, oracle, shape, batch, dp, kind="bluestein", use_c_oracle=False)
+            elif kind == "r2c":
+                parity.check_r2c(run, oracle, shape, batch, dp)
+            else:
+                parity.check_r2r(run, oracle, tuple(max(3, s) for s in shape), batch, dp, rnd.randint(1, 4), rnd.random() < 0.4)
+        except api.VkFFTError as e:
+            assert e.code in UNSUPPORTED, (e, shape, kind)
+            unsupported += 1
+    assert unsupported <= cases // 4
