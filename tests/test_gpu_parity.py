@@ -796,6 +796,21 @@ def test_random_plans_against_the_oracle_on_device(run, oracle, seed):
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("seed", range(4))
+def test_random_planes_and_volumes_of_any_length_on_device(run, oracle, seed):
+    """tests/test_emu_fuzz.py::test_random_planes_and_volumes_of_any_length on the device (seeds disjoint from the emulator's): merged column tiles, Rader / Bluestein
+    column tiles, transposed rows and the real-row forms of round 3 behind whatever the planner produces for smooth, prime and arbitrary axis lengths"""
+    import test_emu_fuzz as fz
+    import random as _r
+    orig = _r.Random
+    try:
+        _r.Random = lambda s_: orig(9000 + seed * 17 + (s_ - 5000))  # the shared body seeds Random(5000 + seed)
+        fz.test_random_planes_and_volumes_of_any_length(run, oracle, seed)
+    finally:
+        _r.Random = orig
+
+
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("kw", [dict(size=[1 << 10]), dict(size=[1 << 13]), dict(size=[1 << 14]), dict(size=[1 << 17]), dict(size=[1 << 20]), dict(size=[1080]), dict(size=[2187]),
                                 dict(size=[1009]), dict(size=[4096], r2c=True), dict(size=[1024], dct=2), dict(size=[1024], dct=4), dict(size=[256, 256]), dict(size=[64, 64, 64]),
                                 dict(size=[1 << 12], dp=True), dict(size=[8191])], ids=lambda k: "x".join(map(str, k["size"])) + "".join(f"-{a}" for a in k if a != "size"))
