@@ -42,3 +42,57 @@ def test_zero_padding_never_touches_what_it_skips(run, case):
             assert v, (k, res)
         else:
             assert v < tol, (k, res)
+
+
+import os as _os
+import random as _random
+_EXTRA = int(_os.environ.get("VKFFT_FUZZ_EXTRA_SEEDS", "0"))
+
+
+@pytest.mark.parametrize("seed", range(3 + _EXTRA))
+def test_random_zero_padding_configurations(run, seed):
+    """random 1-D ... 3-D systems (smooth, prime and arbitrary axis lengths), random padded ranges on a random subset of the axes, spatial or frequency padding, C2C / R2C /
+    DCT: the masked kernels, the sequence skipping and the zero-fill fallback must all agree with numpy on the zero-extended data"""
+    rnd = _random.Random(8000 + seed)
+    for _ in range(12):
+        nd = rnd.choice([1, 2, 2, 3])
+        lim = {1: 600, 2: 48, 3: 20}[nd]
+        def length():
+            c = rnd.random()
+            if c < 0.5:
+                n = 1
+                for p, e in ((2, 6), (3, 3), (5, 2), (7, 1)):
+                    n *= p ** rnd.randint(0, e)
+                return min(max(n, 4), lim) if n <= lim else rnd.choice([8, 12, 16, 20])
+            return rnd.randint(4, lim)
+        shape = tuple(length() for _ in range(nd))
+        kind = rnd.choice(["c2c", "c2c", "r2c", "dct"])
+        if kind == "r2c" and shape[0] % 2:
+            shape = (shape[0] + 1,) + shape[1:]
+        frequency = kind != "dct" and rnd.random() < 0.35
+        pads = {}
+        for a in range(nd):
+            if rnd.random() < 0.6:
+                n = shape[a] // 2 + 1 if (kind == "r2c" and frequency and a == 0) else shape[a]
+                l = rnd.randint(1, max(1, n - 2)); r = rnd.randint(l + 1, n)
+                if kind == "r2c" and frequency and a > 0:
+                    # the half spectrum must stay Hermitian along the full axes (k and n - k zeroed together), else "the" real result is not defined
+                    l = rnd.randint(1, max(1, n // 2)); r = n - l + 1
+                pads[a] = (l, r)
+        if not pads:
+            if kind == "r2c" and frequency:
+                pads[0] = (1, 2)  # (axis 0 is the half axis: any range keeps the spectrum Hermitian)
+            else:
+                a0 = rnd.randrange(nd)
+                pads[a0] = (shape[a0] // 2, shape[a0]) if nd == 1 else (1, 2)
+        dp = rnd.random() < 0.3
+        kw = dict(frequency=frequency, dp=dp, batch=rnd.randint(1, 3), seed=seed)
+        if kind == "r2c": kw["r2c"] = True
+        if kind == "dct": kw["dct"] = rnd.randint(2, 4)
+        try:
+            err = convpad.zeropad_case(run, shape, pads, **kw)
+        except Exception as e:  # documented rejections only
+            from vkfft_amd import api
+            assert isinstance(e, api.VkFFTError) and e.code in (3002, 3003, 3004, 3005, 4001, 4002, 4003, 4004, 4005), (shape, pads, kw, e)
+            continue
+        assert err < (1e-12 if dp else 6e-6), (shape, pads, kw, err)
