@@ -96,3 +96,29 @@ def test_random_zero_padding_configurations(run, seed):
             assert isinstance(e, api.VkFFTError) and e.code in (3002, 3003, 3004, 3005, 4001, 4002, 4003, 4004, 4005), (shape, pads, kw, e)
             continue
         assert err < (1e-12 if dp else 6e-6), (shape, pads, kw, err)
+
+
+@pytest.mark.parametrize("seed", range(3 + _EXTRA))
+def test_random_convolution_configurations(run, seed):
+    """random 1-D ... 3-D convolution plans: matrix sizes 1 ... 3 (full and symmetric), several kernels or several batches, conjugation modes, C2C / R2C, last axes that
+    take the merged kernel (powers of two, incl. the split form of long ones) and last axes that take the separate product pass"""
+    rnd = _random.Random(8500 + seed)
+    for _ in range(8):
+        nd = rnd.choice([1, 2, 2, 3])
+        lim = {1: 4096, 2: 64, 3: 16}[nd]
+        def length(last):
+            if last and rnd.random() < 0.6:
+                return 1 << rnd.randint(2, {1: 12, 2: 6, 3: 4}[nd])
+            return rnd.choice([6, 10, 12, 20, 24, 30, 36, 48, 60]) if lim >= 60 else rnd.choice([4, 6, 8, 10, 12, 16])
+        shape = tuple(length(a == nd - 1) for a in range(nd))
+        r2c = rnd.random() < 0.4
+        if r2c and shape[0] % 2:
+            shape = (shape[0] + 1,) + shape[1:]
+        m = rnd.choice([1, 1, 2, 3])
+        kw = dict(m=m, r2c=r2c, dp=rnd.random() < 0.3, seed=seed, conjugate=rnd.choice([0, 0, 1, 2]))
+        if m > 1: kw["symmetric"] = rnd.random() < 0.5
+        else: kw["cf"] = rnd.randint(1, 3)
+        if rnd.random() < 0.5: kw["nk"] = rnd.randint(1, 2)
+        else: kw["nb"] = rnd.randint(1, 3)
+        err = convpad.conv_case(run, shape, **kw)
+        assert err < (1e-12 if kw["dp"] else 6e-5), (shape, kw, err)
