@@ -105,6 +105,7 @@ def main():
             apps[k].forward()
             apps[k].inverse()
 
+    initial = buf.clone()  # every pair is FFT followed by the normalised inverse: the buffer must come back (checked after the timed region)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -119,6 +120,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # ---- result check of the timed work itself: (warmup + steps) x 15 forward/inverse pairs later the buffer is its initial contents up to rounding
+    diff = buf - initial
+    roundtrip_rel_l2 = float(torch.linalg.vector_norm(diff.double()) / torch.linalg.vector_norm(initial.double()))
+    max_abs_err = float(diff.abs().max())
+    finite = bool(torch.isfinite(buf).all())
+    del diff, initial
+    rt_limit = 2e-6 * (args.steps + args.warmup) ** 0.5
+    if dist:
+        t = torch.tensor([roundtrip_rel_l2, max_abs_err, 0.0 if finite else 1.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        roundtrip_rel_l2, max_abs_err, finite = float(t[0]), float(t[1]), float(t[2]) == 0.0
+    if not finite or not (roundtrip_rel_l2 <= rt_limit):
+        raise SystemExit(f"bench.py: result check failed after the timed loop: round-trip rel. L2 {roundtrip_rel_l2:.3e} (limit {rt_limit:.3e}), "
+                         f"max |err| {max_abs_err:.3e}, finite={finite}")
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -206,7 +221,9 @@ def main():
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload="batched 1D C2C fp32 in-place, N=2^8..2^22, batch=2^27/N (1 GiB per GPU), FFT+iFFT pair per size per step (sample-0 protocol)",
                                sizes_log2=[KMIN, KMAX], buffer_bytes_per_gpu=8 << TOTAL_LOG2, parallelism=f"batch-sharded x{world}, no collectives"),
-                   alg_GBps=round(bytes_step / (ms_per_step * 1e-3) / 1e9, 1), per_size=per_size, roofline=roofline, cpu_baseline=cpu)
+                   alg_GBps=round(bytes_step / (ms_per_step * 1e-3) / 1e9, 1),
+                   roundtrip_rel_l2=float(f"{roundtrip_rel_l2:.3e}"), max_abs_err=float(f"{max_abs_err:.3e}"), roundtrip_limit_rel_l2=float(f"{rt_limit:.3e}"),
+                   roundtrip_pairs=(args.steps + args.warmup) * (KMAX - KMIN + 1), per_size=per_size, roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()

@@ -11,6 +11,35 @@ TOL = {
 }
 
 
+# Per-element bounds — the reference's own metric (sample_11_precision_VkFFT_single.cpp:289-331: max / average |delta| and |delta|/|ref| per element
+# against the double-precision truth; it prints them and asserts nothing).  Stated in ULPs of the output's RMS, ulp = eps(dtype) * rms(ref):
+#   max |delta|            <= MAX_ULP ulp   (one wrong element in 2^27 moves the relative L2 by 1e-4 of nothing; it moves this by 10^6 ulp)
+#   mean |delta| / |ref|   <= AVG_EPS_ULP * eps   (complex outputs only: for real outputs E[1/|ref|] diverges)
+MAX_ULP = {("c2c", False): 64, ("c2c", True): 72, ("bluestein", False): 192, ("bluestein", True): 216, ("real", False): 128, ("real", True): 216}
+AVG_EPS_ULP = {("c2c", False): 24, ("c2c", True): 27, ("bluestein", False): 72, ("bluestein", True): 81, ("real", False): 48, ("real", True): 81}
+
+
+def element_errors(y, ref):
+    """(max |delta| and mean |delta|/|ref|) in ulps of the output's RMS resp. in eps — see MAX_ULP"""
+    ref = np.asarray(ref).reshape(-1)
+    y = np.asarray(y).reshape(-1)
+    dp = y.dtype in (np.float64, np.complex128)
+    eps = np.finfo(np.float64 if dp else np.float32).eps
+    d = np.abs(y.astype(np.complex128 if np.iscomplexobj(ref) else np.float64) - ref.astype(np.complex128 if np.iscomplexobj(ref) else np.float64))
+    mag = np.abs(ref.astype(np.complex128 if np.iscomplexobj(ref) else np.float64))
+    rms = max(float(np.sqrt(np.mean(mag ** 2))), 1e-300)
+    nz = mag > 0
+    return float(d.max() / (eps * rms)), float(np.mean(d[nz] / mag[nz]) / eps) if nz.any() else 0.0
+
+
+def assert_elementwise(y, ref, kind, dp, what=""):
+    mx, avg = element_errors(y, ref)
+    assert mx <= MAX_ULP[(kind, dp)], f"{what}: max |delta| = {mx:.1f} ulp of the output RMS > {MAX_ULP[(kind, dp)]}"
+    if np.iscomplexobj(ref):
+        assert avg <= AVG_EPS_ULP[(kind, dp)], f"{what}: mean |delta|/|ref| = {avg:.1f} eps > {AVG_EPS_ULP[(kind, dp)]}"
+    return mx, avg
+
+
 def rel_l2(a, b):
     a = np.asarray(a).reshape(-1).astype(np.clongdouble if np.iscomplexobj(b) or np.iscomplexobj(a) else np.longdouble)
     b = np.asarray(b).reshape(-1)

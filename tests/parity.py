@@ -1,7 +1,7 @@
 """Parity checks shared by the CPU (emulated) and GPU test modules: library (through the C-ABI) vs the oracle
 on the same seeded inputs."""
 import numpy as np
-from helpers import rel_l2, TOL
+from helpers import rel_l2, TOL, assert_elementwise
 
 
 def seeded_complex(n, dp, seed):
@@ -18,6 +18,7 @@ def check_c2c(runner, oracle, shape, batch, dp, *, kind="c2c", use_c_oracle=None
     truth = oracle.truth_c2c(x, shape, batch, longdouble=dp)
     e = rel_l2(y, truth)
     assert e < tol, f"forward {shape} b={batch} dp={dp}: rel-L2 {e:.3e} >= {tol}"
+    assert_elementwise(y, truth, kind, dp, f"forward {shape} b={batch} dp={dp}")
     # forward o inverse = N x (unnormalised), bound: twice the one-way bound
     e2 = rel_l2(z, x.astype(np.complex128) * np.prod(shape))
     assert e2 < 2 * tol, f"roundtrip {shape}: {e2:.3e}"
@@ -41,6 +42,7 @@ def check_r2c(runner, oracle, shape, batch, dp, seed=2):
     Y = y.view(np.complex128 if dp else np.complex64)
     truth = np.fft.rfftn(rows.astype(np.float64).reshape([batch] + list(shape)[::-1]), axes=tuple(range(1, 1 + len(shape)))).reshape(-1)
     assert rel_l2(Y, truth) < tol, f"r2c {shape}"
+    assert_elementwise(Y, truth, "real", dp, f"r2c {shape}")
     back = z.reshape(batch * rest, 2 * Wc)[:, :W]
     assert rel_l2(back, rows.astype(np.float64) * np.prod(shape)) < 2 * tol, f"c2r(r2c) {shape}"
     if len(shape) == 1:
@@ -57,6 +59,7 @@ def check_r2r(runner, oracle, shape, batch, dp, type, dst, seed=3):
     y, z, _ = runner.transform(x, shape, batch, both=True, **kw)
     truth = oracle.truth_r2r(x, shape, batch, type=type, dst=dst, longdouble=dp)
     assert rel_l2(y, truth) < tol, f"{'dst' if dst else 'dct'}{type} {shape}"
+    assert_elementwise(y, truth, "real", dp, f"{'dst' if dst else 'dct'}{type} {shape}")
     norm = 1.0
     for s in shape:
         norm *= (2.0 * (s + 1) if dst else 2.0 * (s - 1)) if type == 1 else 2.0 * s
