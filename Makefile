@@ -7,12 +7,13 @@ CXXFLAGS := -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I$(CSRC) -Wno-un
 OBJS := build/obj/api.o build/obj/planner.o build/obj/kernels.o build/obj/kernels_blue_r2r.o build/obj/kernels_fused.o build/obj/kernels_aux.o build/obj/kernels_mixed_0.o build/obj/kernels_mixed_1.o build/obj/kernels_mixed_2.o build/obj/kernels_mixed_3.o build/obj/kernels_mixed_4.o build/obj/kernels_mixed_5.o \
         build/obj/kernels_mixconv_0.o build/obj/kernels_mixconv_1.o build/obj/kernels_mixconv_2.o build/obj/kernels_mixconv_3.o build/obj/kernels_mixconv_4.o build/obj/kernels_mixconv_5.o \
         $(foreach t,f32_row f32_col f64_row f64_col,build/obj/kernels_opfft_$(t)_0.o build/obj/kernels_opfft_$(t)_1.o)
-FUSED_HDRS := $(CSRC)/kernel_pow2_fused.h $(CSRC)/kernel_pow2_fused2.h
+FUSED_HDRS := $(CSRC)/kernel_pow2_fused.h
 MIXCONV_HDRS := $(CSRC)/kernel_mixconv.h
 OTHER_INC := $(filter-out $(wildcard $(CSRC)/mixconv_table_*.inc),$(wildcard $(CSRC)/*.inc))
 HDRS := $(filter-out $(FUSED_HDRS) $(MIXCONV_HDRS),$(wildcard $(CSRC)/*.h)) include/vkFFT.h
 
-all: $(LIBDIR)/libvkfft_mi355x.so build/vkfft_mi355x_cli build/vkfft_mi355x_multi
+all: $(LIBDIR)/libvkfft_mi355x.so build/vkfft_mi355x_cli $(if $(wildcard /opt/rocm/lib/librccl.so),build/vkfft_mi355x_multi)
+multi: build/vkfft_mi355x_multi
 
 # caller-side benchmark driver (flag-compatible in spirit with the reference's VkFFT_TestSuite): links the C-ABI only
 build/vkfft_mi355x_cli: tools/vkfft_cli.cpp include/vkFFT.h $(LIBDIR)/libvkfft_mi355x.so
@@ -58,4 +59,4 @@ oracle:
 clean:
 	rm -rf build/obj $(LIBDIR)/*.so
 
-.PHONY: all oracle clean dev
+.PHONY: all oracle clean dev multi

@@ -122,3 +122,35 @@ def test_random_convolution_configurations(run, seed):
         else: kw["nb"] = rnd.randint(1, 3)
         err = convpad.conv_case(run, shape, **kw)
         assert err < (1e-12 if kw["dp"] else 6e-5), (shape, kw, err)
+
+
+@pytest.mark.parametrize("shape", [(128, 16), (96, 16), (64, 8, 4)])
+def test_plain_inverse_of_a_convolution_application(run, shape):
+    """VkFFTAppend(app, 1) of a performConvolution application is an ordinary inverse over EVERY axis (vkFFT_RunApp.h:347: the inverse plan), whether
+    or not the last axis of the convolution itself runs merged (a shape-dependent planner decision: (128, 16) merges, (96, 16) does not)."""
+    import numpy as np
+    from vkfft_amd import api
+    from helpers import rel_l2
+    rng = np.random.default_rng(5)
+    dims = tuple(reversed(shape))
+    x = (rng.uniform(-1, 1, dims) + 1j * rng.uniform(-1, 1, dims)).astype(np.complex64)
+    k = np.ones(dims, np.complex64)
+    hk, pk = run._alloc(k)
+    hd, pd = run._alloc(x)
+    ca = api.App(list(shape), 1, buffer_ptr=pd, performConvolution=1, kernel=pk, lib=run.lib, normalize=True)
+    ca.inverse()
+    got = run._fetch(hd, np.complex64).reshape(dims)
+    n_launch, _ = ca.launch_info(inverse=True)
+    ca.delete()
+    assert n_launch >= 1
+    assert rel_l2(got, np.fft.ifftn(x.astype(np.complex128))) < 2e-6
+
+
+def test_symmetric_kernel_slot_order_differs_from_the_reference_for_m3():
+    """pins a deliberate parity break: the packed upper triangle is read in the DOCUMENTED order xx, xy, xz, yy, yz, zz; the reference's
+    generated index a*m - a*a + b (vkFFT_Convolution.h:354) reads slot 4 for zz where this library reads slot 5 — identical for m = 2"""
+    doc = lambda a, b, m: [(r, c) for r in range(m) for c in range(r, m)].index((a, b))
+    ref = lambda a, b, m: a * m - a * a + b
+    assert all(doc(a, b, 2) == ref(a, b, 2) for a in range(2) for b in range(a, 2))
+    assert doc(2, 2, 3) == 5 and ref(2, 2, 3) == 4
+    assert convpad._kernel_index(2, 2, 3, True) == 5

@@ -332,24 +332,6 @@ def test_fused_fourstep_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
 
 
-@pytest.mark.parametrize("k,variant,batch,chunk_kib,lag,ring,queues", [(15, 2, 7, 256, 2, 3, 1), (16, 2, 5, 512, 1, 2, 1), (16, 3, 5, 512, 2, 4, 1), (17, 2, 3, 1024, 1, 2, 1),
-                                                                       (18, 2, 3, 2048, 1, 2, 1), (15, 2, 37, 256, 2, 3, 8), (16, 2, 19, 512, 3, 5, 8)])
-def test_fused_fourstep_second_generation(run, oracle, monkeypatch, k, variant, batch, chunk_kib, lag, ring, queues):
-    """the service-wave / LDS-DMA form of the fused Four-Step kernel (kernel_pow2_fused2.h; development and emulator builds only, not the
-    product default): same ticket queue and ring, tiles through the two alternating LDS buffers, two-ahead ticket pipeline of the service wave"""
-    monkeypatch.setenv(f"VKFFT_MI355X_FUV{k}", str(variant))
-    monkeypatch.setenv("VKFFT_MI355X_FUSED_CHUNK_KIB", str(chunk_kib))
-    monkeypatch.setenv("VKFFT_MI355X_FUSED_LAG", str(lag))
-    monkeypatch.setenv("VKFFT_MI355X_FUSED_RING", str(ring))
-    monkeypatch.setenv("VKFFT_MI355X_FUSED_QUEUES", str(queues))
-    N = 1 << k
-    x = parity.seeded_complex(N * batch, False, N + batch)
-    y, z, up = run.transform(x, (N,), batch, both=True)
-    assert up == [2]
-    assert rel_l2(y, oracle.truth_c2c(x, (N,), batch)) < 1e-6
-    assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
-
-
 @pytest.mark.parametrize("k,batch", [(14, 5), (15, 3), (16, 3), (17, 2), (18, 2), (19, 2), (20, 1)])
 def test_fused_fourstep_fp64(run, oracle, monkeypatch, k, batch):
     """fp64 members of the fused Four-Step family (16-byte elements, 16-column tiles), several chunks"""

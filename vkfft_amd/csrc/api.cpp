@@ -31,6 +31,8 @@ struct AppState {
 	VkFFTApplication* convInv = nullptr;
 	VkFFTPlan* convMid = nullptr;  // merged form (strided power-of-two last axis): ONE pass does that axis forward, the kernel product and the axis backwards;
 	                               // convFwd / convInv then omit the axis (planner.cpp build_conv_axis_plan)
+	VkFFTApplication* convInvFull = nullptr; // merged form only: VkFFTAppend(app, 1) is a plain inverse over ALL axes; convInv lacks the merged one, so that
+	VkFFTConfiguration convInvFullCfg = {};  // direction gets its own application, created at its first use from this configuration
 	uint32_t zeroPadMask = 0;      // zero-padded axes whose plan cannot skip the range: it is written with zeros ahead of the transform that reads it
 };
 
@@ -114,7 +116,11 @@ VKFFT_API int vkfftMI355XDescribePlan(const VkFFTApplication* app, int inverse, 
 	if (st && st->convFwd) {
 		// convolution application: what VkFFTAppend(app, -1) launches — forward transform (without the merged axis), the merged axis or the separate
 		// element-wise product, inverse transform of the results
-		if (inverse == 1) return 0;
+		if (inverse == 1) { // a plain inverse of the results (the merged form builds that application at its first use)
+			const VkFFTApplication* inv = st->convMid ? st->convInvFull : st->convInv;
+			if (inv) describe_passes(inv->localFFTPlan_inverse, names, cap, pos, launches);
+			return launches;
+		}
 		describe_passes(st->convFwd->localFFTPlan, names, cap, pos, launches);
 		if (st->convMid) describe_passes(st->convMid, names, cap, pos, launches);
 		else {
@@ -135,6 +141,7 @@ VKFFT_API void deleteVkFFT(VkFFTApplication* app) {
 		if (st->tempOwned) (void)hipFree(st->tempOwned);
 		if (st->convFwd) { deleteVkFFT(st->convFwd); free(st->convFwd); }
 		if (st->convInv) { deleteVkFFT(st->convInv); free(st->convInv); }
+		if (st->convInvFull) { deleteVkFFT(st->convInvFull); free(st->convInvFull); }
 		free_direction(st->convMid);
 		if (app->saveApplicationString) free(app->saveApplicationString);
 		if (st->events) {
@@ -521,6 +528,7 @@ VkFFTResult initialize_convolution(VkFFTApplication* app, const VkFFTConfigurati
 		for (pfUINT i = 0; i < in.FFTdim && i < 4; i++) if (in.performZeropadding[i] && in.fft_zeropad_right[i] > in.fft_zeropad_left[i]) { d.padL[i] = in.fft_zeropad_left[i]; d.padR[i] = in.fft_zeropad_right[i]; }
 		if (const char* e = getenv("VKFFT_MI355X_GENERIC_ONLY")) d.disableFastKernels = atoi(e) != 0;
 		if (in.sharedMemorySize && in.sharedMemorySize < 160 * 1024) d.disableFastKernels = true;
+		if (in.userTempBuffer && in.tempBufferSize) d.userTempBytes = in.tempBufferSize[0];
 		ConvAxisDesc cd;
 		cd.matrix = (uint32_t)m; cd.coordinates = (uint32_t)c.coordinateFeatures; cd.symmetric = in.symmetricKernel ? 1u : 0u; cd.conjugate = (uint32_t)in.conjugateConvolution;
 		cd.kernelSystems = m > 1 ? (in.symmetricKernel ? m * (m + 1) / 2 : m * m) : c.coordinateFeatures;
@@ -529,10 +537,12 @@ VkFFTResult initialize_convolution(VkFFTApplication* app, const VkFFTConfigurati
 		DirectionPlan* dpl = new (std::nothrow) DirectionPlan();
 		if (pl && dpl) {
 			pl->impl = dpl;
-			if (build_conv_axis_plan(d, cd, *dpl) == 0 && !dpl->arena.empty() && hipMalloc(&dpl->dArena, dpl->arena.size()) == hipSuccess &&
+			// (a caller-supplied temp buffer that is too small for the split merged form: separate passes instead, whose own check reports 2016 if it is too small for them too)
+			if (build_conv_axis_plan(d, cd, *dpl) == 0 && !dpl->arena.empty() && !(d.userTempBytes && dpl->totalTemp() > d.userTempBytes) && hipMalloc(&dpl->dArena, dpl->arena.size()) == hipSuccess &&
 			    hipMemcpy(dpl->dArena, dpl->arena.data(), dpl->arena.size(), hipMemcpyHostToDevice) == hipSuccess &&
 			    (dpl->totalTemp() == 0 || in.userTempBuffer || (hipMalloc(&st->tempOwned, dpl->totalTemp()) == hipSuccess && (st->tempOwnedBytes = dpl->totalTemp(), true)))) {
 				st->convMid = pl;
+				st->convInvFullCfg = b;
 				f.omitDimension[in.FFTdim - 1] = 1; b.omitDimension[in.FFTdim - 1] = 1;
 				if (in.printMemoryLayout || getenv("VKFFT_MI355X_PRINT_PLAN")) fprintf(stderr, "[vkfft_mi355x] convolution: axis %d merged (forward, %ux%u kernel product, inverse in one pass of pow2_col_blue_kernel)\n", (int)in.FFTdim - 1, cd.matrix, cd.matrix);
 			} else free_direction(pl);
@@ -559,7 +569,21 @@ VkFFTResult append_convolution(VkFFTApplication* app, int inverse, VkFFTLaunchPa
 	}
 	VkFFTLaunchParams inv = VKFFT_ZERO_INIT;
 	if (lp) { inv.buffer = lp->buffer; inv.tempBuffer = lp->tempBuffer; inv.bufferOffset = lp->bufferOffset; inv.tempBufferOffset = lp->tempBufferOffset; }
-	if (inverse == 1) return VkFFTAppend(st->convInv, 1, lp ? &inv : nullptr); // a plain inverse of the numberKernels results
+	if (inverse == 1) { // a plain inverse of the numberKernels results, over every axis
+		if (!st->convMid) return VkFFTAppend(st->convInv, 1, lp ? &inv : nullptr);
+		if (!st->convInvFull) { // (convInv omits the merged axis)
+			st->convInvFull = (VkFFTApplication*)calloc(1, sizeof(VkFFTApplication));
+			if (!st->convInvFull) return VKFFT_ERROR_MALLOC_FAILED;
+			VkFFTConfiguration full = st->convInvFullCfg;
+			full.buffer = c.buffer; full.tempBuffer = c.tempBuffer; full.stream = c.stream; full.bufferOffset = c.bufferOffset; full.tempBufferOffset = c.tempBufferOffset;
+			const VkFFTResult r0 = initializeVkFFT(st->convInvFull, full);
+			if (r0 != VKFFT_SUCCESS) { free(st->convInvFull); st->convInvFull = nullptr; return r0; }
+		}
+		VkFFTLaunchParams full = inv;
+		if (!lp || !lp->buffer) full.buffer = c.buffer;
+		if (!full.tempBuffer && c.userTempBuffer) full.tempBuffer = c.tempBuffer;
+		return VkFFTAppend(st->convInvFull, 1, &full);
+	}
 	if (c.kernel == nullptr || c.kernel[0] == nullptr) return VKFFT_ERROR_EMPTY_kernel;
 	if (c.buffer == nullptr || c.buffer[0] == nullptr) return VKFFT_ERROR_EMPTY_buffer;
 	VkFFTResult r = VkFFTAppend(st->convFwd, -1, lp);
@@ -569,7 +593,11 @@ VkFFTResult append_convolution(VkFFTApplication* app, int inverse, VkFFTLaunchPa
 		lb.base[ROLE_BUFFER] = (char*)c.buffer[0] + c.bufferOffset;
 		lb.kernel = (const char*)c.kernel[0] + c.kernelOffset;
 		if (((DirectionPlan*)st->convMid->impl)->totalTemp()) {
-			if (c.userTempBuffer) { if (c.tempBuffer == nullptr || c.tempBuffer[0] == nullptr) return VKFFT_ERROR_EMPTY_tempBuffer; lb.base[ROLE_TEMP] = (char*)c.tempBuffer[0] + c.tempBufferOffset; }
+			if (c.userTempBuffer) { // (the launch parameters may replace the temp buffer, as in VkFFTAppend)
+				void** tb = (lp && lp->tempBuffer) ? lp->tempBuffer : c.tempBuffer;
+				if (tb == nullptr || tb[0] == nullptr) return VKFFT_ERROR_EMPTY_tempBuffer;
+				lb.base[ROLE_TEMP] = (char*)tb[0] + ((lp && c.specifyOffsetsAtLaunch) ? lp->tempBufferOffset : c.tempBufferOffset);
+			}
 			else lb.base[ROLE_TEMP] = st->tempOwned;
 		}
 		StreamSet ss;

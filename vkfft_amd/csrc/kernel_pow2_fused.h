@@ -102,7 +102,7 @@ __device__ inline uint32_t fused_xcc_id() {
 #endif
 }
 
-// MODE bit 1: non-temporal hint on the HBM side
+// MODE bit 1: non-temporal hint on the HBM side; bit 2 (development build only): per-phase cycle sums (tools/prof_fused.py)
 // TWL: stage twiddles staged in LDS (1) or read through the buffer path from L2 (0: where the LDS copy would cost a workgroup per CU)
 // CPT: columns per thread.  2 (fp32 only): a thread keeps two adjacent columns, so that every global and ring access is 16 bytes per lane and
 // every LDS exchange access 16 bytes (the fp64 kernels, whose elements are 16 bytes, measured 10-15 % above the 8-byte fp32 ones)
@@ -117,9 +117,9 @@ pow2_fused_kernel(const FusedParams p) {
 	static_assert(LA * TCA == LB * TCB, "both phases move the same number of points per tile");
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	constexpr int AUX_SC = 16;                   // ring loads: agent scope, served from the memory side
-	constexpr int AUX_ST = (MODE & 32) ? 0 : 16;  // ring stores: write-through (no XCD's L2 ever holds a ring line); (development, MODE bit 5: plain — wrong across XCDs, timing only)
+	constexpr int AUX_ST = 16;                   // ring stores: write-through (no XCD's L2 ever holds a ring line)
 	constexpr int AUX_HBM = (MODE & 2) ? 2 : 0;
-	constexpr int AUX_HBM_LD = (MODE & 128) ? 0 : AUX_HBM, AUX_HBM_ST = (MODE & 64) ? 0 : AUX_HBM; // (development: the hint on one side only)
+	constexpr int AUX_HBM_LD = AUX_HBM, AUX_HBM_ST = AUX_HBM;
 	constexpr int LDSN = LA * TCPA > LB * TCPB ? LA * TCPA : LB * TCPB;
 	constexpr int LUTA = TWL ? SA::lutTotal() : 0, LUTB = TWL ? SB::lutTotal() : 0;
 	__shared__ cx<T> lds[LDSN + LUTA + LUTB];
@@ -233,12 +233,10 @@ pow2_fused_kernel(const FusedParams p) {
 #pragma unroll
 						for (int m = 0; m < CPT * EA; m++) v[m] = cswap(v[m]);
 					}
-					if constexpr ((MODE & 8) == 0) fused_stages<T, SA, TPFA, TCPA, TWL, CPT>(v, lds + c, twA, p.lutA, oz, tau);
+					fused_stages<T, SA, TPFA, TCPA, TWL, CPT>(v, lds + c, twA, p.lutA, oz, tau);
 					VKFFT_PROF(8);
-					if constexpr ((MODE & 8) == 0) {
 #pragma unroll
-						for (int cc = 0; cc < CPT; cc++) pow2_fs_twiddle<T, SA::LOGE, TPFA>(v + cc * EA, gtw, p.fsLoBits, tau, col0 + c + cc);
-					}
+					for (int cc = 0; cc < CPT; cc++) pow2_fs_twiddle<T, SA::LOGE, TPFA>(v + cc * EA, gtw, p.fsLoBits, tau, col0 + c + cc);
 					VKFFT_PROF(9);
 					if constexpr (SA::NS > 1) VKFFT_SYNC(); // the last exchange's reads are complete
 #pragma unroll
@@ -250,7 +248,7 @@ pow2_fused_kernel(const FusedParams p) {
 					VKFFT_PROF(10);
 				}
 			}
-			if (live && (MODE & 16) == 0) {
+			if (live) {
 				const GBuf gs = make_gbuf(sbase + (uint64_t)col0 * LA * ES);
 				if constexpr (sizeof(T) == 4) {
 					// two consecutive k per lane: 16-byte write-through stores (8-byte sc1 stores cost 2.7x per byte)
@@ -278,8 +276,8 @@ pow2_fused_kernel(const FusedParams p) {
 			if (!okB) { fused_wait(p.ctr + depB(s), TPC); VKFFT_PROF(6); } // rare (okB was sampled one ticket ago: ordered before the loads by S1)
 #pragma unroll
 			for (int m = 0; m < EB; m++) {
-				if constexpr (CPT == 1) vB[m] = gb_load_x<T, AUX_SC>(gsB, (MODE & 16) ? kGbInvalid : laneB, m * stepB);
-				else gb_load2_x<T, AUX_SC>(gsB, (MODE & 16) ? kGbInvalid : laneB, m * stepB, vB[m], vB[EB + m]);
+				if constexpr (CPT == 1) vB[m] = gb_load_x<T, AUX_SC>(gsB, laneB, m * stepB);
+				else gb_load2_x<T, AUX_SC>(gsB, laneB, m * stepB, vB[m], vB[EB + m]);
 			}
 			VKFFT_VMEM_DRAIN(); // the tile is in registers; the A part's ring stores are acknowledged
 			VKFFT_SYNC();    // S3: ... in every wave
@@ -289,7 +287,7 @@ pow2_fused_kernel(const FusedParams p) {
 				fused_publish(p.ctr, pending);
 			}
 			if (liveB) {
-				if constexpr ((MODE & 8) == 0) fused_stages<T, SB, TPFB, TCPB, TWL, CPT>(vB, lds + cBl, twB, p.lutB, oz, tauB);
+				fused_stages<T, SB, TPFB, TCPB, TWL, CPT>(vB, lds + cBl, twB, p.lutB, oz, tauB);
 				if (p.swapOut) {
 #pragma unroll
 					for (int m = 0; m < CPT * EB; m++) vB[m] = cswap(vB[m]);
@@ -333,7 +331,6 @@ struct Pow2FusedVariant {
 	int log2n; bool dp; int mode; int la, lb; int bitsA[4], bitsB[4]; int tca, tcb, threads, wgPerCu; // la, lb: log2 of the two factors
 	void (*launch)(const FusedParams&, dim3, hipStream_t);
 	const void* fn;
-	int gen; // 1: kernel_pow2_fused.h, 2: kernel_pow2_fused2.h (LDS-DMA double buffering)
 };
 
 template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE, int TWL, int CPT> void pow2_fused_launch(const FusedParams& prm, dim3 grid, hipStream_t s) {

@@ -1,9 +1,6 @@
 // Instantiations and registry of the fused Four-Step kernels (kernel_pow2_fused.h): own translation unit (build time).
 #include "engine.h"
 #include "kernel_pow2_fused.h"
-#if defined(VKFFT_MI355X_DEV) || defined(VKFFT_HOSTEMU)
-#include "kernel_pow2_fused2.h"
-#endif
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
@@ -15,33 +12,17 @@ namespace vkfft_mi355x {
 	{ (a0) + (a1) + (a2) + (b0) + (b1) + (b2), dp, mode, (a0) + (a1) + (a2), (b0) + (b1) + (b2), {a0, a1, a2, 0}, {b0, b1, b2, 0}, tca, tcb, \
 	  ((1 << ((a0) + (a1) + (a2))) >> Pow2Sched<a0, a1, a2, 0>::LOGE) * (tca) / (cpt), pow2_fused_wg_per_cu<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, twl, cpt>(), \
 	  &pow2_fused_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt>, \
-	  (const void*)&pow2_fused_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt>, 1 }
-// mode 2 = product (non-temporal hint on the streamed side); the others exist only in development builds (-DVKFFT_MI355X_DEV):
-// 0 = no hint, 66 / 130 = hint on the loads / on the stores only, 6 = per-phase cycle profile, 8 / 16 / 24 = without the FFT arithmetic / without the ring traffic / without both
+	  (const void*)&pow2_fused_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt> }
+// mode 2 = product (non-temporal hint on the streamed side); the development build (-DVKFFT_MI355X_DEV) adds mode 6 = the same with per-phase cycle sums
 #if defined(VKFFT_MI355X_DEV)
 #define VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, cpt) \
-	VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 0, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 8, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 16, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 24, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 34, twl, cpt), \
-	VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 66, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 130, twl, cpt)
+	VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, cpt), VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, twl, cpt)
 #else
 #define VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, cpt) VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, cpt)
 #endif
 #define VKFFT_FUT(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, 1)
 #define VKFFT_FU(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 1)
 #define VKFFT_FU2(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 2) /* two columns per thread */
-
-// second generation (kernel_pow2_fused2.h): tiles arrive by LDS-DMA into two buffers, the next tile in flight while the current one computes
-#define VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, mode, cpt, wpc) \
-	{ (a0) + (a1) + (a2) + (b0) + (b1) + (b2), dp, mode, (a0) + (a1) + (a2), (b0) + (b1) + (b2), {a0, a1, a2, 0}, {b0, b1, b2, 0}, tca, tcb, \
-	  Fused2Shape<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, cpt>::NT, wpc, \
-	  &pow2_fused2_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, cpt, wpc>, \
-	  (const void*)&pow2_fused2_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, cpt, wpc>, 2 }
-#if defined(VKFFT_MI355X_DEV)
-#define VKFFT_FG(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, cpt, wpc) \
-	VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 10, cpt, wpc), \
-	VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 18, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 26, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 34, cpt, wpc), VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 42, cpt, wpc)
-#else
-#define VKFFT_FG(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, cpt, wpc) VKFFT_FG1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, cpt, wpc)
-#endif
 
 // first entry of each (log2 N, dp, mode) is the default; VKFFT_MI355X_FUV<log2n>=k selects the k-th shape (tuning)
 static const Pow2FusedVariant kPow2FusedVariants[] = {
@@ -58,15 +39,6 @@ static const Pow2FusedVariant kPow2FusedVariants[] = {
 	// 2^18 = 512 x 512
 	VKFFT_FU2(float, false, 4, 3, 2, 16, 4, 3, 2, 16),
 	VKFFT_FU(float, false, 5, 4, 0, 16, 5, 4, 0, 16),
-#if defined(VKFFT_MI355X_DEV) || defined(VKFFT_HOSTEMU)
-	// Second generation (kernel_pow2_fused2.h: service wave + LDS-DMA), measured and NOT adopted (profiles/r03_fused_gen2*): development
-	// and emulator builds only; the first entries above stay the defaults.  VKFFT_MI355X_FUV<k> = 2.. selects them (15, 17, 18: index 2; 16: 2, 3)
-	VKFFT_FG(float, false, 4, 3, 0, 32, 4, 4, 0, 16, 1, 2),
-	VKFFT_FG(float, false, 4, 4, 0, 16, 4, 4, 0, 16, 1, 2),
-	VKFFT_FG(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 1, 1),
-	VKFFT_FG(float, false, 4, 4, 0, 32, 4, 3, 2, 16, 1, 1),
-	VKFFT_FG(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 1),
-#endif
 	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: one workgroup per CU (the 1024-point column tile needs 139 KiB of LDS); 8-column tiles
 	// (two workgroups per CU, 64-byte segments on the HBM side) measured 12 % slower, 2^20 as 512 x 2048 20 % slower
 	VKFFT_FU2(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
@@ -149,21 +121,6 @@ int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t st
 		double sum[12] = {};
 		for (uint64_t w = 0; w < grid; w++) for (int i = 0; i < 12; i++) sum[i] += (double)h[w * 12 + i];
 		const double nt = sum[7] > 0 ? sum[7] : 1;
-		if (v.gen == 2) { // two records per workgroup: compute thread 0 and the ticket thread (service wave)
-			std::vector<unsigned long long> h2(grid * 24);
-			(void)hipMemcpy(h2.data(), dbuf, h2.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-			static const char* nm[12] = {"top_wait_and_barrier", "A_landing_read", "A_stages", "A_fs_twiddle", "A_transpose", "unused5", "B_request_and_ring_stores", "", "mid_barrier", "unused9", "B_stages", "B_hbm_stores_and_tail"};
-			for (int who = 0; who < 2; who++) {
-				double sm[12] = {};
-				for (uint64_t w = 0; w < grid; w++) for (int i = 0; i < 12; i++) sm[i] += (double)h2[(w * 2 + who) * 12 + i];
-				const double ntk = sm[7] / 1e6 > 0 ? sm[7] / 1e6 : 1;
-				double tot = 0;
-				fprintf(stderr, "{\"fused2_profile\": {\"log2n\": %d, \"tca\": %d, \"tcb\": %d, \"threads\": %d, \"grid\": %llu, \"thread\": \"%s\", \"tickets_per_wg\": %.1f, \"cycles_per_ticket\": {", v.log2n, v.tca, v.tcb, v.threads, (unsigned long long)grid, who ? "ticket thread (service wave)" : "compute thread 0", ntk / grid);
-				for (int i = 0; i < 12; i++) { if (i == 7) continue; fprintf(stderr, "\"%s\": %.0f, ", nm[i], sm[i] / ntk); tot += sm[i] / ntk; }
-				fprintf(stderr, "\"total\": %.0f}}}\n", tot);
-			}
-			return 0;
-		}
 		fprintf(stderr, "[fused profile] grid %llu tickets/wg %.1f | cycles per ticket: S1 %.0f  A-load %.0f  A-stages %.0f A-twiddle %.0f A-transpose %.0f A-stores %.0f  B-load %.0f  B-compute %.0f  waitA %.0f waitB %.0f | total %.0f\n",
 		        (unsigned long long)grid, nt / grid, sum[0] / nt, sum[1] / nt, sum[8] / nt, sum[9] / nt, sum[10] / nt, sum[2] / nt, sum[3] / nt, sum[4] / nt, sum[5] / nt, sum[6] / nt, (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6] + sum[8] + sum[9] + sum[10]) / nt);
 		return 0;
