@@ -4,13 +4,11 @@ ARCH ?= gfx950
 CSRC := vkfft_amd/csrc
 LIBDIR := vkfft_amd/lib
 CXXFLAGS := -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I$(CSRC) -Wno-unused-result
-OBJS := build/obj/api.o build/obj/planner.o build/obj/kernels.o build/obj/kernels_blue_r2r.o build/obj/kernels_fused.o build/obj/kernels_aux.o build/obj/kernels_mixed_0.o build/obj/kernels_mixed_1.o build/obj/kernels_mixed_2.o build/obj/kernels_mixed_3.o build/obj/kernels_mixed_4.o build/obj/kernels_mixed_5.o \
+OBJS := build/obj/api.o build/obj/planner.o build/obj/kernels.o build/obj/kernels_pow2.o build/obj/kernels_blue_r2r.o build/obj/kernels_fused.o build/obj/kernels_aux.o build/obj/kernels_mixed_0.o build/obj/kernels_mixed_1.o build/obj/kernels_mixed_2.o build/obj/kernels_mixed_3.o build/obj/kernels_mixed_4.o build/obj/kernels_mixed_5.o \
         build/obj/kernels_mixconv_0.o build/obj/kernels_mixconv_1.o build/obj/kernels_mixconv_2.o build/obj/kernels_mixconv_3.o build/obj/kernels_mixconv_4.o build/obj/kernels_mixconv_5.o \
         $(foreach t,f32_row f32_col f64_row f64_col,build/obj/kernels_opfft_$(t)_0.o build/obj/kernels_opfft_$(t)_1.o)
-FUSED_HDRS := $(CSRC)/kernel_pow2_fused.h
-MIXCONV_HDRS := $(CSRC)/kernel_mixconv.h
-OTHER_INC := $(filter-out $(wildcard $(CSRC)/mixconv_table_*.inc),$(wildcard $(CSRC)/*.inc))
-HDRS := $(filter-out $(FUSED_HDRS) $(MIXCONV_HDRS),$(wildcard $(CSRC)/*.h)) include/vkFFT.h
+# header dependencies come from the compiler (-MMD): a change to one kernel family rebuilds only the translation units that include it
+DEPFLAGS = -MMD -MP -MF build/obj/$*.d
 
 all: $(LIBDIR)/libvkfft_mi355x.so build/vkfft_mi355x_cli $(if $(wildcard /opt/rocm/lib/librccl.so),build/vkfft_mi355x_multi)
 multi: build/vkfft_mi355x_multi
@@ -25,18 +23,13 @@ build/vkfft_mi355x_multi: tools/vkfft_multi.cpp include/vkFFT.h $(LIBDIR)/libvkf
 	@mkdir -p build
 	$(HIPCC) -O2 -std=c++17 -pthread -Wno-unused-value -Wno-unused-result -Iinclude tools/vkfft_multi.cpp -L$(LIBDIR) -lvkfft_mi355x -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib -o $@
 
-build/obj/%.o: $(CSRC)/%.cpp $(HDRS)
+build/obj/%.o: $(CSRC)/%.cpp
 	@mkdir -p build/obj
-	$(HIPCC) $(CXXFLAGS) --offload-arch=$(ARCH) -c $< -o $@
+	$(HIPCC) $(CXXFLAGS) $(DEPFLAGS) --offload-arch=$(ARCH) -c $< -o $@
 
-# (generated tables: every family's translation units depend on their own .inc files only)
-build/obj/kernels_mixconv_%.o: $(CSRC)/kernels_mixconv_%.hip $(HDRS) $(MIXCONV_HDRS) $(CSRC)/mixconv_table_%.inc
+build/obj/%.o: $(CSRC)/%.hip
 	@mkdir -p build/obj
-	$(HIPCC) $(CXXFLAGS) --offload-arch=$(ARCH) -c $< -o $@
-
-build/obj/%.o: $(CSRC)/%.hip $(HDRS) $(OTHER_INC)
-	@mkdir -p build/obj
-	$(HIPCC) $(CXXFLAGS) --offload-arch=$(ARCH) -c $< -o $@
+	$(HIPCC) $(CXXFLAGS) $(DEPFLAGS) --offload-arch=$(ARCH) -c $< -o $@
 
 $(LIBDIR)/libvkfft_mi355x.so: $(OBJS)
 	@mkdir -p $(LIBDIR)
@@ -44,11 +37,9 @@ $(LIBDIR)/libvkfft_mi355x.so: $(OBJS)
 
 # development build of the fused Four-Step kernels (per-phase cycle profile, arithmetic-free variants): tools/prof_fused.py,
 # selected with VKFFT_MI355X_LIB=build/libvkfft_mi355x_dev.so; never shipped
-build/obj/kernels_fused.o: $(FUSED_HDRS)
-build/obj/kernels.o: $(MIXCONV_HDRS)
-build/obj/kernels_fused_dev.o: $(CSRC)/kernels_fused.hip $(HDRS) $(FUSED_HDRS)
+build/obj/kernels_fused_dev.o: $(CSRC)/kernels_fused.hip
 	@mkdir -p build/obj
-	$(HIPCC) $(CXXFLAGS) -DVKFFT_MI355X_DEV --offload-arch=$(ARCH) -c $< -o $@
+	$(HIPCC) $(CXXFLAGS) -DVKFFT_MI355X_DEV -MMD -MP -MF build/obj/kernels_fused_dev.d --offload-arch=$(ARCH) -c $< -o $@
 build/libvkfft_mi355x_dev.so: $(OBJS) build/obj/kernels_fused_dev.o
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(filter-out build/obj/kernels_fused.o,$(OBJS)) build/obj/kernels_fused_dev.o -o $@
 dev: build/libvkfft_mi355x_dev.so
@@ -58,5 +49,7 @@ oracle:
 
 clean:
 	rm -rf build/obj $(LIBDIR)/*.so
+
+-include $(wildcard build/obj/*.d)
 
 .PHONY: all oracle clean dev multi

@@ -126,12 +126,17 @@ def main():
     max_abs_err = float(diff.abs().max())
     finite = bool(torch.isfinite(buf).all())
     del diff, initial
-    rt_limit = 2e-6 * (args.steps + args.warmup) ** 0.5
+    # The rounding of a transform is a FIXED perturbation of the exact operator (the same twiddle tables and butterflies every time), so the errors of
+    # repeated pairs on the same buffer add coherently: the limit is linear in the number of pairs, 3e-7 per pair (a single pair measures 2.2-3.0e-7
+    # and is asserted below 2e-6 in tests/; measured over 90 pairs: 1.06e-5 = 1.2e-7 per pair); the largest element error is bounded at 8x the
+    # same figure in absolute units (inputs uniform in [-1, 1]: a single wrong element anywhere in the 2^27 points is off by ~0.5)
+    pairs = (args.steps + args.warmup) * (KMAX - KMIN + 1)
+    rt_limit = 3e-7 * pairs
     if dist:
         t = torch.tensor([roundtrip_rel_l2, max_abs_err, 0.0 if finite else 1.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         roundtrip_rel_l2, max_abs_err, finite = float(t[0]), float(t[1]), float(t[2]) == 0.0
-    if not finite or not (roundtrip_rel_l2 <= rt_limit):
+    if not finite or not (roundtrip_rel_l2 <= rt_limit) or not (max_abs_err <= 8 * rt_limit):
         raise SystemExit(f"bench.py: result check failed after the timed loop: round-trip rel. L2 {roundtrip_rel_l2:.3e} (limit {rt_limit:.3e}), "
                          f"max |err| {max_abs_err:.3e}, finite={finite}")
     if dist:
@@ -223,7 +228,7 @@ def main():
                                sizes_log2=[KMIN, KMAX], buffer_bytes_per_gpu=8 << TOTAL_LOG2, parallelism=f"batch-sharded x{world}, no collectives"),
                    alg_GBps=round(bytes_step / (ms_per_step * 1e-3) / 1e9, 1),
                    roundtrip_rel_l2=float(f"{roundtrip_rel_l2:.3e}"), max_abs_err=float(f"{max_abs_err:.3e}"), roundtrip_limit_rel_l2=float(f"{rt_limit:.3e}"),
-                   roundtrip_pairs=(args.steps + args.warmup) * (KMAX - KMIN + 1), per_size=per_size, roofline=roofline, cpu_baseline=cpu)
+                   roundtrip_pairs=pairs, per_size=per_size, roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()

@@ -86,7 +86,7 @@ def test_bluestein_multi_pass_fused(run, oracle, N, dp, uploads):
     assert up == [uploads]
 
 
-@pytest.mark.parametrize("N,passes", [(1 << 15, 2), (1 << 16, 2), (1 << 18, 2), (3 ** 10, 2), (1 << 21, 2), (5 ** 9, 3)])
+@pytest.mark.parametrize("N,passes", [(1 << 15, 1), (1 << 16, 2), (1 << 18, 2), (3 ** 10, 2), (1 << 21, 2), (5 ** 9, 3)])
 def test_fourstep(run, oracle, N, passes):
     up = parity.check_c2c(run, oracle, (N,), 1, False, use_c_oracle=N <= (1 << 16))
     assert up == [passes]
@@ -282,7 +282,7 @@ def test_out_of_place_formatted_buffers(emu_lib):
 
 
 def test_user_temp_buffer_too_small(emu_lib):
-    N = 1 << 15
+    N = 1 << 16
     buf = np.zeros(N, np.complex64); tmp = np.zeros(16, np.complex64)
     with pytest.raises(api.VkFFTError) as e:
         api.App([N], 1, buffer_ptr=buf.ctypes.data, userTempBuffer=1, tempBuffer=tmp.ctypes.data, tempBufferSize=tmp.nbytes, lib=emu_lib)
@@ -325,6 +325,57 @@ def test_fused_fourstep_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag
     monkeypatch.setenv("VKFFT_MI355X_FUSED_LAG", str(lag))
     monkeypatch.setenv("VKFFT_MI355X_FUSED_RING", str(ring))
     monkeypatch.setenv("VKFFT_MI355X_FUSED_QUEUES", str(queues))
+    monkeypatch.setenv("VKFFT_MI355X_ROW15", "0")  # (2^15 runs as one pass of the register-lean row kernel since round 4: keep the two-pass plan here)
+    x = parity.seeded_complex(N * batch, False, N + batch)
+    y, z, up = run.transform(x, (N,), batch, both=True)
+    assert up == [2]
+    assert rel_l2(y, oracle.truth_c2c(x, (N,), batch)) < 1e-6
+    assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
+
+
+@pytest.mark.parametrize("k,variant", [(13, v) for v in range(6)] + [(14, v) for v in range(6)] + [(15, v) for v in range(4)])
+def test_register_lean_rows_every_variant(run, oracle, monkeypatch, k, variant):
+    """kernel_pow2_lean.h: 32 points per thread, real / imaginary planes exchanged one after the other, in-place DIF butterflies, twiddles in chunks (with
+    and without the prefetch across the exchange) — every registered shape of 2^13, 2^14 and the one-pass 2^15, next to the round-1 kernels they replace"""
+    monkeypatch.setenv(f"VKFFT_MI355X_P2V{k}", str(variant))
+    N = 1 << k
+    x = parity.seeded_complex(N * 3, False, N + variant)
+    y, z, up = run.transform(x, (N,), 3, both=True)
+    assert up == [1]
+    truth = oracle.truth_c2c(x, (N,), 3)
+    assert rel_l2(y, truth) < 1e-6
+    from helpers import assert_elementwise
+    assert_elementwise(y, truth, "c2c", False, f"2^{k} variant {variant}")
+    assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
+
+
+def test_register_lean_row_strides_padding_and_scale(run, oracle):
+    """the lean row kernel behind the general plan features: padded batch stride, zero padding (read and write masks), normalised inverse"""
+    N = 1 << 14
+    rng = np.random.default_rng(7)
+    pitch = N + 24
+    buf = (rng.uniform(-1, 1, (3, pitch)) + 1j * rng.uniform(-1, 1, (3, pitch))).astype(np.complex64)
+    h, ptr = run._alloc(buf.reshape(-1))
+    app = api.App([N], 3, buffer_ptr=ptr, lib=run.lib, normalize=True, bufferStride=[pitch])
+    app.forward(); y = run._fetch(h, np.complex64).reshape(3, pitch)
+    app.inverse(); z = run._fetch(h, np.complex64).reshape(3, pitch); app.delete()
+    assert rel_l2(y[:, :N], np.fft.fft(buf[:, :N].astype(np.complex128), axis=1)) < 1e-6
+    assert np.array_equal(y[:, N:], buf[:, N:]) and np.array_equal(z[:, N:], buf[:, N:])  # the gap between rows is never touched
+    assert rel_l2(z[:, :N], buf[:, :N]) < 2e-6
+    import convpad
+    assert convpad.zeropad_case(run, (N,), {0: (N // 2, N)}, batch=2) < 3e-6
+
+
+@pytest.mark.parametrize("k,variant,batch", [(15, 2, 5), (16, 2, 3), (17, 2, 3), (18, 0, 3), (19, 2, 2), (20, 2, 2), (21, 0, 1), (22, 0, 1)])
+def test_fused_fourstep_register_lean_shapes(run, oracle, monkeypatch, k, variant, batch):
+    """the register-lean form of the fused Four-Step kernel (two columns per thread, plane-split exchanges, tile turned through the plane for the
+    ring stores): the shipping shapes of 2^18, 2^21 and 2^22 (2048-point tiles 16 columns wide) and the measured-but-not-adopted ones of the other sizes"""
+    monkeypatch.setenv(f"VKFFT_MI355X_FUV{k}", str(variant))
+    monkeypatch.setenv("VKFFT_MI355X_ROW15", "0")
+    if k <= 18:
+        monkeypatch.setenv("VKFFT_MI355X_FUSED_CHUNK_KIB", str((8 << k) >> 10)); monkeypatch.setenv("VKFFT_MI355X_FUSED_LAG", "2")
+        monkeypatch.setenv("VKFFT_MI355X_FUSED_RING", "3"); monkeypatch.setenv("VKFFT_MI355X_FUSED_QUEUES", "2")
+    N = 1 << k
     x = parity.seeded_complex(N * batch, False, N + batch)
     y, z, up = run.transform(x, (N,), batch, both=True)
     assert up == [2]

@@ -1,6 +1,7 @@
 // Hand-specialised power-of-two kernels and their registries (design notes: kernel_pow2_core.h).
 #pragma once
 #include "kernel_pow2_core.h"
+#include "kernel_pow2_lean.h"
 
 namespace vkfft_mi355x {
 
@@ -501,159 +502,6 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 			gb_store<T>(gout, in ? (c + (tau + m * TPF) * stride) * ES : kGbInvalid, 0, y);
 		}
 	}
-}
-
-// ---- registry --------------------------------------------------------------------------------------------
-
-template <typename T, typename SCH, int FPW> void pow2_row_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
-	constexpr int threads = ((1 << SCH::LOGN) >> SCH::LOGE) * FPW;
-	hipLaunchKernelGGL((pow2_row_kernel<T, SCH, FPW>), grid, dim3(threads), 0, s, prm);
-}
-
-template <typename T, typename SCH, int TC> void pow2_col_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
-	constexpr int threads = ((1 << SCH::LOGN) >> SCH::LOGE) * TC;
-	if (prm.bigSpan) hipLaunchKernelGGL((pow2_col_kernel<T, SCH, TC, true>), grid, dim3(threads), 0, s, prm);
-	else hipLaunchKernelGGL((pow2_col_kernel<T, SCH, TC, false>), grid, dim3(threads), 0, s, prm);
-}
-
-#define VKFFT_P2C(T, dp, b0, b1, b2, b3, tc) \
-	{ (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, tc, (((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (tc)), &pow2_col_launch<T, Pow2Sched<b0, b1, b2, b3>, tc> }
-
-#define VKFFT_P2(T, dp, b0, b1, b2, b3, fpw) \
-	{ (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, fpw, (((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (fpw)), &pow2_row_launch<T, Pow2Sched<b0, b1, b2, b3>, fpw> }
-
-// first entry of each (log2n, dp) is the default; VKFFT_MI355X_P2V<log2n>=k selects the k-th (tuning)
-static const Pow2Variant kPow2Variants[] = {
-	// fp32
-	VKFFT_P2(float, false, 2, 0, 0, 0, 64),
-	VKFFT_P2(float, false, 3, 0, 0, 0, 64),
-	VKFFT_P2(float, false, 4, 0, 0, 0, 64),
-	VKFFT_P2(float, false, 3, 2, 0, 0, 32),
-	VKFFT_P2(float, false, 3, 3, 0, 0, 32),
-	VKFFT_P2(float, false, 4, 3, 0, 0, 16), VKFFT_P2(float, false, 3, 2, 2, 0, 16),
-	VKFFT_P2(float, false, 4, 4, 0, 0, 8), VKFFT_P2(float, false, 4, 4, 0, 0, 16), VKFFT_P2(float, false, 3, 3, 2, 0, 8), VKFFT_P2(float, false, 3, 3, 2, 0, 4),
-	VKFFT_P2(float, false, 5, 4, 0, 0, 8), VKFFT_P2(float, false, 4, 3, 2, 0, 8), VKFFT_P2(float, false, 3, 3, 3, 0, 4), VKFFT_P2(float, false, 4, 3, 2, 0, 4), VKFFT_P2(float, false, 5, 4, 0, 0, 4),
-	VKFFT_P2(float, false, 5, 5, 0, 0, 8), VKFFT_P2(float, false, 4, 3, 3, 0, 4), VKFFT_P2(float, false, 4, 3, 3, 0, 2), VKFFT_P2(float, false, 5, 5, 0, 0, 4), VKFFT_P2(float, false, 5, 5, 0, 0, 2),
-	VKFFT_P2(float, false, 5, 5, 1, 0, 2), VKFFT_P2(float, false, 4, 4, 3, 0, 1), VKFFT_P2(float, false, 4, 4, 3, 0, 2), VKFFT_P2(float, false, 5, 5, 1, 0, 4), VKFFT_P2(float, false, 4, 4, 3, 0, 4),
-	VKFFT_P2(float, false, 4, 4, 4, 0, 1), VKFFT_P2(float, false, 5, 5, 2, 0, 1), VKFFT_P2(float, false, 4, 4, 4, 0, 2), VKFFT_P2(float, false, 5, 5, 2, 0, 2),
-	VKFFT_P2(float, false, 5, 4, 4, 0, 1), VKFFT_P2(float, false, 4, 3, 3, 3, 1), VKFFT_P2(float, false, 5, 5, 3, 0, 1),
-	VKFFT_P2(float, false, 5, 5, 4, 0, 1), VKFFT_P2(float, false, 4, 4, 3, 3, 1), VKFFT_P2(float, false, 4, 4, 4, 2, 1),
-	// fp64
-	VKFFT_P2(double, true, 2, 0, 0, 0, 64),
-	VKFFT_P2(double, true, 3, 0, 0, 0, 64),
-	VKFFT_P2(double, true, 4, 0, 0, 0, 64),
-	VKFFT_P2(double, true, 3, 2, 0, 0, 32),
-	VKFFT_P2(double, true, 3, 3, 0, 0, 32),
-	VKFFT_P2(double, true, 3, 2, 2, 0, 16),
-	VKFFT_P2(double, true, 3, 3, 2, 0, 8),
-	VKFFT_P2(double, true, 3, 3, 3, 0, 4),
-	VKFFT_P2(double, true, 3, 3, 2, 2, 2), VKFFT_P2(double, true, 4, 3, 3, 0, 2),
-	VKFFT_P2(double, true, 3, 3, 3, 2, 1), VKFFT_P2(double, true, 4, 4, 3, 0, 1),
-	VKFFT_P2(double, true, 3, 3, 3, 3, 1), VKFFT_P2(double, true, 4, 4, 4, 0, 1),
-	VKFFT_P2(double, true, 4, 3, 3, 3, 1),
-};
-constexpr int kNumPow2Variants = (int)(sizeof(kPow2Variants) / sizeof(kPow2Variants[0]));
-
-// column kernels: first entry of each (log2n, dp) is the default; VKFFT_MI355X_P2C<log2n>=k selects the k-th
-static const Pow2Variant kPow2ColVariants[] = {
-	VKFFT_P2C(float, false, 1, 0, 0, 0, 64), VKFFT_P2C(float, false, 2, 0, 0, 0, 64), VKFFT_P2C(float, false, 3, 0, 0, 0, 64), // thin axes (a depth of 2, 4, 8): one butterfly per thread
-	VKFFT_P2C(float, false, 2, 2, 0, 0, 32), VKFFT_P2C(float, false, 2, 2, 0, 0, 16),
-	VKFFT_P2C(float, false, 3, 2, 0, 0, 32), VKFFT_P2C(float, false, 3, 2, 0, 0, 16),
-	VKFFT_P2C(float, false, 3, 3, 0, 0, 32), VKFFT_P2C(float, false, 3, 3, 0, 0, 16),
-	VKFFT_P2C(float, false, 4, 3, 0, 0, 32), VKFFT_P2C(float, false, 4, 3, 0, 0, 16), VKFFT_P2C(float, false, 3, 2, 2, 0, 32),
-	VKFFT_P2C(float, false, 4, 4, 0, 0, 32), VKFFT_P2C(float, false, 4, 4, 0, 0, 16), VKFFT_P2C(float, false, 3, 3, 2, 0, 32), VKFFT_P2C(float, false, 3, 3, 2, 0, 16), VKFFT_P2C(float, false, 5, 3, 0, 0, 32),
-	VKFFT_P2C(float, false, 5, 4, 0, 0, 32), VKFFT_P2C(float, false, 4, 3, 2, 0, 16), VKFFT_P2C(float, false, 4, 3, 2, 0, 32), VKFFT_P2C(float, false, 3, 3, 3, 0, 16), VKFFT_P2C(float, false, 5, 4, 0, 0, 16),
-	VKFFT_P2C(float, false, 5, 5, 0, 0, 16), VKFFT_P2C(float, false, 4, 3, 3, 0, 16), VKFFT_P2C(float, false, 4, 3, 3, 0, 8),
-	VKFFT_P2C(double, true, 1, 0, 0, 0, 32), VKFFT_P2C(double, true, 2, 0, 0, 0, 32), VKFFT_P2C(double, true, 3, 0, 0, 0, 32),
-	VKFFT_P2C(double, true, 2, 2, 0, 0, 16),
-	VKFFT_P2C(double, true, 3, 2, 0, 0, 16),
-	VKFFT_P2C(double, true, 3, 3, 0, 0, 16),
-	VKFFT_P2C(double, true, 3, 2, 2, 0, 16), VKFFT_P2C(double, true, 4, 3, 0, 0, 16),
-	VKFFT_P2C(double, true, 3, 3, 2, 0, 16), VKFFT_P2C(double, true, 4, 4, 0, 0, 16),
-	VKFFT_P2C(double, true, 3, 3, 3, 0, 8), VKFFT_P2C(double, true, 4, 3, 2, 0, 8), VKFFT_P2C(double, true, 3, 3, 3, 0, 16),
-	VKFFT_P2C(double, true, 4, 3, 3, 0, 8),
-};
-constexpr int kNumPow2ColVariants = (int)(sizeof(kPow2ColVariants) / sizeof(kPow2ColVariants[0]));
-
-// fused Bluestein on a power-of-two padded length: one entry per (log2 M, dp)
-template <typename T, typename SCH, int FPW> void pow2_blue_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
-	constexpr int threads = ((1 << SCH::LOGN) >> SCH::LOGE) * FPW;
-	const unsigned resident = pow2_num_cus() * 8u; // persistent: the workgroups stride over the row tiles
-	hipLaunchKernelGGL((pow2_blue_kernel<T, SCH, FPW>), dim3(grid.x < resident ? grid.x : resident), dim3(threads), 0, s, prm);
-}
-#define VKFFT_P2B(T, dp, b0, b1, b2, b3, fpw) \
-	{ (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, fpw, (((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (fpw)), &pow2_blue_launch<T, Pow2Sched<b0, b1, b2, b3>, fpw> }
-static const Pow2Variant kPow2BlueVariants[] = {
-	VKFFT_P2B(float, false, 3, 3, 0, 0, 32),
-	VKFFT_P2B(float, false, 4, 3, 0, 0, 16),
-	VKFFT_P2B(float, false, 4, 4, 0, 0, 16),
-	VKFFT_P2B(float, false, 4, 3, 2, 0, 8),
-	VKFFT_P2B(float, false, 4, 3, 3, 0, 4),
-	VKFFT_P2B(float, false, 4, 4, 3, 0, 2),
-	VKFFT_P2B(float, false, 4, 4, 4, 0, 1),
-	VKFFT_P2B(float, false, 4, 3, 3, 3, 1),
-	VKFFT_P2B(float, false, 4, 4, 3, 3, 1),
-	VKFFT_P2B(double, true, 3, 3, 0, 0, 32),
-	VKFFT_P2B(double, true, 3, 2, 2, 0, 16),
-	VKFFT_P2B(double, true, 3, 3, 2, 0, 8),
-	VKFFT_P2B(double, true, 3, 3, 3, 0, 4),
-	VKFFT_P2B(double, true, 3, 3, 2, 2, 2),
-	VKFFT_P2B(double, true, 3, 3, 3, 2, 1),
-	VKFFT_P2B(double, true, 3, 3, 3, 3, 1),
-	VKFFT_P2B(double, true, 4, 3, 3, 3, 1),
-};
-constexpr int kNumPow2BlueVariants = (int)(sizeof(kPow2BlueVariants) / sizeof(kPow2BlueVariants[0]));
-
-// multi-pass Bluestein column kernels: one entry per (log2 L, dp, mode); Pow2Variant::fpw holds the tile width
-template <typename T, typename SCH, int TC, int MODE> void pow2_col_blue_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
-	constexpr int threads = ((1 << SCH::LOGN) >> SCH::LOGE) * TC;
-	hipLaunchKernelGGL((pow2_col_blue_kernel<T, SCH, TC, MODE>), grid, dim3(threads), 0, s, prm);
-}
-struct Pow2ColBlueVariant { Pow2Variant v; int mode; };
-#define VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, mode) \
-	{ { (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, tc, (((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (tc)), &pow2_col_blue_launch<T, Pow2Sched<b0, b1, b2, b3>, tc, mode> }, mode }
-#define VKFFT_P2CB(T, dp, b0, b1, b2, b3, tc) VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 1), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 2), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 3), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 4), \
-	VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 5), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 6), VKFFT_P2CB1(T, dp, b0, b1, b2, b3, tc, 8)
-static const Pow2ColBlueVariant kPow2ColBlueVariants[] = {
-	VKFFT_P2CB(float, false, 3, 3, 0, 0, 32),
-	VKFFT_P2CB(float, false, 4, 3, 0, 0, 32),
-	VKFFT_P2CB(float, false, 4, 4, 0, 0, 32),
-	VKFFT_P2CB(float, false, 4, 3, 2, 0, 16),
-	VKFFT_P2CB(float, false, 4, 3, 3, 0, 16),
-	VKFFT_P2CB1(float, false, 4, 4, 3, 0, 8, 5), // one-pass column Bluestein on 2048 padded points (147 KiB tile)
-	VKFFT_P2CB1(float, false, 4, 3, 3, 0, 8, 7), // merged matrix convolution along 1024 points: 8-column tiles, 512 threads (three coordinate systems in registers)
-	VKFFT_P2CB1(double, true, 3, 3, 3, 0, 8, 7), // ... 512 points in double precision
-	VKFFT_P2CB(double, true, 3, 3, 0, 0, 16),
-	VKFFT_P2CB(double, true, 3, 2, 2, 0, 16),
-	VKFFT_P2CB(double, true, 3, 3, 2, 0, 16),
-	VKFFT_P2CB(double, true, 3, 3, 3, 0, 8),
-	VKFFT_P2CB(double, true, 4, 3, 3, 0, 8),
-};
-constexpr int kNumPow2ColBlueVariants = (int)(sizeof(kPow2ColBlueVariants) / sizeof(kPow2ColBlueVariants[0]));
-
-inline int launch_pow2_col_blue(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
-	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
-	if (grid64 == 0) return 0;
-	if (grid64 > 0x7fffffffull || pp.variant < 0 || pp.variant >= kNumPow2ColBlueVariants) return 4039;
-	kPow2ColBlueVariants[pp.variant].v.launch(prm, dim3((uint32_t)grid64), stream);
-	return hipGetLastError() == hipSuccess ? 0 : 4039;
-}
-
-inline int launch_pow2_blue(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
-	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
-	if (grid64 == 0) return 0;
-	if (grid64 > 0x7fffffffull || pp.variant < 0 || pp.variant >= kNumPow2BlueVariants) return 4039;
-	kPow2BlueVariants[pp.variant].launch(prm, dim3((uint32_t)grid64), stream);
-	return hipGetLastError() == hipSuccess ? 0 : 4039;
-}
-
-inline int launch_pow2(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
-	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * (prm.colMerge ? 1u : prm.dim[1].count) * prm.dim[2].count;
-	if (grid64 == 0) return 0;
-	const bool col = pp.kernel == KERNEL_POW2_COL;
-	if (grid64 > 0x7fffffffull || pp.variant < 0 || pp.variant >= (col ? kNumPow2ColVariants : kNumPow2Variants)) return 4039;
-	(col ? kPow2ColVariants : kPow2Variants)[pp.variant].launch(prm, dim3((uint32_t)grid64), stream);
-	return hipGetLastError() == hipSuccess ? 0 : 4039;
 }
 
 } // namespace vkfft_mi355x

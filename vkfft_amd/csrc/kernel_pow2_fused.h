@@ -77,13 +77,16 @@ __device__ inline void fused_wait(uint32_t* ctr, uint32_t target) {
 }
 
 // workgroups of a fused kernel that fit one CU (LDS and wave slots), at most 4: fixes the register budget through __launch_bounds__
-template <typename T, typename SA, int TCA, typename SB, int TCB, int TWL, int CPT> constexpr int pow2_fused_wg_per_cu() {
+// LEAN: the register-lean stages of kernel_pow2_lean.h (real and imaginary parts through one real-valued plane: half the LDS per tile, 128 VGPRs)
+template <typename T, typename SA, int TCA, typename SB, int TCB, int TWL, int CPT, int LEAN = 0> constexpr int pow2_fused_wg_per_cu() {
 	constexpr int la = (1 << SA::LOGN) * (TCA + (CPT == 2 ? 2 : 1)), lb = (1 << SB::LOGN) * (TCB + (CPT == 2 ? 2 : 1));
-	constexpr int ldsBytes = ((la > lb ? la : lb) + (TWL ? SA::lutTotal() + SB::lutTotal() : 0)) * (int)sizeof(cx<T>) + 64;
+	constexpr int pa = (int)pow2_lean_plane_elems<SA, TCA>(), pb = (int)pow2_lean_plane_elems<SB, TCB>();
+	constexpr int ldsBytes = LEAN ? (pa > pb ? pa : pb) * (int)sizeof(T) + (TWL ? SA::lutTotal() + SB::lutTotal() : 0) * (int)sizeof(cx<T>) + 64
+	                              : ((la > lb ? la : lb) + (TWL ? SA::lutTotal() + SB::lutTotal() : 0)) * (int)sizeof(cx<T>) + 64;
 	constexpr int nt = ((1 << SA::LOGN) >> SA::LOGE) * TCA / CPT;
 	int w = 163840 / ldsBytes;
 	if (w > 2048 / nt) w = 2048 / nt;
-	return w > 4 ? 4 : w < 1 ? 1 : w;
+	return w > (LEAN ? 8 : 4) ? (LEAN ? 8 : 4) : w < 1 ? 1 : w;
 }
 
 // Publishing an A tile's completion (thread 0, at a point where every wave's vector-memory operations have drained: the ring stores
@@ -106,10 +109,11 @@ __device__ inline uint32_t fused_xcc_id() {
 // TWL: stage twiddles staged in LDS (1) or read through the buffer path from L2 (0: where the LDS copy would cost a workgroup per CU)
 // CPT: columns per thread.  2 (fp32 only): a thread keeps two adjacent columns, so that every global and ring access is 16 bytes per lane and
 // every LDS exchange access 16 bytes (the fp64 kernels, whose elements are 16 bytes, measured 10-15 % above the 8-byte fp32 ones)
-template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE, int TWL, int CPT>
-__global__ void __launch_bounds__(((1 << SA::LOGN) >> SA::LOGE) * TCA / CPT, (pow2_fused_wg_per_cu<T, SA, TCA, SB, TCB, TWL, CPT>() * (((1 << SA::LOGN) >> SA::LOGE) * TCA / CPT) + 255) / 256)
+template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE, int TWL, int CPT, int LEAN = 0>
+__global__ void __launch_bounds__(((1 << SA::LOGN) >> SA::LOGE) * TCA / CPT, (pow2_fused_wg_per_cu<T, SA, TCA, SB, TCB, TWL, CPT, LEAN>() * (((1 << SA::LOGN) >> SA::LOGE) * TCA / CPT) + 255) / 256)
 pow2_fused_kernel(const FusedParams p) {
 	static_assert(CPT == 1 || (CPT == 2 && sizeof(T) == 4), "two columns per thread: fp32 only");
+	static_assert(!LEAN || CPT == 2, "register-lean form: two columns per thread");
 	constexpr int LA = 1 << SA::LOGN, EA = 1 << SA::LOGE, TPFA = LA / EA, TCPA = TCA + (CPT == 2 ? 2 : 1);
 	constexpr int LB = 1 << SB::LOGN, EB = 1 << SB::LOGE, TPFB = LB / EB, TCPB = TCB + (CPT == 2 ? 2 : 1);
 	constexpr int NT = TPFA * TCA / CPT;
@@ -120,9 +124,12 @@ pow2_fused_kernel(const FusedParams p) {
 	constexpr int AUX_ST = 16;                   // ring stores: write-through (no XCD's L2 ever holds a ring line)
 	constexpr int AUX_HBM = (MODE & 2) ? 2 : 0;
 	constexpr int AUX_HBM_LD = AUX_HBM, AUX_HBM_ST = AUX_HBM;
-	constexpr int LDSN = LA * TCPA > LB * TCPB ? LA * TCPA : LB * TCPB;
+	constexpr int PLA = (int)pow2_lean_plane_elems<SA, TCA>(), PLB = (int)pow2_lean_plane_elems<SB, TCB>(), PLN = (PLA > PLB ? PLA : PLB) + ((PLA > PLB ? PLA : PLB) & 1);
+	constexpr int LDSN = LEAN ? PLN / 2 : (LA * TCPA > LB * TCPB ? LA * TCPA : LB * TCPB); // (in complex elements; the lean plane holds PLN real ones)
 	constexpr int LUTA = TWL ? SA::lutTotal() : 0, LUTB = TWL ? SB::lutTotal() : 0;
+	constexpr int TWG = 8, PFN = TWL ? 0 : 8; // lean stages: stage twiddles in flight at a time; twiddles read through L2 are requested ahead of the exchange
 	__shared__ cx<T> lds[LDSN + LUTA + LUTB];
+	T* const plane = (T*)lds;
 	__shared__ uint32_t sTicket[2], sOkA[2], sOkB[2];
 	const uint32_t tid = threadIdx.x;
 	// stage twiddles of both factors staged in LDS for the lifetime of the workgroup
@@ -233,12 +240,28 @@ pow2_fused_kernel(const FusedParams p) {
 #pragma unroll
 						for (int m = 0; m < CPT * EA; m++) v[m] = cswap(v[m]);
 					}
-					fused_stages<T, SA, TPFA, TCPA, TWL, CPT>(v, lds + c, twA, p.lutA, oz, tau);
+					if constexpr (LEAN) {
+						if constexpr (TWL) pow2_lean_stages<T, SA, 0, TPFA, TCA, TwLds<T>, TWG, CPT>(v, plane + c, TwLds<T>{twA}, tau);
+						else pow2_lean_stages<T, SA, 0, TPFA, TCA, TwGlobal<T>, TWG, CPT, PFN>(v, plane + c, TwGlobal<T>{make_gbuf((const char*)p.lutA + oz)}, tau);
+					} else fused_stages<T, SA, TPFA, TCPA, TWL, CPT>(v, lds + c, twA, p.lutA, oz, tau);
 					VKFFT_PROF(8);
 #pragma unroll
 					for (int cc = 0; cc < CPT; cc++) pow2_fs_twiddle<T, SA::LOGE, TPFA>(v + cc * EA, gtw, p.fsLoBits, tau, col0 + c + cc);
 					VKFFT_PROF(9);
 					if constexpr (SA::NS > 1) VKFFT_SYNC(); // the last exchange's reads are complete
+					if constexpr (LEAN) {
+						// the tile turned through the plane (real parts, then imaginary parts) into per-column contiguous order and stored from registers
+						cx<T> r[CPT * EA];
+						pow2_lean_transpose<T, LA, EA, TPFA, TCA, NT>(v, r, plane, tid, c, tau);
+						VKFFT_PROF(10);
+						const GBuf gs = make_gbuf(sbase + (uint64_t)col0 * LA * ES);
+#pragma unroll
+						for (int i = 0; i < CPT * EA / 2; i++) {
+							const uint32_t idx = tid + i * NT;
+							const uint32_t kp = idx % (LA / 2), cc = idx / (LA / 2);
+							gb_store2_x<T, AUX_ST>(gs, (cc * LA + 2u * kp) * ES, r[2 * i], r[2 * i + 1]);
+						}
+					} else {
 #pragma unroll
 					for (int m = 0; m < EA; m++) {
 						if constexpr (CPT == 1) lds[(tau + m * TPFA) * TCPA + c] = v[m];
@@ -246,9 +269,10 @@ pow2_fused_kernel(const FusedParams p) {
 					}
 					VKFFT_SYNC();
 					VKFFT_PROF(10);
+					}
 				}
 			}
-			if (live) {
+			if (live && !LEAN) {
 				const GBuf gs = make_gbuf(sbase + (uint64_t)col0 * LA * ES);
 				if constexpr (sizeof(T) == 4) {
 					// two consecutive k per lane: 16-byte write-through stores (8-byte sc1 stores cost 2.7x per byte)
@@ -287,7 +311,10 @@ pow2_fused_kernel(const FusedParams p) {
 				fused_publish(p.ctr, pending);
 			}
 			if (liveB) {
-				fused_stages<T, SB, TPFB, TCPB, TWL, CPT>(vB, lds + cBl, twB, p.lutB, oz, tauB);
+				if constexpr (LEAN) {
+					if constexpr (TWL) pow2_lean_stages<T, SB, 0, TPFB, TCB, TwLds<T>, TWG, CPT>(vB, plane + cBl, TwLds<T>{twB}, tauB);
+					else pow2_lean_stages<T, SB, 0, TPFB, TCB, TwGlobal<T>, TWG, CPT, PFN>(vB, plane + cBl, TwGlobal<T>{make_gbuf((const char*)p.lutB + oz)}, tauB);
+				} else fused_stages<T, SB, TPFB, TCPB, TWL, CPT>(vB, lds + cBl, twB, p.lutB, oz, tauB);
 				if (p.swapOut) {
 #pragma unroll
 					for (int m = 0; m < CPT * EB; m++) vB[m] = cswap(vB[m]);
@@ -328,14 +355,14 @@ pow2_fused_kernel(const FusedParams p) {
 }
 
 struct Pow2FusedVariant {
-	int log2n; bool dp; int mode; int la, lb; int bitsA[4], bitsB[4]; int tca, tcb, threads, wgPerCu; // la, lb: log2 of the two factors
+	int log2n; bool dp; int mode; int la, lb; int bitsA[4], bitsB[4]; int tca, tcb, threads, wgPerCu; // la, lb: log2 of the two factors; wgPerCu: workgroups per CU the kernel is launched with (resources, or a measured cap below them)
 	void (*launch)(const FusedParams&, dim3, hipStream_t);
 	const void* fn;
 };
 
-template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE, int TWL, int CPT> void pow2_fused_launch(const FusedParams& prm, dim3 grid, hipStream_t s) {
+template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE, int TWL, int CPT, int LEAN = 0> void pow2_fused_launch(const FusedParams& prm, dim3 grid, hipStream_t s) {
 	constexpr int threads = ((1 << SA::LOGN) >> SA::LOGE) * TCA / CPT;
-	hipLaunchKernelGGL((pow2_fused_kernel<T, SA, TCA, SB, TCB, MODE, TWL, CPT>), grid, dim3(threads), 0, s, prm);
+	hipLaunchKernelGGL((pow2_fused_kernel<T, SA, TCA, SB, TCB, MODE, TWL, CPT, LEAN>), grid, dim3(threads), 0, s, prm);
 }
 
 } // namespace vkfft_mi355x

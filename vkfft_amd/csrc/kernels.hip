@@ -2,7 +2,6 @@
 // glue, vkFFT_DispatchPlan.h:226-295 — but on ahead-of-time compiled gfx950 kernels).
 #include "engine.h"
 #include "kernel_generic.h"
-#include "kernel_pow2.h"
 #include "kernel_opfft.h"
 #include "kernel_mixed.h"
 #include "kernel_mixconv.h"
@@ -201,46 +200,6 @@ int launch_opfft(const PassPlan& pp, const PassParams& prm, hipStream_t stream) 
 	if (grid64 > 0x7fffffffull || pp.variant < 0 || idx >= cnt) return 4039;
 	tab[idx].launch(prm, dim3((uint32_t)grid64), stream);
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
-}
-
-static bool pow2_lookup(const Pow2Variant* tab, int ntab, const char* envPrefix, uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads) {
-	int want = 0;
-	char name[64];
-	snprintf(name, sizeof(name), "%s%u", envPrefix, log2n);
-	if (const char* e = getenv(name)) want = atoi(e);
-	int seen = 0, found = -1;
-	for (int i = 0; i < ntab; i++) {
-		if (tab[i].log2n != (int)log2n || tab[i].dp != dp) continue;
-		if (found < 0) found = i;
-		if (seen == want) { found = i; break; }
-		seen++;
-	}
-	if (found < 0) return false;
-	*variant = found;
-	for (int k = 0; k < 4; k++) bits[k] = tab[found].bits[k];
-	*fpw = tab[found].fpw; *threads = tab[found].threads;
-	return true;
-}
-bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads) {
-	return pow2_lookup(kPow2Variants, kNumPow2Variants, "VKFFT_MI355X_P2V", log2n, dp, variant, bits, fpw, threads);
-}
-bool pow2_col_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* tc, int* threads) {
-	return pow2_lookup(kPow2ColVariants, kNumPow2ColVariants, "VKFFT_MI355X_P2C", log2n, dp, variant, bits, tc, threads);
-}
-
-bool pow2_col_blue_lookup(uint32_t log2l, bool dp, int mode, int* variant, int bits[4], int* tc, int* threads) {
-	for (int i = 0; i < kNumPow2ColBlueVariants; i++) {
-		const Pow2ColBlueVariant& e = kPow2ColBlueVariants[i];
-		if (e.v.log2n != (int)log2l || e.v.dp != dp || e.mode != mode) continue;
-		*variant = i;
-		for (int k = 0; k < 4; k++) bits[k] = e.v.bits[k];
-		*tc = e.v.fpw; *threads = e.v.threads;
-		return true;
-	}
-	return false;
-}
-bool pow2_blue_lookup(uint32_t log2m, bool dp, int* variant, int bits[4], int* fpw, int* threads) {
-	return pow2_lookup(kPow2BlueVariants, kNumPow2BlueVariants, "VKFFT_MI355X_P2B", log2m, dp, variant, bits, fpw, threads);
 }
 
 static int launch_with_hostloop(const PassPlan& pp, PassParams prm, const StreamSet& ss, uint32_t& rr, size_t level) {

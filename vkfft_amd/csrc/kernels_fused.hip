@@ -4,15 +4,20 @@
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 #include <atomic>
 
 namespace vkfft_mi355x {
 
-#define VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, mode, twl, cpt) \
+constexpr int fused_min(int a, int b) { return a < b ? a : b; }
+// cap: workgroups per CU at most (measured: more of them than the ring's lag tolerates only add dependency stalls)
+#define VKFFT_FU0(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, mode, twl, cpt, lean) VKFFT_FUX(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, mode, twl, cpt, lean, 8)
+#define VKFFT_FUX(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, mode, twl, cpt, lean, cap) \
 	{ (a0) + (a1) + (a2) + (b0) + (b1) + (b2), dp, mode, (a0) + (a1) + (a2), (b0) + (b1) + (b2), {a0, a1, a2, 0}, {b0, b1, b2, 0}, tca, tcb, \
-	  ((1 << ((a0) + (a1) + (a2))) >> Pow2Sched<a0, a1, a2, 0>::LOGE) * (tca) / (cpt), pow2_fused_wg_per_cu<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, twl, cpt>(), \
-	  &pow2_fused_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt>, \
-	  (const void*)&pow2_fused_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt> }
+	  ((1 << ((a0) + (a1) + (a2))) >> Pow2Sched<a0, a1, a2, 0>::LOGE) * (tca) / (cpt), fused_min(cap, pow2_fused_wg_per_cu<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, twl, cpt, lean>()), \
+	  &pow2_fused_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt, lean>, \
+	  (const void*)&pow2_fused_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, cpt, lean> }
+#define VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, mode, twl, cpt) VKFFT_FU0(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, mode, twl, cpt, 0)
 // mode 2 = product (non-temporal hint on the streamed side); the development build (-DVKFFT_MI355X_DEV) adds mode 6 = the same with per-phase cycle sums
 #if defined(VKFFT_MI355X_DEV)
 #define VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, cpt) \
@@ -20,6 +25,13 @@ namespace vkfft_mi355x {
 #else
 #define VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, cpt) VKFFT_FU1(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, cpt)
 #endif
+// register-lean form (kernel_pow2_lean.h): two columns per thread, real / imaginary planes exchanged one after the other
+#if defined(VKFFT_MI355X_DEV)
+#define VKFFT_FULC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, cap) VKFFT_FUX(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, 2, 1, cap), VKFFT_FUX(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 6, twl, 2, 1, cap)
+#else
+#define VKFFT_FULC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, cap) VKFFT_FUX(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, 2, 1, cap)
+#endif
+#define VKFFT_FUL(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl) VKFFT_FULC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, 8)
 #define VKFFT_FUT(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, 1)
 #define VKFFT_FU(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 1)
 #define VKFFT_FU2(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 2) /* two columns per thread */
@@ -30,23 +42,32 @@ static const Pow2FusedVariant kPow2FusedVariants[] = {
 	// 2^15 = 128 x 256
 	VKFFT_FU2(float, false, 4, 3, 0, 32, 4, 4, 0, 16),
 	VKFFT_FU(float, false, 4, 3, 0, 32, 4, 4, 0, 16),
+	VKFFT_FUL(float, false, 4, 3, 0, 32, 4, 4, 0, 16, 1),
 	// 2^16 = 256 x 256
 	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 4, 0, 32),
 	VKFFT_FU(float, false, 4, 4, 0, 32, 4, 4, 0, 32),
+	VKFFT_FUL(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 1),
 	// 2^17 = 256 x 512
 	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
 	VKFFT_FU(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
-	// 2^18 = 512 x 512
+	VKFFT_FUL(float, false, 4, 4, 0, 32, 4, 3, 2, 16, 1),
+	// 2^18 = 512 x 512: the register-lean form at two workgroups per CU measured 4-6 % above the shape after it (3.24-3.26 against 3.07-3.10 TB/s)
+	VKFFT_FULC(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 2),
 	VKFFT_FU2(float, false, 4, 3, 2, 16, 4, 3, 2, 16),
 	VKFFT_FU(float, false, 5, 4, 0, 16, 5, 4, 0, 16),
 	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: one workgroup per CU (the 1024-point column tile needs 139 KiB of LDS); 8-column tiles
 	// (two workgroups per CU, 64-byte segments on the HBM side) measured 12 % slower, 2^20 as 512 x 2048 20 % slower
 	VKFFT_FU2(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
 	VKFFT_FU(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
+	VKFFT_FUL(float, false, 4, 3, 2, 32, 4, 3, 3, 16, 0), // (2^19: index 2) 69.6 KiB planes: two workgroups per CU
 	VKFFT_FU2(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
 	VKFFT_FU(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
+	VKFFT_FUL(float, false, 4, 3, 3, 16, 4, 3, 3, 16, 0), // (2^20: index 2)
 	// 2^21 = 1024 x 2048, 2^22 = 2048 x 2048: 2048-point column tiles are 8 columns wide (147 KiB of LDS; 64-byte segments on the HBM side)
 	// (2^21 as 1024 x 2048 — the wide 16-column tiles on the HBM read side — measured 10 % above 2048 x 1024)
+	// register-lean (round 4): 2048-point tiles 16 columns wide (128-byte segments), 1024 threads, 139 KiB planes: 2^21 +4.5 %, 2^22 +29 % over the 8-column shapes below
+	VKFFT_FUL(float, false, 4, 3, 3, 32, 4, 4, 3, 16, 0),
+	VKFFT_FUL(float, false, 4, 4, 3, 16, 4, 4, 3, 16, 0),
 	VKFFT_FUT(float, false, 5, 5, 0, 16, 5, 3, 3, 8, 0),
 	VKFFT_FUT(float, false, 5, 3, 3, 8, 5, 5, 0, 16, 0),
 	VKFFT_FUT(float, false, 5, 3, 3, 8, 5, 3, 3, 8, 0),
@@ -105,7 +126,7 @@ int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t st
 		if (cached) occ[dev][pp.variant].store(n, std::memory_order_relaxed);
 	}
 	const uint64_t tickets = (uint64_t)(prm.C + prm.D * prm.Q) << (prm.logG + prm.logTiles);
-	uint64_t grid = (uint64_t)pow2_num_cus() * (pp.fusedWgPerCu > 0 ? (uint32_t)pp.fusedWgPerCu : (uint32_t)n);
+	uint64_t grid = (uint64_t)pow2_num_cus() * (pp.fusedWgPerCu > 0 ? (uint32_t)pp.fusedWgPerCu : (uint32_t)std::min(n, v.wgPerCu));
 	if (grid > tickets) grid = tickets;
 	if (grid == 0) return 0;
 #if !defined(VKFFT_HOSTEMU)

@@ -12,7 +12,10 @@
 #define VKFFT_SYNC_RAW() __syncthreads()
 #define VKFFT_OPAQUE_ZERO(z) uint32_t z = 0
 #define VKFFT_SCHED_FENCE() do { } while (0)
+#define VKFFT_PIN(x) do { } while (0)
 #else
+// pins a value where it is computed: the optimiser may neither sink the instructions that produce it nor hoist later uses above this point
+#define VKFFT_PIN(x) asm volatile("" : "+v"(x))
 // hides a (wave-uniform) pointer's provenance from the optimiser: stops loop-invariant twiddle loads from being
 // hoisted out of the persistent tile loop and pinned in dozens of VGPRs
 #define VKFFT_OPAQUE_ZERO(z) uint32_t z = 0; asm volatile("" : "+s"(z))

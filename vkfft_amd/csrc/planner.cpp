@@ -1279,7 +1279,9 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 			singleCap = 2048;
 		}
 	}
-	if (j.N <= singleCap || (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N <= (dp ? 8192u : 16384u))) {
+	// 2^15 fp32 as ONE pass of the register-lean row kernel (measured 4.2 TB/s against 3.2 for the fused two-pass kernel); VKFFT_MI355X_ROW15=0: two passes
+	const bool row15 = !(getenv("VKFFT_MI355X_ROW15") && atoi(getenv("VKFFT_MI355X_ROW15")) == 0);
+	if (j.N <= singleCap || (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N <= (dp ? 8192u : (row15 ? 32768u : 16384u)))) {
 		b.L = j.N;
 		if (unit && !padded && !d.disableFastKernels && ((j.N & (j.N - 1)) != 0 || j.N == 2)) { // curated non-power-of-two lengths (and N = 2): hand-specialised mixed-radix kernel
 			int variant, rad5[5], fpw, thr;
