@@ -27,13 +27,13 @@ def test_native_library_is_loaded(product_lib):
 
 
 # ---- config 1 / 2: batched 1D C2C fp32 powers of two --------------------------------------------------
-@pytest.mark.parametrize("k", list(range(1, 15)))
+@pytest.mark.parametrize("k", list(range(1, 16)))
 def test_pow2_single_pass(run, oracle, k):
     N = 1 << k
     parity.check_c2c(run, oracle, (N,), max(1, min(97, (1 << 17) // N)), False)
 
 
-@pytest.mark.parametrize("k,passes", [(15, 2), (16, 2), (17, 2), (18, 2), (19, 2), (20, 2), (21, 2), (22, 2)])
+@pytest.mark.parametrize("k,passes", [(15, 1), (16, 2), (17, 2), (18, 2), (19, 2), (20, 2), (21, 2), (22, 2)])
 def test_pow2_multi_pass(run, oracle, k, passes):
     N = 1 << k
     up = parity.check_c2c(run, oracle, (N,), 3 if k < 20 else 2, False)
@@ -41,12 +41,52 @@ def test_pow2_multi_pass(run, oracle, k, passes):
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("k,variant", [(13, v) for v in range(6)] + [(14, v) for v in range(6)] + [(15, v) for v in range(4)])
+def test_register_lean_rows_every_variant_on_device(run, oracle, monkeypatch, k, variant):
+    """kernel_pow2_lean.h on the device: every registered shape of 2^13 / 2^14 / one-pass 2^15 (the defaults are index 0), a chip-filling batch against
+    the small batch bit for bit, and the oracle"""
+    monkeypatch.setenv(f"VKFFT_MI355X_P2V{k}", str(variant))
+    N = 1 << k
+    x = parity.seeded_complex(N * 3, False, N + variant)
+    y, z, up = run.transform(x, (N,), 3, both=True)
+    assert up == [1]
+    truth = oracle.truth_c2c(x, (N,), 3)
+    assert rel_l2(y, truth) < 1e-6 and rel_l2(z, x.astype(np.complex128) * N) < 2e-6
+    from helpers import assert_elementwise
+    assert_elementwise(y, truth, "c2c", False, f"2^{k} variant {variant}")
+    reps = (1 << 24) // (3 * N)
+    big, _ = run.transform(np.tile(x, reps), (N,), 3 * reps)
+    assert np.array_equal(np.tile(y, reps).view(np.uint8), big.view(np.uint8))
+
+
+@pytest.mark.parametrize("k,variant", [(15, 2), (16, 2), (17, 2), (18, 0), (18, 1), (19, 2), (20, 2), (21, 0), (21, 2), (22, 0), (22, 1)])
+def test_fused_fourstep_register_lean_shapes_on_device(run, oracle, monkeypatch, k, variant):
+    """register-lean fused Four-Step shapes (shipping: 2^18, 2^21, 2^22 at index 0) and the shapes they replaced, full 1 GiB batch: spot transforms and
+    the round trip of the whole buffer element by element"""
+    import torch
+    monkeypatch.setenv(f"VKFFT_MI355X_FUV{k}", str(variant))
+    monkeypatch.setenv("VKFFT_MI355X_ROW15", "0")
+    N = 1 << k; B = (1 << 27) // N
+    g = torch.Generator(device="cuda"); g.manual_seed(k + variant)
+    x = torch.empty(2 * N * B, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    buf = x.clone()
+    app = api.App([N], B, buffer_ptr=buf.data_ptr(), normalize=True, lib=run.lib)
+    app.forward(); torch.cuda.synchronize()
+    X = torch.view_as_complex(buf.view(-1, 2)).view(B, N); xc = torch.view_as_complex(x.view(-1, 2)).view(B, N)
+    for b in (0, B // 2, B - 1):
+        ref = torch.fft.fft(xc[b].to(torch.complex128))
+        assert (torch.abs(X[b].to(torch.complex128) - ref).max() / (torch.sqrt(torch.mean(torch.abs(ref) ** 2)) * 2.0 ** -23)).item() <= 64
+    app.inverse(); torch.cuda.synchronize(); app.delete()
+    assert (torch.abs(buf - x).max() / (0.577 * 2.0 ** -23)).item() <= 128
+
+
 @pytest.mark.parametrize("k,batch", [(15, 37), (16, 65), (17, 19), (18, 9), (19, 5), (20, 3), (21, 3), (22, 2)])
 def test_fused_fourstep_equals_separate_passes(run, oracle, monkeypatch, k, batch):
     """2^15..2^20 run as ONE persistent launch (kernel_pow2_fused.h) whose intermediate lives in an Infinity-Cache resident ring; the same
     plan with the fusion switched off runs the two Four-Step passes as separate launches through a full-size temp buffer.  Odd batches:
     partial last chunk, queues of unequal length."""
     N = 1 << k
+    monkeypatch.setenv("VKFFT_MI355X_ROW15", "0")  # (2^15 is ONE pass of the register-lean row kernel by default since round 4; the two-pass plans are compared here)
     x = parity.seeded_complex(N * batch, False, 77 + k)
     yf, zf, up = run.transform(x, (N,), batch, both=True)
     monkeypatch.setenv("VKFFT_MI355X_FUSED", "0")
@@ -78,6 +118,7 @@ def test_fused_fourstep_under_dependency_pressure(product_lib, monkeypatch, k, e
     """the smallest legal ring and lag: almost every tile finds its dependency unsatisfied and takes the polling path, ring slots are
     reused immediately, the grid is oversubscribed — results must not change and the launch must terminate (1 GiB, 12 launches)"""
     import torch
+    monkeypatch.setenv("VKFFT_MI355X_ROW15", "0")
     for a, b in env.items():
         monkeypatch.setenv("VKFFT_MI355X_FUSED_" + a, str(b))
     N = 1 << k; B = (1 << 27) // N
@@ -107,6 +148,7 @@ def test_fused_fourstep_unbalanced_queues_many_launches(product_lib, monkeypatch
     theirs (regression: before every workgroup barrier also waited for the wave's own LDS writes, waves occasionally read the previous
     ticket after a queue switch — 2-29 wrong round trips in 300 launch pairs with this configuration, a few ppm of relative error each)"""
     import torch
+    monkeypatch.setenv("VKFFT_MI355X_ROW15", "0")
     monkeypatch.setenv("VKFFT_MI355X_FUSED_LAG", "1"); monkeypatch.setenv("VKFFT_MI355X_FUSED_RING", "4")
     monkeypatch.setenv("VKFFT_MI355X_FUSED_QUEUES", str(queues))
     N = 1 << k; B = (1 << 27) // N
