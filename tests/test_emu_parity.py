@@ -366,10 +366,12 @@ def test_register_lean_row_strides_padding_and_scale(run, oracle):
     assert convpad.zeropad_case(run, (N,), {0: (N // 2, N)}, batch=2) < 3e-6
 
 
-@pytest.mark.parametrize("k,variant,batch", [(15, 2, 5), (16, 2, 3), (17, 2, 3), (18, 0, 3), (19, 2, 2), (20, 2, 2), (21, 0, 1), (22, 0, 1)])
-def test_fused_fourstep_register_lean_shapes(run, oracle, monkeypatch, k, variant, batch):
-    """the register-lean form of the fused Four-Step kernel (two columns per thread, plane-split exchanges, tile turned through the plane for the
-    ring stores): the shipping shapes of 2^18, 2^21 and 2^22 (2048-point tiles 16 columns wide) and the measured-but-not-adopted ones of the other sizes"""
+@pytest.mark.parametrize("k,variant,batch", [(15, 0, 5), (15, 1, 5), (15, 2, 5), (16, 1, 3), (16, 2, 3), (17, 1, 3), (17, 2, 3), (18, 1, 3), (18, 2, 3), (19, 1, 2), (19, 2, 2),
+                                             (20, 1, 2), (20, 2, 2), (21, 0, 1), (21, 2, 1), (22, 0, 1), (22, 1, 1)])
+def test_fused_fourstep_every_registered_shape(run, oracle, monkeypatch, k, variant, batch):
+    """every shape in the fused Four-Step registry besides the defaults the other tests run: index 0 = what ships (2^16 ... 2^20: the software-pipelined
+    form, kernel_pow2_fused_pipe.h; 2^21 / 2^22: the register-lean form with 2048-point tiles 16 columns wide), 1 = the round-2/3 shape, 2 = the
+    register-lean plane-split form (2^21: the second round-3 shape)"""
     monkeypatch.setenv(f"VKFFT_MI355X_FUV{k}", str(variant))
     monkeypatch.setenv("VKFFT_MI355X_ROW15", "0")
     if k <= 18:

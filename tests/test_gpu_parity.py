@@ -59,10 +59,12 @@ def test_register_lean_rows_every_variant_on_device(run, oracle, monkeypatch, k,
     assert np.array_equal(np.tile(y, reps).view(np.uint8), big.view(np.uint8))
 
 
-@pytest.mark.parametrize("k,variant", [(15, 2), (16, 2), (17, 2), (18, 0), (18, 1), (19, 2), (20, 2), (21, 0), (21, 2), (22, 0), (22, 1)])
-def test_fused_fourstep_register_lean_shapes_on_device(run, oracle, monkeypatch, k, variant):
-    """register-lean fused Four-Step shapes (shipping: 2^18, 2^21, 2^22 at index 0) and the shapes they replaced, full 1 GiB batch: spot transforms and
-    the round trip of the whole buffer element by element"""
+@pytest.mark.parametrize("k,variant", [(15, 0), (15, 1), (15, 2), (16, 0), (16, 1), (16, 2), (17, 0), (17, 1), (17, 2), (18, 0), (18, 1), (18, 2), (19, 0), (19, 1), (19, 2),
+                                       (20, 0), (20, 1), (20, 2), (21, 0), (21, 1), (21, 2), (22, 0), (22, 1)])
+def test_fused_fourstep_every_registered_shape_on_device(run, oracle, monkeypatch, k, variant):
+    """every shape of the fused Four-Step registry (index 0 ships: software-pipelined form for 2^16 ... 2^20, register-lean 16-column 2048-point tiles for
+    2^21 / 2^22; the others are the shapes they were measured against), full 1 GiB batch: spot transforms and the round trip of the whole buffer
+    element by element"""
     import torch
     monkeypatch.setenv(f"VKFFT_MI355X_FUV{k}", str(variant))
     monkeypatch.setenv("VKFFT_MI355X_ROW15", "0")

@@ -8,14 +8,11 @@ from vkfft_amd import api
 
 TOTAL = 27
 CONFIGS = {
-    13: [{"P2V13": i} for i in range(6)],
-    14: [{"P2V14": i} for i in range(6)],
-    15: [{"P2V15": i} for i in range(4)] + [{"ROW15": 0}],
-    18: [{}, {"FUV18": 2, "FUSED_WGS": 2}],
-    19: [{}, {"FUV19": 2}, {"FUV19": 2, "FUSED_WGS": 1}],
-    20: [{}, {"FUV20": 2}, {"FUV20": 2, "FUSED_WGS": 1}],
-    21: [{}, {"FUV21": 1}],
-    22: [{}, {"FUV22": 1}],
+    16: [{}, {"FUV16": 3}, {"FUV16": 4}, {"FUV16": 3, "FUSED_MARGIN": 400}],
+    17: [{}, {"FUV17": 3}, {"FUV17": 4}, {"FUV17": 3, "FUSED_MARGIN": 400}],
+    18: [{}, {"FUV18": 3}, {"FUV18": 4}, {"FUV18": 3, "FUSED_MARGIN": 400}],
+    19: [{}, {"FUV19": 3}, {"FUV19": 4}, {"FUV19": 5}, {"FUV19": 3, "FUSED_MARGIN": 300}, {"FUV19": 3, "FUSED_MARGIN": 400}],
+    20: [{}, {"FUV20": 3}, {"FUV20": 4}, {"FUV20": 5}, {"FUV20": 3, "FUSED_MARGIN": 300}, {"FUV20": 3, "FUSED_MARGIN": 400}],
 }
 
 
@@ -51,7 +48,34 @@ def run(k, env, iters=6):
                 fwd_max_ulp=round(spot, 1), roundtrip_max_ulp=round(rt, 1))
 
 
+def stress(k, env, pairs=100):
+    """many launch pairs under unbalanced queues: every pair must return the buffer (the race class of DESIGN 4.10)"""
+    for key in list(os.environ):
+        if key.startswith("VKFFT_MI355X_"):
+            del os.environ[key]
+    os.environ.update({"VKFFT_MI355X_" + a: str(b) for a, b in env.items()})
+    N = 1 << k; B = (1 << TOTAL) // N
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    x = torch.empty(2 << TOTAL, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    buf = x.clone()
+    app = api.App([N], B, buffer_ptr=buf.data_ptr(), normalize=True)
+    nx = torch.linalg.norm(x); worst = 0.0; bad = 0
+    for _ in range(pairs):
+        buf.copy_(x)
+        app.forward(); app.inverse()
+        e = float(torch.linalg.norm(buf - x) / nx)
+        worst = max(worst, e); bad += e > 2e-6
+    app.delete()
+    return dict(stress=k, cfg=env, pairs=pairs, worst_rel_l2=float(f"{worst:.3e}"), bad_pairs=int(bad))
+
+
 if __name__ == "__main__":
+    if sys.argv[1:2] == ["stress"]:
+        for k, q in ((16, 3), (18, 5), (20, 6), (19, 3), (17, 7), (15, 3)):
+            print(json.dumps(stress(k, {f"FUV{k}": 3, "ROW15": 0, "FUSED_LAG": 1, "FUSED_RING": 4, "FUSED_QUEUES": q})), flush=True)
+        for k in (16, 20):
+            print(json.dumps(stress(k, {f"FUV{k}": 3, "ROW15": 0})), flush=True)
+        sys.exit(0)
     ks = [int(a) for a in sys.argv[1:]] or sorted(CONFIGS)
     for k in ks:
         for env in CONFIGS[k]:

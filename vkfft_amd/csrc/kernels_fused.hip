@@ -1,6 +1,7 @@
 // Instantiations and registry of the fused Four-Step kernels (kernel_pow2_fused.h): own translation unit (build time).
 #include "engine.h"
 #include "kernel_pow2_fused.h"
+#include "kernel_pow2_fused_pipe.h"
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
@@ -32,39 +33,46 @@ constexpr int fused_min(int a, int b) { return a < b ? a : b; }
 #define VKFFT_FULC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, cap) VKFFT_FUX(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 2, twl, 2, 1, cap)
 #endif
 #define VKFFT_FUL(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl) VKFFT_FULC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, 8)
+// software-pipelined form (kernel_pow2_fused_pipe.h): register-lean stages, the other tile's memory traffic in flight while one tile computes
+#define VKFFT_FUP(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, wgc) \
+	{ (a0) + (a1) + (a2) + (b0) + (b1) + (b2), dp, 2, (a0) + (a1) + (a2), (b0) + (b1) + (b2), {a0, a1, a2, 0}, {b0, b1, b2, 0}, tca, tcb, \
+	  ((1 << ((a0) + (a1) + (a2))) >> Pow2Sched<a0, a1, a2, 0>::LOGE) * (tca) / 2, pow2_fused_pipe_wg_per_cu<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, twl, wgc>(), \
+	  &pow2_fused_pipe_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, 2, twl, wgc>, \
+	  (const void*)&pow2_fused_pipe_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, 2, twl, wgc> }
 #define VKFFT_FUT(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, 1)
 #define VKFFT_FU(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 1)
 #define VKFFT_FU2(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 2) /* two columns per thread */
 
 // first entry of each (log2 N, dp, mode) is the default; VKFFT_MI355X_FUV<log2n>=k selects the k-th shape (tuning)
 static const Pow2FusedVariant kPow2FusedVariants[] = {
-	// fp32, two adjacent columns per thread (16-byte accesses): measured 3-18 % above the one-column shapes that follow them
-	// 2^15 = 128 x 256
+	// fp32.  First entry of a size = what ships; the ones after it are the shapes it was measured against (VKFFT_MI355X_FUV<k> selects them).
+	// Round 4: the software-pipelined form (kernel_pow2_fused_pipe.h) for 2^16 ... 2^20: +4 % (2^18) ... +15 % (2^17) over the round-2/3 shapes that
+	// follow it (two adjacent columns per thread; one column per thread; register-lean plane-split form without the pipelining).
+	// 2^15 = 128 x 256 (only with VKFFT_MI355X_ROW15=0: 2^15 ships as ONE pass of the register-lean row kernel, 4.2 against 3.2-3.5 TB/s)
+	VKFFT_FUP(float, false, 4, 3, 0, 32, 4, 4, 0, 16, 1, 4),
 	VKFFT_FU2(float, false, 4, 3, 0, 32, 4, 4, 0, 16),
-	VKFFT_FU(float, false, 4, 3, 0, 32, 4, 4, 0, 16),
 	VKFFT_FUL(float, false, 4, 3, 0, 32, 4, 4, 0, 16, 1),
 	// 2^16 = 256 x 256
+	VKFFT_FUP(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 1, 2),
 	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 4, 0, 32),
-	VKFFT_FU(float, false, 4, 4, 0, 32, 4, 4, 0, 32),
 	VKFFT_FUL(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 1),
 	// 2^17 = 256 x 512
+	VKFFT_FUP(float, false, 4, 4, 0, 32, 4, 3, 2, 16, 1, 2),
 	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
-	VKFFT_FU(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
 	VKFFT_FUL(float, false, 4, 4, 0, 32, 4, 3, 2, 16, 1),
-	// 2^18 = 512 x 512: the register-lean form at two workgroups per CU measured 4-6 % above the shape after it (3.24-3.26 against 3.07-3.10 TB/s)
-	VKFFT_FULC(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 2),
+	// 2^18 = 512 x 512
+	VKFFT_FUP(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 2),
 	VKFFT_FU2(float, false, 4, 3, 2, 16, 4, 3, 2, 16),
-	VKFFT_FU(float, false, 5, 4, 0, 16, 5, 4, 0, 16),
-	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: one workgroup per CU (the 1024-point column tile needs 139 KiB of LDS); 8-column tiles
-	// (two workgroups per CU, 64-byte segments on the HBM side) measured 12 % slower, 2^20 as 512 x 2048 20 % slower
+	VKFFT_FULC(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 2),
+	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: 128 KiB tiles, one workgroup per CU (512 threads x 256 registers = the whole register file: one tile
+	// computing + one tile in flight); 8-column tiles (two workgroups per CU, 64-byte segments on the HBM side) measured 12 % slower, 2^20 as
+	// 512 x 2048 20 % slower, the plane-split form at two workgroups per CU without the pipelining 7-16 % slower (it is VALU/LDS-bound, r04 profile)
+	VKFFT_FUP(float, false, 4, 3, 2, 32, 4, 3, 3, 16, 1, 1),
 	VKFFT_FU2(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
-	VKFFT_FU(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
-	VKFFT_FUL(float, false, 4, 3, 2, 32, 4, 3, 3, 16, 0), // (2^19: index 2) 69.6 KiB planes: two workgroups per CU
+	VKFFT_FUL(float, false, 4, 3, 2, 32, 4, 3, 3, 16, 0),
+	VKFFT_FUP(float, false, 4, 3, 3, 16, 4, 3, 3, 16, 1, 1),
 	VKFFT_FU2(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
-	VKFFT_FU(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
-	VKFFT_FUL(float, false, 4, 3, 3, 16, 4, 3, 3, 16, 0), // (2^20: index 2)
-	// 2^21 = 1024 x 2048, 2^22 = 2048 x 2048: 2048-point column tiles are 8 columns wide (147 KiB of LDS; 64-byte segments on the HBM side)
-	// (2^21 as 1024 x 2048 — the wide 16-column tiles on the HBM read side — measured 10 % above 2048 x 1024)
+	VKFFT_FUL(float, false, 4, 3, 3, 16, 4, 3, 3, 16, 0),
 	// register-lean (round 4): 2048-point tiles 16 columns wide (128-byte segments), 1024 threads, 139 KiB planes: 2^21 +4.5 %, 2^22 +29 % over the 8-column shapes below
 	VKFFT_FUL(float, false, 4, 3, 3, 32, 4, 4, 3, 16, 0),
 	VKFFT_FUL(float, false, 4, 4, 3, 16, 4, 4, 3, 16, 0),

@@ -784,7 +784,8 @@ static bool emit_fused(const TransformDesc& d, const AxisJob& j, Arena& ar, Dire
 	const uint64_t wgs = 256ull * (uint64_t)(d.fusedWgPerCu ? d.fusedWgPerCu : wgPerCu);
 	// measured (tools/tune_fused.py): completions are published up to a ticket late and the ticket rate rises with the speed of the
 	// kernel, so the window is taken generously: 3 windows where two or more workgroups share a CU, 2 with one workgroup per CU
-	uint64_t marginPct = d.fusedMarginPct ? d.fusedMarginPct : (wgPerCu >= 2 ? 300 : 200);
+	// (round 4, pipelined form of 2^19 / 2^20: one workgroup per CU, but the A tile of the NEXT ticket is requested early: 3 windows measured +2.7 % over 2)
+	uint64_t marginPct = d.fusedMarginPct ? d.fusedMarginPct : ((wgPerCu >= 2 || (!dp && j.N <= (1ull << 20))) ? 300 : 200);
 	uint64_t Q = 1, X = 1, D = 1, NS = 1, Cq = C;
 	auto shape = [&](uint64_t q, uint64_t pct) {
 		Q = q; Cq = (C + Q - 1) / Q;
