@@ -36,6 +36,24 @@ def _worker(rank, world, port, emu_path, case, ret):
                 ref = np.fft.fft(full.astype(np.complex128).reshape(B, N), axis=1)
                 ret["err"] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
             plan.delete()
+        elif case == "uneven":
+            nx, ny, nz = 16, 9, 11  # neither ny nor nz divisible by 2 or 3: UnevenSlabFFT3D
+            rng = np.random.default_rng(3)
+            vol = (rng.uniform(-1, 1, nx * ny * nz) + 1j * rng.uniform(-1, 1, nx * ny * nz)).astype(np.complex64).reshape(nz, ny, nx)
+            zlo, zhi = shard_range(nz, rank, world); ylo, yhi = shard_range(ny, rank, world)
+            plan = SlabFFT3D(nx, ny, nz, lib=lib)
+            assert type(plan).__name__ == "UnevenSlabFFT3D"
+            y = plan.forward(torch.from_numpy(vol[zlo:zhi].copy()))
+            ref = np.fft.fftn(vol.astype(np.complex128))[:, ylo:yhi, :]
+            e_f = float(np.linalg.norm(y.numpy() - ref) / np.linalg.norm(ref))
+            back = plan.inverse(y.clone())
+            want = vol[zlo:zhi].astype(np.complex128) * (nx * ny * nz)
+            e_b = float(np.linalg.norm(back.numpy() - want) / np.linalg.norm(want))
+            out = [None] * world
+            dist.all_gather_object(out, (True, e_f, e_b))
+            if rank == 0:
+                ret["exact"] = True; ret["e_f"] = max(o[1] for o in out); ret["e_b"] = max(o[2] for o in out)
+            plan.delete()
         else:
             case_groups = 3 if case == "slab3" else None
             nx, ny, nz = 16, 8, 12
@@ -71,10 +89,10 @@ def _worker(rank, world, port, emu_path, case, ret):
         dist.destroy_process_group()
 
 
-def _run(case, emu_lib_path):
+def _run(case, emu_lib_path, world=2):
     mgr = mp.Manager(); ret = mgr.dict()
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, emu_lib_path, case, ret), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + 7 * world
+    mp.spawn(_worker, args=(world, port, emu_lib_path, case, ret), nprocs=world, join=True)
     return dict(ret)
 
 
@@ -94,6 +112,13 @@ def test_slab_3d_all_to_all_two_ranks(emu_path, case):
     r = _run(case, emu_path)
     assert r["exact"], "slab exchange is not a bit-exact permutation"
     assert r["e_f"] < 1e-6 and r["e_b"] < 2e-6
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_3d_uneven_slabs(emu_path, world):
+    """nz = 11 planes and ny = 9 rows over 2 and 3 ranks: slabs of shard_range sizes, messages of rank-dependent size, forward and inverse against numpy"""
+    r = _run("uneven", emu_path, world)
+    assert r["e_f"] < 1e-6 and r["e_b"] < 2e-6, r
 
 
 def test_shard_range_partitions_exactly():

@@ -385,6 +385,31 @@ def test_fused_fourstep_every_registered_shape(run, oracle, monkeypatch, k, vari
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
 
 
+@pytest.mark.parametrize("N", [2 * 37, 3 * 41, 8 * 37, 7 * 127, 30 * 89, 32 * 101, 5 * 53, 4 * 61, 16 * 257, 9 * 113, 25 * 73, 21 * 43, 2 * 1297, 12 * 337, 64 * 37, 6 * 521])
+def test_rader_stage_of_a_composite_length(run, oracle, monkeypatch, N):
+    """kernel_mixrad.h: rows of M * P points, the Rader convolution of the prime P as a stage (cofactors below, equal to and above the thread groups of
+    the prime's instance; 64 * 37 has no such plan — cofactor above 32 — and must still be right through Bluestein); against the truth, against the
+    Bluestein plan of the same length, a batch that leaves the last workgroup partly filled, and the inverse"""
+    batch = 7
+    x = parity.seeded_complex(N * batch, False, N)
+    y, z, up = run.transform(x, (N,), batch, both=True)
+    assert up == [1]
+    truth = oracle.truth_c2c(x, (N,), batch)
+    assert rel_l2(y, truth) < 3e-6, rel_l2(y, truth)
+    assert rel_l2(z, x.astype(np.complex128) * N) < 6e-6
+    monkeypatch.setenv("VKFFT_MI355X_MIXRAD", "0")
+    yb, _ = run.transform(x, (N,), batch)
+    assert rel_l2(y, yb) < 3e-6
+
+
+def test_rader_stage_plan_is_taken(emu_lib):
+    """the planner sends M * P rows to the Rader-stage kernel (one launch of the mixconv family with the composite parameter) and not through Bluestein"""
+    buf = np.zeros(2670 * 4, np.complex64)
+    a = api.App([2670], 4, buffer_ptr=buf.ctypes.data, lib=emu_lib)
+    n, kern = a.launch_info(); a.delete()
+    assert n == 1 and "mixconv" in kern, (n, kern)
+
+
 @pytest.mark.parametrize("k,batch", [(14, 5), (15, 3), (16, 3), (17, 2), (18, 2), (19, 2), (20, 1)])
 def test_fused_fourstep_fp64(run, oracle, monkeypatch, k, batch):
     """fp64 members of the fused Four-Step family (16-byte elements, 16-column tiles), several chunks"""

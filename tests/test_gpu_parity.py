@@ -41,6 +41,24 @@ def test_pow2_multi_pass(run, oracle, k, passes):
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("N", [2 * 37, 3 * 41, 8 * 37, 7 * 127, 30 * 89, 32 * 101, 5 * 53, 4 * 61, 16 * 257, 9 * 113, 25 * 73, 21 * 43, 2 * 1297, 12 * 337, 6 * 521, 10 * 401, 28 * 97, 18 * 181])
+def test_rader_stage_of_a_composite_length_on_device(run, oracle, monkeypatch, N):
+    """kernel_mixrad.h on the device: rows of M * P points with the prime's Rader convolution as a stage — the truth, the Bluestein plan of the same
+    length, a chip-filling batch against the small one bit for bit"""
+    batch = 7
+    x = parity.seeded_complex(N * batch, False, N)
+    y, z, up = run.transform(x, (N,), batch, both=True)
+    assert up == [1]
+    truth = oracle.truth_c2c(x, (N,), batch)
+    assert rel_l2(y, truth) < 3e-6 and rel_l2(z, x.astype(np.complex128) * N) < 6e-6
+    reps = (1 << 23) // (batch * N)
+    big, _ = run.transform(np.tile(x, reps), (N,), batch * reps)
+    assert np.array_equal(np.tile(y, reps).view(np.uint8), big.view(np.uint8))
+    monkeypatch.setenv("VKFFT_MI355X_MIXRAD", "0")
+    yb, _ = run.transform(x, (N,), batch)
+    assert rel_l2(y, yb) < 3e-6
+
+
 @pytest.mark.parametrize("k,variant", [(13, v) for v in range(6)] + [(14, v) for v in range(6)] + [(15, v) for v in range(4)])
 def test_register_lean_rows_every_variant_on_device(run, oracle, monkeypatch, k, variant):
     """kernel_pow2_lean.h on the device: every registered shape of 2^13 / 2^14 / one-pass 2^15 (the defaults are index 0), a chip-filling batch against

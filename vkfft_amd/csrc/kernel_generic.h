@@ -57,6 +57,44 @@ template <typename T> __device__ inline cx<T> twiddle4(const PassParams& p, uint
 	return cmul(tab[lo], tab[(1u << p.fsLoBits) + hi]);
 }
 
+// Run f(std::integral_constant<uint32_t, OP>) with the pass's run-time pre / post operation as a COMPILE-TIME constant: inside f the switch of
+// pre_gather / post_store folds to the one case, loops over a thread's elements unroll and their loads are requested back to back.  (Called per
+// element with a run-time op, the switch is a branch tree in every iteration of a loop the compiler cannot unroll: a thread then waits for each
+// of its dozen loads in turn — measured on R2C / DCT rows between the instance transforms of kernel_mixed.h: 2x the time of the complex transform.)
+template <uint32_t OP> struct OpTag { static constexpr uint32_t value = OP; };
+template <typename F> __device__ inline void dispatch_pre_op(uint32_t op, const F& f) {
+	switch (op) {
+	case OP_C2R_EVEN_PRE: f(OpTag<OP_C2R_EVEN_PRE>{}); break;
+	case OP_R2C_FULL: f(OpTag<OP_R2C_FULL>{}); break;
+	case OP_C2R_FULL: f(OpTag<OP_C2R_FULL>{}); break;
+	case OP_DCT2_PRE: f(OpTag<OP_DCT2_PRE>{}); break;
+	case OP_DCT3_PRE: f(OpTag<OP_DCT3_PRE>{}); break;
+	case OP_DCT2H_PRE: f(OpTag<OP_DCT2H_PRE>{}); break;
+	case OP_DCT3H_PRE: f(OpTag<OP_DCT3H_PRE>{}); break;
+	case OP_DCT4_PRE: f(OpTag<OP_DCT4_PRE>{}); break;
+	case OP_DCT1H_PRE: f(OpTag<OP_DCT1H_PRE>{}); break;
+	case OP_NONE: f(OpTag<OP_NONE>{}); break;
+	default: f(op); break; // (the DST members, DCT-I / DST-I in their full-length forms: the run-time switch)
+	}
+}
+template <typename F> __device__ inline void dispatch_post_op(uint32_t op, const F& f) {
+	switch (op) {
+	case OP_R2C_EVEN_POST: f(OpTag<OP_R2C_EVEN_POST>{}); break;
+	case OP_R2C_FULL: f(OpTag<OP_R2C_FULL>{}); break;
+	case OP_C2R_FULL: f(OpTag<OP_C2R_FULL>{}); break;
+	case OP_DCT2_POST: f(OpTag<OP_DCT2_POST>{}); break;
+	case OP_DCT3_POST: f(OpTag<OP_DCT3_POST>{}); break;
+	case OP_DCT2H_POST: f(OpTag<OP_DCT2H_POST>{}); break;
+	case OP_DCT3H_POST: f(OpTag<OP_DCT3H_POST>{}); break;
+	case OP_DCT4_POST: f(OpTag<OP_DCT4_POST>{}); break;
+	case OP_DCT1H_POST: f(OpTag<OP_DCT1H_POST>{}); break;
+	case OP_NONE: f(OpTag<OP_NONE>{}); break;
+	default: f(op); break;
+	}
+}
+__device__ inline constexpr uint32_t op_value(uint32_t op) { return op; }
+template <uint32_t OP> __device__ inline constexpr uint32_t op_value(OpTag<OP>) { return OP; }
+
 // value that goes to LDS position `pos` of sub-FFT f (before the optional inverse swap)
 template <typename T, typename IO>
 __device__ inline cx<T> pre_gather(const PassParams& p, const IO& io, uint32_t pos, uint32_t natBase, const uint32_t op) {
@@ -485,6 +523,47 @@ __device__ inline cx<T>* run_stage_rader_fft(const PassParams& p, const StageDes
 	}
 	VKFFT_SYNC();
 	return oth;
+}
+
+// ---- rows between the pre- and the post-map of a real transform, shared by the instance kernels (kernel_mixed.h / kernel_mixconv.h, OPS = 1) -------
+// The operation is a compile-time constant INSIDE the loop (dispatch_pre_op / dispatch_post_op hoist the switch out of it): with a run-time operation
+// every element pays a branch tree of five or six taken branches, which on this machine cost more than the arithmetic of the transform (measured:
+// R2C / DCT rows between the instance transforms took 2x the time of the complex transform of the same length).  The loops stay rolled: unrolled,
+// they are 4-9x the code of the transform they surround, once per kernel instance.
+// divN divides by the row length, rows of the tile at lds + fi * SP, natural order.
+template <typename T, typename OPC>
+__device__ inline void ops_rows_in(const PassParams& p, OPC opc, const FastDiv divN, cx<T>* lds, uint32_t SP, uint32_t TOT, uint32_t nvalid, int64_t inBase, uint32_t nat0) {
+	const uint32_t tid = threadIdx.x, NT = blockDim.x;
+	const bool swI = p.swapIn != 0;
+#pragma unroll 1
+	for (uint32_t idx = tid; idx < TOT; idx += NT) {
+		uint32_t fi, pos;
+		divN.divmod(idx, fi, pos);
+		cx<T> v = {(T)0, (T)0};
+		if (fi < nvalid) {
+			Io64<T> io{p.in, p.out, inBase + (int64_t)fi * p.dim[0].inStride, 0, p.inStrideJ, p.outStrideJ};
+			io.set_pad(p);
+			v = pre_gather<T>(p, io, pos, nat0 + fi * p.opStride0, op_value(opc));
+		}
+		lds[fi * SP + pos] = swI ? cswap(v) : v;
+	}
+}
+// rows of the tile -> post-map -> global memory; fetch(fi, a) delivers element a of row fi (un-swapped); rows at lds + fi * SP unless `dc` (Rader: element 0 of a row lives in dc[fi])
+template <typename T, typename OPC>
+__device__ inline void ops_rows_out(const PassParams& p, OPC opc, const cx<T>* lds, const cx<T>* dc, uint32_t SP, uint32_t FPW, uint32_t nvalid, int64_t outBase, uint32_t nat0) {
+	const uint32_t tid = threadIdx.x, NT = blockDim.x;
+	const uint32_t total = p.outLen * FPW;
+	const bool swO = p.swapOut != 0;
+#pragma unroll 1
+	for (uint32_t idx = tid; idx < total; idx += NT) {
+		uint32_t fi, k;
+		p.divOutLen.divmod(idx, fi, k);
+		if (fi >= nvalid) continue;
+		auto rd = [&](uint32_t a) -> cx<T> { const cx<T> v = (dc && a == 0u) ? dc[fi] : lds[fi * SP + a]; return swO ? cswap(v) : v; };
+		Io64<T> io{p.in, p.out, 0, outBase + (int64_t)fi * p.dim[0].outStride, p.inStrideJ, p.outStrideJ};
+		io.set_pad(p);
+		post_store<T>(p, io, k, 0u, nat0 + fi * p.opStride0, rd, op_value(opc));
+	}
 }
 
 template <typename T> __global__ void __launch_bounds__(1024) generic_pass_kernel(const PassParams p) {

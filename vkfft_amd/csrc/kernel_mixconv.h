@@ -17,6 +17,7 @@
 #include "mix_sched.h"
 #include "mix_stage.h"
 #include "kernel_generic.h"
+#include "kernel_mixrad.h"
 
 namespace vkfft_mi355x {
 
@@ -87,16 +88,9 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 		// ---- the row as it lies in memory -> LDS (dense rows: the tile is one contiguous run)
 		if constexpr (OPS != 0) {
 			const int64_t inB = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride;
-			for (uint32_t idx = tid; idx < (uint32_t)FPW * n; idx += (uint32_t)NT) {
-				const uint32_t fi = idx / n, pos = idx % n;
-				cx<T> v = {(T)0, (T)0};
-				if (fi < rowsHere) {
-					Io64<T> io{p.in, p.out, inB + (int64_t)fi * p.dim[0].inStride, 0, p.inStrideJ, p.outStrideJ};
-					io.set_pad(p);
-					v = pre_gather<T>(p, io, pos, (f0 + fi) * p.opStride0 + g1 * p.opStride1, p.preOp);
-				}
-				rows[fi * SP + pos] = swI ? cswap(v) : v;
-			}
+			// (the operation hoisted out of the loop: ops_rows_in, kernel_generic.h)
+			FastDiv divN; divN.d = n; divN.rcp = 1.0f / (float)n;
+			dispatch_pre_op(p.preOp, [&](auto opc) { ops_rows_in<T>(p, opc, divN, rows, (uint32_t)SP, (uint32_t)FPW * n, rowsHere, inB, f0 * p.opStride0 + g1 * p.opStride1); });
 		} else if (denseIn) {
 			for (uint32_t e = tid; e < rowsHere * n; e += (uint32_t)NT) {
 				const cx<T> v = gb_load<T>(gin, e * ES, 0);
@@ -125,16 +119,7 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 		auto fin = [&](cx<T> v) { if (swO) v = cswap(v); if (sc != (T)1) v = cscale(v, sc); return v; };
 		if constexpr (OPS != 0) {
 			const int64_t outB = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride;
-			const uint32_t total = p.outLen * (uint32_t)FPW;
-			for (uint32_t idx = tid; idx < total; idx += (uint32_t)NT) {
-				uint32_t fi, k;
-				p.divOutLen.divmod(idx, fi, k);
-				if (fi >= rowsHere) continue;
-				auto rd = [&](uint32_t a) -> cx<T> { const cx<T> v = a == 0u ? sDc[fi] : rows[fi * SP + a]; return swO ? cswap(v) : v; };
-				Io64<T> io{p.in, p.out, 0, outB + (int64_t)fi * p.dim[0].outStride, p.inStrideJ, p.outStrideJ};
-				io.set_pad(p);
-				post_store<T>(p, io, k, 0u, (f0 + fi) * p.opStride0 + g1 * p.opStride1, rd, p.postOp);
-			}
+			dispatch_post_op(p.postOp, [&](auto opc) { ops_rows_out<T>(p, opc, rows, sDc, (uint32_t)SP, (uint32_t)FPW, rowsHere, outB, f0 * p.opStride0 + g1 * p.opStride1); });
 		} else if (denseOut) {
 			for (uint32_t e = tid; e < rowsHere * n; e += (uint32_t)NT) {
 				const uint32_t r = e / n, j = e % n;
@@ -171,6 +156,7 @@ struct MixConvVariant {
 	int l; bool dp; int rader; int col; int rad[5]; int tpf; int fpw;
 	void (*launch)(const PassParams&, dim3, hipStream_t);
 	void (*launchOps)(const PassParams&, dim3, hipStream_t); // Rader rows: the form with the interpreter's pre / post maps (nullptr otherwise)
+	void (*launchRad)(const PassParams&, dim3, hipStream_t); // Rader rows: the prime as a stage of a composite length M * P (kernel_mixrad.h; nullptr otherwise)
 };
 template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL, int OPS> void mixconv_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
 	hipLaunchKernelGGL((mixconv_kernel<T, SCH, TPF, FPW, RADER, COL, OPS>), grid, dim3(TPF * FPW), 0, s, prm);
@@ -181,6 +167,6 @@ template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> conste
 }
 #define VKFFT_MC(T, dp, rader, col, r0, r1, r2, r3, r4, tpf, fpw) \
 	{ (r0) * (r1) * (r2) * (r3) * (r4), dp, rader, col, {r0, r1, r2, r3, r4}, tpf, fpw, &mixconv_launch<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, rader, col, 0>, \
-	  mixconv_ops_ptr<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, rader, col>() },
+	  mixconv_ops_ptr<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, rader, col>(), mixrad_ptr<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, rader, col>() },
 
 } // namespace vkfft_mi355x

@@ -137,6 +137,12 @@ bool mixconv_lookup(bool rader, bool col, uint64_t pOrMinLen, bool dp, int* vari
 	*fpw = best->fpw; *threads = best->tpf * best->fpw;
 	return true;
 }
+bool mixrad_available(int variant) {
+	int cnt = 0;
+	const MixConvVariant* tab = mixconv_part((variant >> 16) % kMixConvParts, &cnt);
+	const int idx = variant & 0xffff;
+	return variant >= 0 && idx < cnt && tab[idx].launchRad != nullptr;
+}
 int launch_mixconv(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * (prm.colMerge ? 1u : prm.dim[1].count) * prm.dim[2].count;
 	if (grid64 == 0) return 0;
@@ -144,6 +150,11 @@ int launch_mixconv(const PassPlan& pp, const PassParams& prm, hipStream_t stream
 	const MixConvVariant* tab = mixconv_part((pp.variant >> 16) % kMixConvParts, &cnt);
 	const int idx = pp.variant & 0xffff;
 	if (grid64 > 0x7fffffffull || pp.variant < 0 || idx >= cnt) return 4039;
+	if (prm.raderM > 1) { // the prime as a stage of the composite length raderM * P (kernel_mixrad.h)
+		if (!tab[idx].launchRad) return 4039;
+		tab[idx].launchRad(prm, dim3((uint32_t)grid64), stream);
+		return hipGetLastError() == hipSuccess ? 0 : 4039;
+	}
 	if ((prm.preOp != OP_NONE || prm.postOp != OP_NONE) && prm.preOp != OP_BLUESTEIN_PRE) { // (the Bluestein form handles its chirp itself: not the interpreter's maps)
 		if (!tab[idx].launchOps) return 4039;
 		tab[idx].launchOps(prm, dim3((uint32_t)grid64), stream);

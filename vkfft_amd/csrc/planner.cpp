@@ -6,6 +6,7 @@
 // computed in extended precision on the CPU).  The decisions themselves are re-derived for MI355X:
 // 160 KiB LDS per workgroup, 256-byte coalescing segments for strided tiles, fused Four-Step through the Infinity Cache.
 #include "engine.h"
+#include "kernel_mixrad.h" // (mixrad_cofactor_ok)
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -119,6 +120,7 @@ struct PassBuild {
 	uint32_t raderDirectMax = 0;
 	std::string label;
 	uint32_t forceT = 0;
+	uint32_t raderM = 0; // mixrad_kernel: cofactor of the composite length (kernel_mixrad.h)
 	std::vector<uint32_t> radices; // explicit stage radices (fast kernels fix their own schedule)
 	int fastKernel = KERNEL_GENERIC, fastVariant = -1, fastThreads = 0;
 	bool allowFast = true;
@@ -162,6 +164,22 @@ static void make_mixconv_rader_tables(uint64_t P, bool dp, Arena& ar, size_t& ta
 	host_fft(bk);
 	bhatOff = ar.alloc(L * (dp ? 16 : 8));
 	for (uint64_t m = 0; m < L; m++) ar.putc(bhatOff, m, bk[m] / (ld)L, dp);
+}
+
+// ... followed by the column twiddles of the composite form (kernel_mixrad.h): W_N^(b k2) at L + (b - 1) * P + k2, b = 1 ... M - 1, N = M * P
+static void make_mixrad_tables(uint64_t P, uint64_t M, bool dp, Arena& ar, size_t& tabOff, size_t& bhatOff) {
+	const uint64_t L = P - 1, g = primitive_root(P), gi = powmod(g, P - 2, P), N = M * P;
+	tabOff = ar.alloc(2 * (size_t)L * sizeof(uint32_t));
+	std::vector<cld> bk(L);
+	{
+		uint32_t* tab = (uint32_t*)(ar.b.data() + tabOff);
+		uint64_t gp = 1, gm = 1;
+		for (uint64_t q = 0; q < L; q++) { tab[q] = (uint32_t)gp; tab[L + q] = (uint32_t)gm; bk[q] = unit_root(gm, P); gp = gp * g % P; gm = gm * gi % P; }
+	}
+	host_fft(bk);
+	bhatOff = ar.alloc((L + (M - 1) * P) * (dp ? 16 : 8));
+	for (uint64_t m = 0; m < L; m++) ar.putc(bhatOff, m, bk[m] / (ld)L, dp);
+	for (uint64_t b = 1; b < M; b++) for (uint64_t k = 0; k < P; k++) ar.putc(bhatOff, L + (b - 1) * P + k, unit_root((b * k) % N, N), dp);
 }
 
 static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
@@ -418,6 +436,11 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.bigSpan = b.bigSpan ? 1u : 0u;
 	p.divL = make_fastdiv((uint32_t)b.L);
 	p.divOutLen = make_fastdiv(p.outLen);
+	if (b.raderM > 1) { // mixrad_kernel: rows of raderM * (L + 1) points; the kernel divides by the row length and by the cofactor
+		p.raderM = b.raderM;
+		p.divL = make_fastdiv((uint32_t)(b.raderM * (b.L + 1)));
+		p.divOutLen = make_fastdiv(b.raderM);
+	}
 	const uint64_t padded = p.padShift >= 31 ? b.L : b.L + (b.L >> p.padShift);
 	p.ldsElems = (uint32_t)((padded + 1) * p.Tp);
 	p.tilesPerG0 = (uint32_t)((dims[0].count + T - 1) / T);
@@ -987,6 +1010,36 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	// strided axis: Rader for a prime with 13-smooth p-1 (p-1 points, no padding), Bluestein on the smallest ladder length >= 2N-1.  Against the
 	// register-resident power-of-two kernels a point of these costs kCostRader / kCostBlue times as much (an LDS round trip more per transform, table
 	// look-ups through L2); VKFFT_MI355X_MIXCONV=0 turns the family off, =2 always prefers it (tests, tuning)
+	// ... or, for a composite length M * P with ONE prime factor above 31 whose P - 1 is 13-smooth and a cofactor of at most 32: the Rader convolution as a
+	// stage of the row (kernel_mixrad.h; the reference's Rader stage inside its radix kernels, vkFFT_Scheduler.h:1733-1873).  VKFFT_MI355X_MIXRAD=0: off
+	if (unit && !padded && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !dp && j.N <= 4096u &&
+	    !(getenv("VKFFT_MI355X_MIXRAD") && atoi(getenv("VKFFT_MI355X_MIXRAD")) == 0)) {
+		uint64_t P = 0, rest = j.N;
+		for (uint64_t q = 2; q * q <= rest; q++) while (rest % q == 0) { P = q; rest /= q; }
+		if (rest > 1) P = rest; // largest prime factor
+		const uint64_t M = P ? j.N / P : 0;
+		int v, r5[5], f, t; uint64_t len;
+		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
+		if (P >= 37 && mixrad_cofactor_ok((uint32_t)M) && (rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && mixconv_lookup(true, false, P, dp, &v, &len, r5, &f, &t) && mixrad_available(v)) {
+			b.L = len; b.inLen = b.outLen = (uint32_t)j.N; b.opN = (uint32_t)j.N;
+			for (int k = 0; k < 5; k++) if (r5[k] > 1) b.radices.push_back((uint32_t)r5[k]);
+			b.fastKernel = KERNEL_MIXCONV; b.fastVariant = v; b.fastThreads = t;
+			b.forceT = mixrad_rows((uint32_t)P, (uint32_t)f, dp, (uint32_t)j.N); // rows per workgroup (what the tile's LDS holds)
+			b.raderM = (uint32_t)M;
+			b.bsSwapIn = b.bsSwapOut = j.inverse; b.scale = j.scale;
+			b.inStrideJ = j.inStrideJ; b.outStrideJ = j.outStrideJ; b.dims = j.others;
+			b.colIn = b.colOut = false;
+			size_t tabOff, bhatOff;
+			make_mixrad_tables(P, M, dp, ar, tabOff, bhatOff);
+			b.aux2Off = bhatOff;
+			b.label = "rader-stage";
+			PassPlan pp; int r = finish_pass(b, ar, pp); if (r) return r;
+			pp.raderOff = tabOff;
+			passes.push_back(pp);
+			out.uploadsPerAxis[j.axisIndex] = 1;
+			return 0;
+		}
+	}
 	struct { bool use = false, rader = false, col = false; int variant = -1; uint64_t len = 0; int rad[5] = {1, 1, 1, 1, 1}; int fpw = 0, thr = 0; } mc;
 	const bool colTile = !unit && !j.others.empty() && j.others[0].inStride == 1 && j.others[0].outStride == 1;
 	if ((unit || colTile) && !padded && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && (!smooth13(j.N) || (unit && smoothNoInstance))) {

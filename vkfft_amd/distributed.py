@@ -57,13 +57,22 @@ class BatchShardedFFT:
 
 
 class SlabFFT3D:
-    """3D C2C of an (nx, ny, nz) volume distributed as z-slabs over the ranks of `group` (nz and ny divisible by their number).
+    """3D C2C of an (nx, ny, nz) volume distributed as z-slabs over the ranks of `group`.  nz and ny divisible by their number: the pipelined form
+    below; otherwise construction hands over to UnevenSlabFFT3D (slabs of shard_range sizes, one exchange, no plane groups) — same interface.
 
     forward(x): x = local z-slab, torch complex tensor [nz/P, ny, nx] (contiguous; overwritten)  ->  y-slab [nz, ny/P, nx]
     inverse(y): y-slab (overwritten) -> z-slab; unnormalised unless normalize=True.
     The exchange buffers (2 x the slab) and the inverse's output slab belong to the plan and are allocated once: a result is a view of them and
     stays valid until the next call of the same direction.
     `groups`: number of plane groups the exchange is pipelined over (must divide nz/P)."""
+
+    def __new__(cls, nx, ny, nz, group=None, **kw):
+        import torch.distributed as dist
+        P = dist.get_world_size(group) if dist.is_initialized() else 1
+        if cls is SlabFFT3D and (nz % P or ny % P):
+            kw.pop("groups", None)
+            return UnevenSlabFFT3D(nx, ny, nz, group, **kw)
+        return super().__new__(cls)
 
     def __init__(self, nx, ny, nz, group=None, *, dp=False, device_index=0, lib=None, normalize=False, groups=None):
         import torch
@@ -72,7 +81,7 @@ class SlabFFT3D:
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         P = self.P
-        assert nz % P == 0 and ny % P == 0, "slab decomposition needs nz and ny divisible by the number of ranks"
+        assert nz % P == 0 and ny % P == 0
         self.nx, self.ny, self.nz = nx, ny, nz
         self.nzl, self.nyl = nz // P, ny // P
         nzl, nyl = self.nzl, self.nyl
@@ -193,3 +202,143 @@ class SlabFFT3D:
 
     def delete(self):
         self.fy.delete(); self.fx.delete(); self.fz.delete()
+
+
+
+class UnevenSlabFFT3D:
+    """The slab transform for nz or ny NOT divisible by the number of ranks: rank r owns the planes shard_range(nz, r, P) before the exchange and the
+    y-rows shard_range(ny, r, P) after it (the first `total % P` ranks one more than the others).  Same decomposition and the same packing-free exchange
+    as SlabFFT3D — the x transform writes its rows straight into the send layout, now ONE strided plan per block size (blocks of base + 1 rows, then
+    blocks of base rows) — with messages of rank-dependent size and no pipelining over plane groups.
+
+    forward(x): x = local z-slab [nz_r, ny, nx] (contiguous, overwritten) -> y-slab [nz, ny_r, nx];  inverse(y) takes that back to the z-slab."""
+
+    def __init__(self, nx, ny, nz, group=None, *, dp=False, device_index=0, lib=None, normalize=False):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.P = P = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert nz >= P and ny >= P, "every rank needs at least one plane and one row"
+        self.nx, self.ny, self.nz = nx, ny, nz
+        self.zr = [shard_range(nz, r, P) for r in range(P)]   # planes of rank r before the exchange
+        self.yr = [shard_range(ny, r, P) for r in range(P)]   # rows of rank r after it
+        self.nzl = self.zr[self.rank][1] - self.zr[self.rank][0]
+        self.nyl = self.yr[self.rank][1] - self.yr[self.rank][0]
+        self.G = 1
+        self.dp, self.normalize = dp, normalize
+        self.es = 16 if dp else 8
+        self.cuda = torch.cuda.is_available() and not getattr(lib, "_vkfft_test_double", False)
+        self.compute = None
+        stream = None
+        if self.cuda:
+            _check_device(device_index)
+            self.compute = torch.cuda.Stream()
+            stream = self.compute.cuda_stream
+        nzl, nyl = self.nzl, self.nyl
+        kw = dict(dp=dp, device_index=device_index, lib=lib, stream=stream)
+        self.fy = api.App([nx, ny], nzl, omitDimension=[1, 0, 0, 0], **kw)
+        # x transforms, one plan per block size: blocks [b0, b0 + cnt) of `rows` rows each start at row y0 of the natural slab and at element e0 of
+        # the send layout  [block][z][row in block][x]  (block b holds nzl * rows_b * nx elements)
+        self.fx = []
+        base, extra = divmod(ny, P)
+        y0 = e0 = 0
+        for cnt, rows in ((extra, base + 1), (P - extra, base)):
+            if cnt and rows:
+                app = api.App([nx, rows, cnt, nzl], 1, omitDimension=[0, 1, 1, 1], isInputFormatted=1, inverseReturnToInputBuffer=1,
+                              inputBufferStride=[nx, nx * rows, nx * ny, nx * ny * nzl],
+                              bufferStride=[nx, nx * rows * nzl, nx * rows, nx * rows * nzl * cnt], **kw)
+                self.fx.append((app, y0 * nx, e0))
+            y0 += cnt * rows; e0 += cnt * rows * nzl * nx
+        self.fz = api.App([nx, nyl, nz], 1, omitDimension=[1, 1, 0, 0], normalize=int(normalize), **kw)
+        self._bufs = None
+
+    def _buffers(self, like):
+        if self._bufs is None or self._bufs[0].dtype != like.dtype or self._bufs[0].device != like.device:
+            t = self.torch
+            self._bufs = (t.empty(self.nzl * self.ny * self.nx, dtype=like.dtype, device=like.device),   # [block][z][row][x]: this rank's planes, every rank's rows
+                          t.empty(self.nz * self.nyl * self.nx, dtype=like.dtype, device=like.device),   # [z of every rank][row][x]: this rank's rows
+                          t.empty((self.nzl, self.ny, self.nx), dtype=like.dtype, device=like.device))
+        return self._bufs
+
+    def _chunks(self):
+        """(offset, length) in elements of rank r's chunk: in the [block][z][row][x] layout of MY planes, and in the [z][row][x] layout of MY rows"""
+        nx = self.nx
+        byrows, e = [], 0
+        for (lo, hi) in self.yr:
+            byrows.append((e, self.nzl * (hi - lo) * nx)); e += self.nzl * (hi - lo) * nx
+        byplanes = [(lo * self.nyl * nx, (hi - lo) * self.nyl * nx) for (lo, hi) in self.zr]
+        return byrows, byplanes
+
+    def _exchange(self, src, src_chunks, dst, dst_chunks):
+        """chunk r of src -> rank r's dst chunk of this rank; returns the outstanding requests"""
+        dist, torch = self.dist, self.torch
+        me = self.rank
+        so, sl = src_chunks[me]; do, dl = dst_chunks[me]
+        dst[do:do + dl].copy_(src[so:so + sl])
+        if self.P == 1:
+            return []
+        ops = []
+        for d in range(1, self.P):
+            to, frm = (me + d) % self.P, (me - d) % self.P
+            so, sl = src_chunks[to]; do, dl = dst_chunks[frm]
+            ops.append(dist.P2POp(dist.isend, torch.view_as_real(src[so:so + sl]), to, self.group))
+            ops.append(dist.P2POp(dist.irecv, torch.view_as_real(dst[do:do + dl]), frm, self.group))
+        return dist.batch_isend_irecv(ops)
+
+    def forward(self, x):
+        torch = self.torch
+        assert tuple(x.shape) == (self.nzl, self.ny, self.nx) and x.is_contiguous()
+        send, recv, _ = self._buffers(x)
+        caller = torch.cuda.current_stream() if self.cuda else None
+        if self.cuda:
+            self.compute.wait_stream(caller)
+        self.fy.forward(buffer_ptr=x.data_ptr())
+        for app, yoff, eoff in self.fx:
+            app.forward(buffer_ptr=send.data_ptr() + eoff * self.es, input_ptr=x.data_ptr() + yoff * self.es)
+        if self.cuda:
+            caller.wait_stream(self.compute)
+        byrows, byplanes = self._chunks()
+        for w in self._exchange(send, byrows, recv, byplanes):
+            w.wait()
+        y = recv.view(self.nz, self.nyl, self.nx)
+        if self.cuda:
+            self.compute.wait_stream(caller)
+        self.fz.forward(buffer_ptr=y.data_ptr())
+        if self.cuda:
+            caller.wait_stream(self.compute)
+            y.record_stream(self.compute); send.record_stream(self.compute); x.record_stream(self.compute)
+        return y
+
+    def inverse(self, y):
+        torch = self.torch
+        assert tuple(y.shape) == (self.nz, self.nyl, self.nx) and y.is_contiguous()
+        caller = torch.cuda.current_stream() if self.cuda else None
+        a, b, x = self._buffers(y)
+        if self.cuda:
+            self.compute.wait_stream(caller)
+        self.fz.inverse(buffer_ptr=y.data_ptr())
+        if self.cuda:
+            caller.wait_stream(self.compute)
+        byrows, byplanes = self._chunks()
+        for w in self._exchange(y.view(-1), byplanes, a, byrows):
+            w.wait()
+        if self.cuda:
+            self.compute.wait_stream(caller)
+        for app, yoff, eoff in self.fx:
+            app.inverse(buffer_ptr=a.data_ptr() + eoff * self.es, input_ptr=x.data_ptr() + yoff * self.es)
+        self.fy.inverse(buffer_ptr=x.data_ptr())
+        if self.cuda:
+            caller.wait_stream(self.compute)
+            x.record_stream(self.compute); a.record_stream(self.compute); y.record_stream(self.compute)
+        if self.normalize:
+            x /= (self.nx * self.ny)
+        return x
+
+    def exchange_bytes_per_rank(self):
+        return (self.nzl * self.ny - self.nzl * self.nyl) * self.nx * self.es
+
+    def delete(self):
+        self.fy.delete(); self.fz.delete()
+        for app, _, _ in self.fx:
+            app.delete()
