@@ -390,6 +390,7 @@ def test_rader_stage_of_a_composite_length(run, oracle, monkeypatch, N):
     """kernel_mixrad.h: rows of M * P points, the Rader convolution of the prime P as a stage (cofactors below, equal to and above the thread groups of
     the prime's instance; 64 * 37 has no such plan — cofactor above 32 — and must still be right through Bluestein); against the truth, against the
     Bluestein plan of the same length, a batch that leaves the last workgroup partly filled, and the inverse"""
+    monkeypatch.setenv("VKFFT_MI355X_MIXRAD", "2")  # (every served length, also where the cost model prefers Bluestein)
     batch = 7
     x = parity.seeded_complex(N * batch, False, N)
     y, z, up = run.transform(x, (N,), batch, both=True)
@@ -512,3 +513,13 @@ def test_real_planes_of_smooth_lengths_outside_the_curated_list(run, oracle, sha
     for type in (2, 3, 4):
         parity.check_r2r(run, oracle, shape, 2, False, type, False)
     parity.check_r2r(run, oracle, shape, 2, False, 2, True)
+
+
+@pytest.mark.parametrize("kind,N", [("r2c", 265), ("r2c", 328), ("r2c", 148), ("dct2", 265), ("dct2", 148), ("dct3", 111), ("dct4", 74), ("r2c", 2 * 1010), ("dct2", 889), ("dst2", 185)])
+def test_real_rows_whose_complex_length_has_a_rader_stage(run, oracle, monkeypatch, kind, N):
+    """R2C / C2R / DCT / DST rows whose complex transform length is M * P (a Rader prime and a small cofactor): the Rader-stage kernel between the generic
+    pre- and post-maps (kernel_mixrad.h, `ops`), against the oracle and against the plan without it"""
+    if kind == "r2c":
+        parity.check_r2c(run, oracle, (N,), 5, False)
+    else:
+        parity.check_r2r(run, oracle, (N,), 5, False, int(kind[3]), kind.startswith("dst"))

@@ -45,6 +45,7 @@ def test_pow2_multi_pass(run, oracle, k, passes):
 def test_rader_stage_of_a_composite_length_on_device(run, oracle, monkeypatch, N):
     """kernel_mixrad.h on the device: rows of M * P points with the prime's Rader convolution as a stage — the truth, the Bluestein plan of the same
     length, a chip-filling batch against the small one bit for bit"""
+    monkeypatch.setenv("VKFFT_MI355X_MIXRAD", "2")  # (every served length, also where the cost model prefers Bluestein)
     batch = 7
     x = parity.seeded_complex(N * batch, False, N)
     y, z, up = run.transform(x, (N,), batch, both=True)

@@ -532,7 +532,8 @@ __device__ inline cx<T>* run_stage_rader_fft(const PassParams& p, const StageDes
 // they are 4-9x the code of the transform they surround, once per kernel instance.
 // divN divides by the row length, rows of the tile at lds + fi * SP, natural order.
 template <typename T, typename OPC>
-__device__ inline void ops_rows_in(const PassParams& p, OPC opc, const FastDiv divN, cx<T>* lds, uint32_t SP, uint32_t TOT, uint32_t nvalid, int64_t inBase, uint32_t nat0) {
+// subM > 1: the row is stored sub-sequence-major (element M a + b at b * subP + a: kernel_mixrad.h)
+__device__ inline void ops_rows_in(const PassParams& p, OPC opc, const FastDiv divN, cx<T>* lds, uint32_t SP, uint32_t TOT, uint32_t nvalid, int64_t inBase, uint32_t nat0, uint32_t subM = 1, uint32_t subP = 0) {
 	const uint32_t tid = threadIdx.x, NT = blockDim.x;
 	const bool swI = p.swapIn != 0;
 #pragma unroll 1
@@ -545,7 +546,8 @@ __device__ inline void ops_rows_in(const PassParams& p, OPC opc, const FastDiv d
 			io.set_pad(p);
 			v = pre_gather<T>(p, io, pos, nat0 + fi * p.opStride0, op_value(opc));
 		}
-		lds[fi * SP + pos] = swI ? cswap(v) : v;
+		const uint32_t dst = subM > 1 ? (pos % subM) * subP + pos / subM : pos;
+		lds[fi * SP + dst] = swI ? cswap(v) : v;
 	}
 }
 // rows of the tile -> post-map -> global memory; fetch(fi, a) delivers element a of row fi (un-swapped); rows at lds + fi * SP unless `dc` (Rader: element 0 of a row lives in dc[fi])

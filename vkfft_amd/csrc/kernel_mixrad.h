@@ -18,6 +18,8 @@
 #include "memops.h"
 #include "mix_sched.h"
 #include "mix_stage.h"
+#include "mixrad_plan.h"
+#include "kernel_generic.h"
 
 namespace vkfft_mi355x {
 
@@ -58,15 +60,11 @@ template <int M, typename T> __host__ __device__ inline void mixrad_dft(cx<T>* v
 	else if constexpr (M == 30) mixrad_dft_ab<2, 15, T>(v);
 	else dft<M, T>(v); // 2 ... 10, 12, 14, 15, 16, 25, 32
 }
-// cofactors served (one butterfly each inside every instance: cofactors with a prime factor of 11 or more are left to Bluestein — 80 KB of code per instance as it is)
-__host__ __device__ constexpr bool mixrad_cofactor_ok(uint32_t m) {
-	return (m >= 2 && m <= 10) || m == 12 || m == 14 || m == 15 || m == 16 || m == 18 || m == 20 || m == 21 || m == 24 || m == 25 || m == 27 || m == 28 || m == 30 || m == 32;
-}
-
 // step 3 for a compile-time cofactor
+// toLds != nullptr (real transforms between the generic maps): the columns go to a second row region in natural order instead of global memory
 template <typename T, int M, int P, int NT>
 __device__ inline void mixrad_columns(const cx<T>* rowbuf, const uint32_t N, const uint32_t rowsHere, const GBuf gout, const GBuf gtw, const uint32_t outRowBytes,
-                                      const bool swO, const T sc, const uint32_t tid) {
+                                      const bool swO, const T sc, const uint32_t tid, cx<T>* toLds) {
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	const uint32_t total = rowsHere * (uint32_t)P;
 	for (uint32_t j = tid; j < total; j += (uint32_t)NT) {
@@ -87,6 +85,11 @@ __device__ inline void mixrad_columns(const cx<T>* rowbuf, const uint32_t N, con
 			if constexpr (M > 10) VKFFT_SCHED_FENCE();
 		}
 		mixrad_dft<M, T>(y);
+		if (toLds) {
+#pragma unroll
+			for (int k1 = 0; k1 < M; k1++) toLds[r * N + k2 + (uint32_t)(k1 * P)] = y[k1];
+			continue;
+		}
 		const uint32_t o = r * outRowBytes + k2 * ES;
 #pragma unroll
 		for (int k1 = 0; k1 < M; k1++) {
@@ -98,18 +101,15 @@ __device__ inline void mixrad_columns(const cx<T>* rowbuf, const uint32_t N, con
 }
 
 // lut = stage twiddles of SCH (length P - 1); rader = uint32 g^a mod P (a < L) followed by g^-k mod P; aux2 = FFT of the Rader kernel / L (L entries)
-// followed by the column twiddles W_N^(b k2), (b - 1) * P + k2, b = 1 ... M - 1; raderM = M; divL divides by N, divOutLen by M.
+// followed by the column twiddles W_N^(b k2), (b - 1) * P + k2, b = 1 ... M - 1; raderM = M.
 // Tiles: forceT = rows per workgroup = mixrad_rows(P, FPW, N): as many rows as the tile's LDS holds (the thread groups take their sub-sequences in rounds).
 // MHI: which cofactors the instance serves — 0: 2 ... 10 (a thread's butterfly is small: 64 registers, eight waves per SIMD), 1: 12 ... 32.
-// LDS elements of the tile's rows: one round of the thread groups at full occupation (FPW sub-sequences) or the longest row the prime serves, whichever is more
-__host__ __device__ constexpr uint32_t mixrad_row_elems(uint32_t P, uint32_t FPW, bool dp) { return FPW * P > (32u * P < (dp ? 2048u : 4096u) ? 32u * P : (dp ? 2048u : 4096u)) ? FPW * P : (32u * P < (dp ? 2048u : 4096u) ? 32u * P : (dp ? 2048u : 4096u)); }
-__host__ __device__ constexpr uint32_t mixrad_rows(uint32_t P, uint32_t FPW, bool dp, uint32_t N) { return mixrad_row_elems(P, FPW, dp) / N > 0 ? mixrad_row_elems(P, FPW, dp) / N : 1u; }
 template <typename T, typename SCH, int TPF, int FPW, int MHI>
 __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	constexpr int L = SCH::N, P = L + 1, NT = TPF * FPW;
 	constexpr int EXPF = SCH::NS > 1 ? MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems() : 1;
 	constexpr int EX = (EXPF > L ? EXPF : L) | 1;                     // per thread group: exchange buffer of the stages = carrier of the spectrum between the two transforms
-	constexpr int ROWN = (int)mixrad_row_elems(P, FPW, sizeof(T) == 8); // rows of the tile, sub-sequence-major
+	constexpr int ROWN = (int)mixrad_row_elems(P, FPW, sizeof(T) == 8, MHI != 0); // rows of the tile, sub-sequence-major
 	constexpr bool waveOnly = (TPF <= 64) && (64 % TPF == 0);
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	static_assert((size_t)(FPW * EX + ROWN) * sizeof(cx<T>) <= 160 * 1024, "LDS");
@@ -118,7 +118,12 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	const uint32_t tid = threadIdx.x;
 	const uint32_t f = tid / TPF, tau = tid % TPF;
 	const uint32_t M = p.raderM, N = M * (uint32_t)P;
-	const uint32_t RW = mixrad_rows(P, FPW, sizeof(T) == 8, N);
+	// real transforms (R2C / C2R / DCT / DST whose complex length is M * P): the row enters through the generic pre-map and leaves through the generic
+	// post-map (kernel_generic.h: ops_rows_in / ops_rows_out, the operation hoisted out of their loops); the kernel spectrum then comes from aux3
+	FastDiv divN, divM; // (by the row length and by the cofactor: run-time values of this kernel, not the pass's own dividers, which the generic maps use)
+	divN.d = N; divN.rcp = 1.0f / (float)N; divM.d = M; divM.rcp = 1.0f / (float)M;
+	const bool ops = p.preOp != OP_NONE || p.postOp != OP_NONE;
+	const uint32_t RW = mixrad_rows(P, FPW, sizeof(T) == 8, N, M, ops);
 	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
@@ -127,15 +132,20 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	const uint32_t rowsHere = p.dim[0].count - f0 < RW ? p.dim[0].count - f0 : RW;
 	const GBuf gin = make_gbuf((const cx<T>*)p.in + ((int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride));
 	const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride));
-	const GBuf glut = make_gbuf(p.lut), gbh = make_gbuf(p.aux2), gtw = make_gbuf((const cx<T>*)p.aux2 + L);
+	const GBuf glut = make_gbuf(p.lut), gbh = make_gbuf(ops ? p.aux3 : p.aux2), gtw = make_gbuf((const cx<T>*)(ops ? p.aux3 : p.aux2) + L);
 	const bool swI = p.bluesteinSwapIn != 0, swO = p.bluesteinSwapOut != 0;
+	const int64_t rowIn0 = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride;
+	const int64_t rowOut0 = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride;
+	const uint32_t nat0 = f0 * p.opStride0 + g1 * p.opStride1;
 	// ---- 1. rows -> LDS, sub-sequence-major
-	{
+	if (ops) {
+		dispatch_pre_op(p.preOp, [&](auto opc) { ops_rows_in<T>(p, opc, divN, rowbuf, N, rowsHere * N, rowsHere, rowIn0, nat0, M, (uint32_t)P); });
+	} else {
 		const uint32_t inRowBytes = (uint32_t)p.dim[0].inStride * ES;
 		for (uint32_t e = tid; e < rowsHere * N; e += (uint32_t)NT) {
 			uint32_t r, n, a, b;
-			p.divL.divmod(e, r, n);
-			p.divOutLen.divmod(n, a, b);
+			divN.divmod(e, r, n);
+			divM.divmod(n, a, b);
 			const cx<T> v = gb_load<T>(gin, r * inRowBytes + n * ES, 0);
 			rowbuf[r * N + b * (uint32_t)P + a] = swI ? cswap(v) : v;
 		}
@@ -150,7 +160,7 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 		for (uint32_t job = f; job < ((jobs + (uint32_t)FPW - 1u) / (uint32_t)FPW) * (uint32_t)FPW; job += (uint32_t)FPW) { // (every group runs every round: the barriers are the workgroup's)
 			const bool live = job < jobs;
 			uint32_t r = 0, b = 0;
-			if (live) p.divOutLen.divmod(job, r, b);
+			if (live) divM.divmod(job, r, b);
 			cx<T>* const seq = rowbuf + r * N + b * (uint32_t)P;
 			const cx<T> x0 = seq[0];
 			// forward transform of x[g^a]; spectrum * FFT(w^(g^-q)) / L, + x0 on the zero frequency (= x0 added to every output); X[0] = x0 + sum of the others
@@ -172,7 +182,8 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	// ---- 3. column twiddle, M-point butterfly, coalesced stores
 	const uint32_t outRowBytes = (uint32_t)p.dim[0].outStride * ES;
 	const T sc = (T)p.scale;
-#define VKFFT_MIXRAD_CASE(m) case m: mixrad_columns<T, m, P, NT>(rowbuf, N, rowsHere, gout, gtw, outRowBytes, swO, sc, tid); break;
+	cx<T>* const natural = ops ? rowbuf + ROWN / 2 : nullptr; // (the rows of an OPS tile fill at most half the region: mixrad_rows)
+#define VKFFT_MIXRAD_CASE(m) case m: mixrad_columns<T, m, P, NT>(rowbuf, N, rowsHere, gout, gtw, outRowBytes, swO, sc, tid, natural); break;
 	if constexpr (MHI == 0) {
 		switch (M) {
 		VKFFT_MIXRAD_CASE(2) VKFFT_MIXRAD_CASE(3) VKFFT_MIXRAD_CASE(4) VKFFT_MIXRAD_CASE(5) VKFFT_MIXRAD_CASE(6) VKFFT_MIXRAD_CASE(7) VKFFT_MIXRAD_CASE(8)
@@ -187,6 +198,10 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 		}
 	}
 #undef VKFFT_MIXRAD_CASE
+	if (ops) {
+		VKFFT_SYNC();
+		dispatch_post_op(p.postOp, [&](auto opc) { ops_rows_out<T>(p, opc, natural, (const cx<T>*)nullptr, N, RW, rowsHere, rowOut0, nat0); });
+	}
 }
 template <typename T, typename SCH, int TPF, int FPW> void mixrad_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
 	if (prm.raderM <= 10) hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, 0>), grid, dim3(TPF * FPW), 0, s, prm);
@@ -196,7 +211,7 @@ template <typename T, typename SCH, int TPF, int FPW> void mixrad_launch(const P
 template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> constexpr auto mixrad_ptr() -> void (*)(const PassParams&, dim3, hipStream_t) {
 	constexpr int P = SCH::N + 1, NMAX = sizeof(T) == 4 ? 4096 : 2048;
 	constexpr int EXPF = SCH::NS > 1 ? MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems() : 1;
-	constexpr int EX = (EXPF > SCH::N ? EXPF : SCH::N) | 1, ROWN = (int)mixrad_row_elems(P, FPW, sizeof(T) == 8);
+	constexpr int EX = (EXPF > SCH::N ? EXPF : SCH::N) | 1, ROWN = (int)mixrad_row_elems(P, FPW, sizeof(T) == 8, true);
 	if constexpr (RADER != 0 && COL == 0 && sizeof(T) == 4 && 2 * P <= NMAX && (size_t)(FPW * EX + ROWN) * sizeof(cx<T>) <= 160 * 1024) return &mixrad_launch<T, SCH, TPF, FPW>;
 	else return nullptr;
 }

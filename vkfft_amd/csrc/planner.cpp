@@ -6,7 +6,7 @@
 // computed in extended precision on the CPU).  The decisions themselves are re-derived for MI355X:
 // 160 KiB LDS per workgroup, 256-byte coalescing segments for strided tiles, fused Four-Step through the Infinity Cache.
 #include "engine.h"
-#include "kernel_mixrad.h" // (mixrad_cofactor_ok)
+#include "mixrad_plan.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -272,6 +272,28 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 			if (mixed_row_lookup(b.L, b.dp, &variant, rad5, &fpw, &thr)) {
 				b.fastKernel = KERNEL_MIXED_ROW; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
 				for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
+			} else if (!b.dp && b.L >= 74 && b.L <= 4096 && !is_prime_u(b.L) && [&]() {
+				// the complex length is M * P with a Rader prime and a served cofactor: mixrad_kernel behind the maps (kernel_mixrad.h)
+				if (getenv("VKFFT_MI355X_MIXRAD") && atoi(getenv("VKFFT_MI355X_MIXRAD")) == 0) return false;
+				uint64_t P = 0, rest = b.L;
+				for (uint64_t q = 2; q * q <= rest; q++) while (rest % q == 0) { P = q; rest /= q; }
+				if (rest > 1) P = rest;
+				const uint64_t M = P ? b.L / P : 0;
+				if (P < 37 || !mixrad_cofactor_ok((uint32_t)M) || !mixconv_lookup(true, false, P, b.dp, &variant, &len, rad5, &fpw, &thr) || !mixrad_available(variant) ||
+				    !mixrad_fits((uint32_t)P, (uint32_t)fpw, b.dp, (uint32_t)b.L, (uint32_t)M, true)) return false;
+				const uint64_t N = b.L;
+				if (!b.inLen) b.inLen = (uint32_t)N;
+				if (!b.outLen) b.outLen = (uint32_t)N;
+				if (!b.blueN) b.blueN = (uint32_t)N;
+				size_t bhatOff;
+				make_mixrad_tables(P, M, b.dp, ar, mixconvTabOff, bhatOff);
+				b.auxOff2ForPre = bhatOff;
+				b.L = len; b.raderM = (uint32_t)M;
+				b.fastKernel = KERNEL_MIXCONV; b.fastVariant = variant; b.fastThreads = thr;
+				b.forceT = mixrad_rows((uint32_t)P, (uint32_t)fpw, b.dp, (uint32_t)N, (uint32_t)M, true);
+				for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
+				return true;
+			}()) {
 			} else if (b.L >= 37 && is_prime_u(b.L) && mixconv_lookup(true, false, b.L, b.dp, &variant, &len, rad5, &fpw, &thr)) {
 				// the complex length is a Rader prime: mixconv_kernel OPS = 1 (transform length P - 1; kernel spectrum through aux3)
 				const uint64_t P = b.L;
@@ -436,11 +458,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.bigSpan = b.bigSpan ? 1u : 0u;
 	p.divL = make_fastdiv((uint32_t)b.L);
 	p.divOutLen = make_fastdiv(p.outLen);
-	if (b.raderM > 1) { // mixrad_kernel: rows of raderM * (L + 1) points; the kernel divides by the row length and by the cofactor
-		p.raderM = b.raderM;
-		p.divL = make_fastdiv((uint32_t)(b.raderM * (b.L + 1)));
-		p.divOutLen = make_fastdiv(b.raderM);
-	}
+	p.raderM = b.raderM; // mixrad_kernel: rows of raderM * (L + 1) points
 	const uint64_t padded = p.padShift >= 31 ? b.L : b.L + (b.L >> p.padShift);
 	p.ldsElems = (uint32_t)((padded + 1) * p.Tp);
 	p.tilesPerG0 = (uint32_t)((dims[0].count + T - 1) / T);
@@ -1020,11 +1038,17 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		const uint64_t M = P ? j.N / P : 0;
 		int v, r5[5], f, t; uint64_t len;
 		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
-		if (P >= 37 && mixrad_cofactor_ok((uint32_t)M) && (rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && mixconv_lookup(true, false, P, dp, &v, &len, r5, &f, &t) && mixrad_available(v)) {
+		// taken where it was measured faster than the fused Bluestein kernel on the next power of two >= 2N - 1 (profiles/r04_all_lengths_2_320_*, r04_sample1000_*:
+		// 1.2-1.8x for primes up to 97 when the padding is 2.5x or more — 129 ... 200, 258 ... 400, 2670 —, 0.4-0.9x for the larger primes' instances and
+		// for lengths just below a power of two): a point costs 2.6 / 3.5 / 5 points of the padded power-of-two transform for P <= 100 / <= 130 / beyond
+		uint64_t M2 = 64; while (M2 < 2 * j.N - 1) M2 *= 2;
+		const double radCost = (P <= 100 ? 2.6 : P <= 130 ? 3.5 : 5.0) * (double)j.N;
+		const bool radForced = getenv("VKFFT_MI355X_MIXRAD") && atoi(getenv("VKFFT_MI355X_MIXRAD")) == 2; // (tests: always)
+		if (P >= 37 && (radForced || radCost < (double)M2) && mixrad_cofactor_ok((uint32_t)M) && (rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && mixconv_lookup(true, false, P, dp, &v, &len, r5, &f, &t) && mixrad_available(v)) {
 			b.L = len; b.inLen = b.outLen = (uint32_t)j.N; b.opN = (uint32_t)j.N;
 			for (int k = 0; k < 5; k++) if (r5[k] > 1) b.radices.push_back((uint32_t)r5[k]);
 			b.fastKernel = KERNEL_MIXCONV; b.fastVariant = v; b.fastThreads = t;
-			b.forceT = mixrad_rows((uint32_t)P, (uint32_t)f, dp, (uint32_t)j.N); // rows per workgroup (what the tile's LDS holds)
+			b.forceT = mixrad_rows((uint32_t)P, (uint32_t)f, dp, (uint32_t)j.N, (uint32_t)M, false); // rows per workgroup (what the tile's LDS holds)
 			b.raderM = (uint32_t)M;
 			b.bsSwapIn = b.bsSwapOut = j.inverse; b.scale = j.scale;
 			b.inStrideJ = j.inStrideJ; b.outStrideJ = j.outStrideJ; b.dims = j.others;
