@@ -8,11 +8,10 @@ from vkfft_amd import api
 
 TOTAL = 27
 CONFIGS = {
-    16: [{}, {"FUV16": 3}, {"FUV16": 4}, {"FUV16": 3, "FUSED_MARGIN": 400}],
-    17: [{}, {"FUV17": 3}, {"FUV17": 4}, {"FUV17": 3, "FUSED_MARGIN": 400}],
-    18: [{}, {"FUV18": 3}, {"FUV18": 4}, {"FUV18": 3, "FUSED_MARGIN": 400}],
-    19: [{}, {"FUV19": 3}, {"FUV19": 4}, {"FUV19": 5}, {"FUV19": 3, "FUSED_MARGIN": 300}, {"FUV19": 3, "FUSED_MARGIN": 400}],
-    20: [{}, {"FUV20": 3}, {"FUV20": 4}, {"FUV20": 5}, {"FUV20": 3, "FUSED_MARGIN": 300}, {"FUV20": 3, "FUSED_MARGIN": 400}],
+    21: [{}] + [{"FUSED_LAG": l, "FUSED_RING": r, "FUSED_QUEUES": q} for q in (1, 2, 4, 8) for (l, r) in ((1, 2), (1, 3), (2, 3), (2, 4), (3, 5))] + [{"FUSED_MARGIN": m} for m in (100, 300, 400)],
+    22: [{}] + [{"FUSED_LAG": l, "FUSED_RING": r, "FUSED_QUEUES": q} for q in (1, 2, 4, 8) for (l, r) in ((1, 2), (1, 3), (2, 3), (2, 4), (3, 5))] + [{"FUSED_MARGIN": m} for m in (100, 300, 400)],
+    19: [{}] + [{"FUSED_CHUNK_KIB": c} for c in (2048, 8192, 16384)] + [{"FUSED_QUEUES": q} for q in (1, 4)],
+    20: [{}] + [{"FUSED_CHUNK_KIB": c} for c in (4096, 16384, 32768)] + [{"FUSED_QUEUES": q} for q in (1, 4)],
 }
 
 
