@@ -523,3 +523,11 @@ def test_real_rows_whose_complex_length_has_a_rader_stage(run, oracle, monkeypat
         parity.check_r2c(run, oracle, (N,), 5, False)
     else:
         parity.check_r2r(run, oracle, (N,), 5, False, int(kind[3]), kind.startswith("dst"))
+
+
+@pytest.mark.parametrize("N,dp", [(169, False), (385, False), (286, False), (1001, False), (2 * 1573, False), (169, True), (286, True), (33 * 13, True)])
+def test_real_rows_with_the_maps_inside_the_stages(run, oracle, N, dp):
+    """R2C / C2R rows whose complex transform runs on a mixed-radix instance with eight or more threads per row: the plain load / store maps (packed complex
+    side of the even split; full-length real forms of odd lengths: real in, N/2 + 1 bins out, Hermitian half in, real parts out) run inside the first /
+    last stage instead of a staging pass (kernel_mixed.h, `DIRECT`); several rows so that the last workgroup is partly filled"""
+    parity.check_r2c(run, oracle, (N,), 7, dp)

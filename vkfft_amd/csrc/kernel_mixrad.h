@@ -204,8 +204,9 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	}
 }
 template <typename T, typename SCH, int TPF, int FPW> void mixrad_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
+	constexpr int P = SCH::N + 1, NMAX = sizeof(T) == 4 ? 4096 : 2048;
 	if (prm.raderM <= 10) hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, 0>), grid, dim3(TPF * FPW), 0, s, prm);
-	else hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, 1>), grid, dim3(TPF * FPW), 0, s, prm);
+	else if constexpr (12 * P <= NMAX) hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, 1>), grid, dim3(TPF * FPW), 0, s, prm); // (a cofactor of 12 or more fits the longest row)
 }
 // the composite form exists for the fp32 Rader ROW instances whose prime leaves room for a cofactor (2 P <= the longest row) and whose tile fits the LDS
 template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> constexpr auto mixrad_ptr() -> void (*)(const PassParams&, dim3, hipStream_t) {
