@@ -759,7 +759,7 @@ def test_multi_gpu_cxx_drivers_with_virtual_ranks(product_lib):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-s", "-C", root, "build/vkfft_mi355x_multi"])
     exe = os.path.join(root, "build", "vkfft_mi355x_multi")
-    for ranks, n in ((1, 64), (2, 64), (4, 96)):
+    for ranks, n in ((1, 64), (2, 64), (4, 96), (3, 64), (4, 90)):  # (the last two: n is not a multiple of the rank count — slabs of ceil / floor(n / g))
         out = subprocess.run([exe, "-slab3d", "-n", str(n), "-g", str(ranks), "-virtual", "-transport", "copy", "-verify", "-reps", "2"], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         rec = json.loads(out.stdout.strip().splitlines()[-1])

@@ -6,7 +6,7 @@
 //            (weak scaling: -B is the batch PER GPU unless -total is given); the timed region is bracketed by a barrier over the ranks and the
 //            slowest rank's time counts.
 //   -slab3d  one 3D C2C of n^3 points distributed as z-slabs: local (x, y) transforms -> ONE exchange that re-partitions z <-> y (every pair of
-//            ranks trades 8 n^3 / g^2 bytes) -> local z transforms; the result is left in y-slab layout [nz][ny/g][nx] (no second exchange), the
+//            ranks trades about 8 n^3 / g^2 bytes; n need not be a multiple of g: slabs of ceil / floor(n / g) planes and rows) -> local z transforms; the result is left in y-slab layout [nz][ny/g][nx] (no second exchange), the
 //            inverse takes that layout back.  Exchange transports:
 //              rccl  ncclSend / ncclRecv inside one group call per rank (RCCL over xGMI; needs g distinct devices)
 //              copy  device-to-device copies into the peers' receive buffers (hipMemcpyAsync; also what lets g "virtual ranks" share ONE device,
@@ -101,10 +101,20 @@ struct SlabRank {
 	ncclComm_t comm = nullptr;
 };
 
+// contiguous block of `total` items owned by rank r of g (the first total % g ranks one more): the split of vkfft_amd/distributed.py shard_range
+static void shard(uint64_t total, int r, int g, uint64_t& lo, uint64_t& cnt) {
+	const uint64_t base = total / g, extra = total % g;
+	lo = (uint64_t)r * base + std::min<uint64_t>((uint64_t)r, extra);
+	cnt = base + ((uint64_t)r < extra ? 1 : 0);
+}
+
 static int run_slab(int g, const std::vector<int>& devs, uint64_t n, const std::string& transport, bool verify, uint64_t reps) {
-	if (n % g) { fprintf(stderr, "n must be divisible by the number of ranks\n"); return 2; }
-	const uint64_t nx = n, ny = n, nz = n, nzl = nz / g, nyl = ny / g;
-	const uint64_t slabElems = nzl * ny * nx, blockElems = nzl * nyl * nx; // one pair message = blockElems complex
+	if (n < (uint64_t)g) { fprintf(stderr, "every rank needs at least one plane\n"); return 2; }
+	// rank r owns the planes zlo[r] .. zlo[r] + nzr[r] before the exchange and the rows ylo[r] .. + nyr[r] after it; n need not be a multiple of g
+	const uint64_t nx = n, ny = n, nz = n;
+	std::vector<uint64_t> zlo(g), nzr(g), ylo(g), nyr(g);
+	for (int r = 0; r < g; r++) { shard(nz, r, g, zlo[r], nzr[r]); shard(ny, r, g, ylo[r], nyr[r]); }
+	const uint64_t maxBlock = nzr[0] * nyr[0] * nx; // largest pair message (complex elements)
 	Barrier bar(g);
 	std::atomic<int> fail{0};
 	std::vector<SlabRank> R(g);
@@ -119,11 +129,15 @@ static int run_slab(int g, const std::vector<int>& devs, uint64_t n, const std::
 	auto rank_main = [&](int r) {
 		SlabRank& k = R[r];
 		k.r = r; k.dev = devs[r]; k.comm = comms[r];
+		const uint64_t nzl = nzr[r], nyl = nyr[r];
+		const uint64_t slabElems = nzl * ny * nx;   // my planes, every row:   z-slab [nzl][ny][nx] and the send layout [peer s][nzl][nyr[s]][nx]
+		const uint64_t yslabElems = nz * nyl * nx;  // every plane, my rows:   y-slab [nz][nyl][nx] = [peer s][nzr[s]][nyl][nx]
+		const uint64_t bufElems = std::max(slabElems, yslabElems);
 		HIPOK(hipSetDevice(k.dev));
 		HIPOK(hipDeviceGet(&k.hdev, k.dev));
 		HIPOK(hipStreamCreate(&k.st));
-		HIPOK(hipMalloc(&k.slab, slabElems * 8)); HIPOK(hipMalloc(&k.send, slabElems * 8)); HIPOK(hipMalloc(&k.recv, slabElems * 8));
-		if (verify) HIPOK(hipMemcpy(k.slab, hostIn.data() + 2 * (uint64_t)r * slabElems, slabElems * 8, hipMemcpyHostToDevice));
+		HIPOK(hipMalloc(&k.slab, bufElems * 8)); HIPOK(hipMalloc(&k.send, bufElems * 8)); HIPOK(hipMalloc(&k.recv, bufElems * 8));
+		if (verify) HIPOK(hipMemcpy(k.slab, hostIn.data() + 2 * zlo[r] * ny * nx, slabElems * 8, hipMemcpyHostToDevice));
 		else { std::vector<float> h(1 << 20); fill(h, r + 1); for (uint64_t off = 0; off < slabElems * 8; off += h.size() * 4) HIPOK(hipMemcpy((char*)k.slab + off, h.data(), std::min<uint64_t>(h.size() * 4, slabElems * 8 - off), hipMemcpyHostToDevice)); }
 		// local plans: (x, y) of the nzl owned planes in place; z lines of the [nz][nyl][nx] volume (axes 0 and 1 omitted)
 		{
@@ -133,44 +147,53 @@ static int run_slab(int g, const std::vector<int>& devs, uint64_t n, const std::
 			if (initializeVkFFT(&k.xy, c) != VKFFT_SUCCESS) fail.store(1);
 			VkFFTConfiguration d = {};
 			d.FFTdim = 3; d.size[0] = nx; d.size[1] = nyl; d.size[2] = nz; d.omitDimension[0] = 1; d.omitDimension[1] = 1; d.device = &k.hdev; d.stream = &k.st; d.num_streams = 1;
-			d.buffer = &k.recv; d.bufferSize = &bs;
+			uint64_t bz = yslabElems * 8; d.buffer = &k.recv; d.bufferSize = &bz;
 			if (initializeVkFFT(&k.z, d) != VKFFT_SUCCESS) fail.store(1);
 		}
 		bar.wait(); // every rank's buffers exist (the copy transport writes into peers' receive buffers)
-		auto exchange = [&](void* from, void* SlabRank::*to) {
-			// `from` holds [peer][nzl][nyl][nx]: block s goes to rank s, where it lands as block r
+		// element offsets of the block exchanged with peer s: in the layout of MY planes ([s][nzl][nyr[s]][nx]) and in the layout of MY rows ([s][nzr[s]][nyl][nx])
+		auto offPlanes = [&](int s) { return nzl * ylo[s] * nx; };
+		auto lenPlanes = [&](int s) { return nzl * nyr[s] * nx; };
+		auto offRows = [&](int s) { return zlo[s] * nyl * nx; };
+		auto lenRows = [&](int s) { return nzr[s] * nyl * nx; };
+		// forward: the blocks of my planes go out, the blocks of my rows come in; backward: the other way round
+		auto exchange = [&](void* from, void* SlabRank::*to, bool fwd) {
 			if (rccl) {
 				ncclGroupStart();
 				for (int s = 0; s < g; s++) {
-					ncclSend((const char*)from + (uint64_t)s * blockElems * 8, blockElems * 2, ncclFloat, s, k.comm, k.st);
-					ncclRecv((char*)(k.*to) + (uint64_t)s * blockElems * 8, blockElems * 2, ncclFloat, s, k.comm, k.st);
+					ncclSend((const char*)from + (fwd ? offPlanes(s) : offRows(s)) * 8, (fwd ? lenPlanes(s) : lenRows(s)) * 2, ncclFloat, s, k.comm, k.st);
+					ncclRecv((char*)(k.*to) + (fwd ? offRows(s) : offPlanes(s)) * 8, (fwd ? lenRows(s) : lenPlanes(s)) * 2, ncclFloat, s, k.comm, k.st);
 				}
 				if (ncclGroupEnd() != ncclSuccess) fail.store(1);
 			} else {
 				HIPOK(hipStreamSynchronize(k.st)); bar.wait(); // everybody's send layout is complete
-				for (int s = 0; s < g; s++) HIPOK(hipMemcpyAsync((char*)(R[s].*to) + (uint64_t)r * blockElems * 8, (const char*)from + (uint64_t)s * blockElems * 8, blockElems * 8, hipMemcpyDeviceToDevice, k.st));
+				for (int s = 0; s < g; s++) {
+					// my block for peer s lands in peer s's buffer where ITS layout expects the block of peer r (= me)
+					const uint64_t dstOff = fwd ? zlo[r] * nyr[s] * nx : nzr[s] * ylo[r] * nx;
+					HIPOK(hipMemcpyAsync((char*)(R[s].*to) + dstOff * 8, (const char*)from + (fwd ? offPlanes(s) : offRows(s)) * 8, (fwd ? lenPlanes(s) : lenRows(s)) * 8, hipMemcpyDeviceToDevice, k.st));
+				}
 				HIPOK(hipStreamSynchronize(k.st)); bar.wait(); // everything has arrived
 			}
 		};
 		VkFFTLaunchParams lp = {};
 		auto forward = [&]() {
 			if (VkFFTAppend(&k.xy, -1, &lp) != VKFFT_SUCCESS) fail.store(1);
-			// pack: [z][y][x] -> [peer][z][y in block][x]: per peer one strided copy (rows of nyl*nx complex, pitch ny*nx)
+			// pack: [z][y][x] -> [peer][z][y in block][x]: per peer one strided copy (rows of nyr[s]*nx complex, pitch ny*nx)
 			for (int s = 0; s < g; s++)
-				HIPOK(hipMemcpy2DAsync((char*)k.send + (uint64_t)s * blockElems * 8, nyl * nx * 8, (const char*)k.slab + (uint64_t)s * nyl * nx * 8, ny * nx * 8, nyl * nx * 8, nzl, hipMemcpyDeviceToDevice, k.st));
-			exchange(k.send, &SlabRank::recv); // recv = [s][nzl][nyl][nx] = [nz][nyl][nx]
+				HIPOK(hipMemcpy2DAsync((char*)k.send + offPlanes(s) * 8, nyr[s] * nx * 8, (const char*)k.slab + ylo[s] * nx * 8, ny * nx * 8, nyr[s] * nx * 8, nzl, hipMemcpyDeviceToDevice, k.st));
+			exchange(k.send, &SlabRank::recv, true); // recv = [s][nzr[s]][nyl][nx] = [nz][nyl][nx]
 			if (VkFFTAppend(&k.z, -1, &lp) != VKFFT_SUCCESS) fail.store(1);
 		};
 		auto inverse = [&]() {
 			if (VkFFTAppend(&k.z, 1, &lp) != VKFFT_SUCCESS) fail.store(1);
-			exchange(k.recv, &SlabRank::send); // z-block s of the y-slab goes back to rank s: send = [peer][nzl][nyl][nx]
+			exchange(k.recv, &SlabRank::send, false); // z-block s of the y-slab goes back to rank s: send = [peer][nzl][nyr[peer]][nx]
 			for (int s = 0; s < g; s++)
-				HIPOK(hipMemcpy2DAsync((char*)k.slab + (uint64_t)s * nyl * nx * 8, ny * nx * 8, (const char*)k.send + (uint64_t)s * blockElems * 8, nyl * nx * 8, nyl * nx * 8, nzl, hipMemcpyDeviceToDevice, k.st));
+				HIPOK(hipMemcpy2DAsync((char*)k.slab + ylo[s] * nx * 8, ny * nx * 8, (const char*)k.send + offPlanes(s) * 8, nyr[s] * nx * 8, nyr[s] * nx * 8, nzl, hipMemcpyDeviceToDevice, k.st));
 			if (VkFFTAppend(&k.xy, 1, &lp) != VKFFT_SUCCESS) fail.store(1);
 		};
 		if (!fail.load()) forward();
 		HIPOK(hipStreamSynchronize(k.st));
-		if (verify) HIPOK(hipMemcpy(hostOut.data() + 2 * (uint64_t)r * blockElems * g, k.recv, slabElems * 8, hipMemcpyDeviceToHost)); // y-slab r: [nz][nyl][nx]
+		if (verify) HIPOK(hipMemcpy(hostOut.data() + 2 * nz * ylo[r] * nx, k.recv, yslabElems * 8, hipMemcpyDeviceToHost)); // y-slab r: [nz][nyl][nx], slabs one after the other
 		if (!fail.load()) inverse();
 		HIPOK(hipStreamSynchronize(k.st));
 		bar.wait();
@@ -199,9 +222,9 @@ static int run_slab(int g, const std::vector<int>& devs, uint64_t n, const std::
 				std::vector<float> ref(hostIn.size());
 				hipMemcpy(ref.data(), vol, bytes, hipMemcpyDeviceToHost);
 				double num = 0, den = 0;
-				for (int r = 0; r < g; r++) for (uint64_t zz = 0; zz < nz; zz++) for (uint64_t yy = 0; yy < nyl; yy++) for (uint64_t xx = 0; xx < 2 * nx; xx++) {
-					const double a1 = hostOut[2 * (uint64_t)r * blockElems * g + (zz * nyl + yy) * 2 * nx + xx];
-					const double b1 = ref[(zz * ny + (uint64_t)r * nyl + yy) * 2 * nx + xx];
+				for (int r = 0; r < g; r++) for (uint64_t zz = 0; zz < nz; zz++) for (uint64_t yy = 0; yy < nyr[r]; yy++) for (uint64_t xx = 0; xx < 2 * nx; xx++) {
+					const double a1 = hostOut[2 * nz * ylo[r] * nx + (zz * nyr[r] + yy) * 2 * nx + xx];
+					const double b1 = ref[(zz * ny + ylo[r] + yy) * 2 * nx + xx];
 					num += (a1 - b1) * (a1 - b1); den += b1 * b1;
 				}
 				err = std::sqrt(num / den);
@@ -217,7 +240,7 @@ static int run_slab(int g, const std::vector<int>& devs, uint64_t n, const std::
 	const double pts = (double)nx * ny * nz, gflops = 2.0 * 5.0 * pts * std::log2(pts) / (worst * 1e-3) / 1e9;
 	char errs[32]; if (err < 0) snprintf(errs, sizeof(errs), "null"); else snprintf(errs, sizeof(errs), "%.3e", err);
 	printf("{\"driver\": \"slab_3d_c2c\", \"ranks\": %d, \"n\": %llu, \"transport\": \"%s\", \"pair_message_MiB\": %.2f, \"fwd_inv_ms\": %.4f, \"GFLOPs\": %.1f, \"rel_l2_vs_single_device_plan\": %s}\n",
-	       g, (unsigned long long)n, transport.c_str(), blockElems * 8 / 1048576.0, worst, gflops, errs);
+	       g, (unsigned long long)n, transport.c_str(), maxBlock * 8 / 1048576.0, worst, gflops, errs);
 	return (verify && !(err >= 0 && err < 2e-6)) ? 1 : 0;
 }
 
