@@ -531,3 +531,32 @@ def test_real_rows_with_the_maps_inside_the_stages(run, oracle, N, dp):
     side of the even split; full-length real forms of odd lengths: real in, N/2 + 1 bins out, Hermitian half in, real parts out) run inside the first /
     last stage instead of a staging pass (kernel_mixed.h, `DIRECT`); several rows so that the last workgroup is partly filled"""
     parity.check_r2c(run, oracle, (N,), 7, dp)
+
+
+@pytest.mark.parametrize("shape,pad", [((2670,), 6), ((296, 5), 3), ((74, 4, 3), 1), ((889,), 0)])
+def test_rader_stage_rows_with_padded_pitch_out_of_place_and_as_an_axis(emu_lib, monkeypatch, shape, pad):
+    """the Rader-stage kernel as axis 0 of 1-D ... 3-D plans: padded row pitch, a separate formatted input buffer that must stay untouched, forward and the
+    normalised inverse back into place"""
+    monkeypatch.setenv("VKFFT_MI355X_MIXRAD", "2")
+    nd = len(shape); B = 3
+    pitches, acc = [], 1
+    for s in shape:
+        acc = acc * s + pad
+        pitches.append(acc)
+    total = pitches[-1] * B
+    rng = np.random.default_rng(sum(shape))
+    src = (rng.uniform(-1, 1, total) + 1j * rng.uniform(-1, 1, total)).astype(np.complex64)
+    orig = src.copy()
+    strides = [pitches[-1]] + [pitches[i - 1] if i > 0 else 1 for i in range(nd - 1, -1, -1)]
+    idx = np.indices([B] + list(shape)[::-1]).reshape(nd + 1, -1)
+    off = sum(idx[d] * strides[d] for d in range(nd + 1))
+    view = lambda a: a[off].reshape([B] + list(shape)[::-1]).astype(np.complex128)
+    dst = np.zeros(total, np.complex64)
+    app = api.App(list(shape), B, buffer_ptr=dst.ctypes.data, isInputFormatted=1, inputBuffer=src.ctypes.data, inputBufferStride=pitches + [0] * (4 - nd),
+                  bufferStride=pitches + [0] * (4 - nd), normalize=True, lib=emu_lib)
+    app.forward()
+    assert rel_l2(view(dst), np.fft.fftn(view(orig), axes=tuple(range(1, nd + 1)))) < 5e-6
+    assert np.array_equal(src, orig)
+    app.inverse()
+    app.delete()
+    assert rel_l2(view(dst), view(orig)) < 8e-6

@@ -61,18 +61,24 @@ template <int M, typename T> __host__ __device__ inline void mixrad_dft(cx<T>* v
 	else dft<M, T>(v); // 2 ... 10, 12, 14, 15, 16, 25, 32
 }
 // step 3 for a compile-time cofactor
+// Source: sub-sequence b of row r at rowbuf + r * rowPitch + b * SUBS (SUBS = P: the tile of whole rows; SUBS = the buffer pitch of a thread group: every group
+// holds one sub-sequence, whose bin 0 lives in dc[r * M + b] as in the prime's own Rader kernel).
 // toLds != nullptr (real transforms between the generic maps): the columns go to a second row region in natural order instead of global memory
-template <typename T, int M, int P, int NT>
-__device__ inline void mixrad_columns(const cx<T>* rowbuf, const uint32_t N, const uint32_t rowsHere, const GBuf gout, const GBuf gtw, const uint32_t outRowBytes,
-                                      const bool swO, const T sc, const uint32_t tid, cx<T>* toLds) {
+template <typename T, int M, int P, int NT, int SUBS>
+__device__ inline void mixrad_columns(const cx<T>* rowbuf, const uint32_t rowPitch, const cx<T>* dc, const uint32_t N, const uint32_t rowsHere, const GBuf gout, const GBuf gtw,
+                                      const uint32_t outRowBytes, const bool swO, const T sc, const uint32_t tid, cx<T>* toLds) {
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	const uint32_t total = rowsHere * (uint32_t)P;
 	for (uint32_t j = tid; j < total; j += (uint32_t)NT) {
 		const uint32_t r = j / (uint32_t)P, k2 = j % (uint32_t)P;
-		const cx<T>* const src = rowbuf + r * N + k2;
+		const cx<T>* const src = rowbuf + r * rowPitch + k2;
 		cx<T> y[M];
 #pragma unroll
-		for (int b = 0; b < M; b++) y[b] = src[b * P];
+		for (int b = 0; b < M; b++) y[b] = src[b * SUBS];
+		if (dc && k2 == 0u) {
+#pragma unroll
+			for (int b = 0; b < M; b++) y[b] = dc[r * (uint32_t)M + b];
+		}
 		constexpr int TWG = 8; // twiddles in flight at a time (the butterfly of a large cofactor needs the registers)
 #pragma unroll
 		for (int b0 = 1; b0 < M; b0 += TWG) {
@@ -102,14 +108,13 @@ __device__ inline void mixrad_columns(const cx<T>* rowbuf, const uint32_t N, con
 
 // lut = stage twiddles of SCH (length P - 1); rader = uint32 g^a mod P (a < L) followed by g^-k mod P; aux2 = FFT of the Rader kernel / L (L entries)
 // followed by the column twiddles W_N^(b k2), (b - 1) * P + k2, b = 1 ... M - 1; raderM = M.
-// Tiles: forceT = rows per workgroup = mixrad_rows(P, FPW, N): as many rows as the tile's LDS holds (the thread groups take their sub-sequences in rounds).
-// MHI: which cofactors the instance serves — 0: 2 ... 10 (a thread's butterfly is small: 64 registers, eight waves per SIMD), 1: 12 ... 32.
-template <typename T, typename SCH, int TPF, int FPW, int MHI>
+// Tiles: forceT = rows per workgroup = mixrad_rows(2, ...): as many rows as the tile's LDS holds (the thread groups take their sub-sequences in rounds).
+template <typename T, typename SCH, int TPF, int FPW>
 __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	constexpr int L = SCH::N, P = L + 1, NT = TPF * FPW;
 	constexpr int EXPF = SCH::NS > 1 ? MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems() : 1;
 	constexpr int EX = (EXPF > L ? EXPF : L) | 1;                     // per thread group: exchange buffer of the stages = carrier of the spectrum between the two transforms
-	constexpr int ROWN = (int)mixrad_row_elems(P, FPW, sizeof(T) == 8, MHI != 0); // rows of the tile, sub-sequence-major
+	constexpr int ROWN = (int)mixrad_row_elems(P, FPW); // rows of the tile, sub-sequence-major
 	constexpr bool waveOnly = (TPF <= 64) && (64 % TPF == 0);
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	static_assert((size_t)(FPW * EX + ROWN) * sizeof(cx<T>) <= 160 * 1024, "LDS");
@@ -123,7 +128,7 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	FastDiv divN, divM; // (by the row length and by the cofactor: run-time values of this kernel, not the pass's own dividers, which the generic maps use)
 	divN.d = N; divN.rcp = 1.0f / (float)N; divM.d = M; divM.rcp = 1.0f / (float)M;
 	const bool ops = p.preOp != OP_NONE || p.postOp != OP_NONE;
-	const uint32_t RW = mixrad_rows(P, FPW, sizeof(T) == 8, N, M, ops);
+	const uint32_t RW = mixrad_rows(2, P, FPW, M, ops);
 	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
@@ -183,19 +188,13 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	const uint32_t outRowBytes = (uint32_t)p.dim[0].outStride * ES;
 	const T sc = (T)p.scale;
 	cx<T>* const natural = ops ? rowbuf + ROWN / 2 : nullptr; // (the rows of an OPS tile fill at most half the region: mixrad_rows)
-#define VKFFT_MIXRAD_CASE(m) case m: mixrad_columns<T, m, P, NT>(rowbuf, N, rowsHere, gout, gtw, outRowBytes, swO, sc, tid, natural); break;
-	if constexpr (MHI == 0) {
-		switch (M) {
-		VKFFT_MIXRAD_CASE(2) VKFFT_MIXRAD_CASE(3) VKFFT_MIXRAD_CASE(4) VKFFT_MIXRAD_CASE(5) VKFFT_MIXRAD_CASE(6) VKFFT_MIXRAD_CASE(7) VKFFT_MIXRAD_CASE(8)
-		VKFFT_MIXRAD_CASE(9) VKFFT_MIXRAD_CASE(10)
-		default: break;
-		}
-	} else {
-		switch (M) {
-		VKFFT_MIXRAD_CASE(12) VKFFT_MIXRAD_CASE(14) VKFFT_MIXRAD_CASE(15) VKFFT_MIXRAD_CASE(16) VKFFT_MIXRAD_CASE(18) VKFFT_MIXRAD_CASE(20) VKFFT_MIXRAD_CASE(21)
-		VKFFT_MIXRAD_CASE(24) VKFFT_MIXRAD_CASE(25) VKFFT_MIXRAD_CASE(27) VKFFT_MIXRAD_CASE(28) VKFFT_MIXRAD_CASE(30) VKFFT_MIXRAD_CASE(32)
-		default: break;
-		}
+#define VKFFT_MIXRAD_CASE(m) case m: mixrad_columns<T, m, P, NT, P>(rowbuf, N, (const cx<T>*)nullptr, N, rowsHere, gout, gtw, outRowBytes, swO, sc, tid, natural); break;
+	switch (M) {
+	VKFFT_MIXRAD_CASE(2) VKFFT_MIXRAD_CASE(3) VKFFT_MIXRAD_CASE(4) VKFFT_MIXRAD_CASE(5) VKFFT_MIXRAD_CASE(6) VKFFT_MIXRAD_CASE(7) VKFFT_MIXRAD_CASE(8)
+	VKFFT_MIXRAD_CASE(9) VKFFT_MIXRAD_CASE(10) VKFFT_MIXRAD_CASE(12) VKFFT_MIXRAD_CASE(14) VKFFT_MIXRAD_CASE(15) VKFFT_MIXRAD_CASE(16) VKFFT_MIXRAD_CASE(18)
+	VKFFT_MIXRAD_CASE(20) VKFFT_MIXRAD_CASE(21) VKFFT_MIXRAD_CASE(24) VKFFT_MIXRAD_CASE(25) VKFFT_MIXRAD_CASE(27) VKFFT_MIXRAD_CASE(28) VKFFT_MIXRAD_CASE(30)
+	VKFFT_MIXRAD_CASE(32)
+	default: break;
 	}
 #undef VKFFT_MIXRAD_CASE
 	if (ops) {
@@ -203,17 +202,89 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 		dispatch_post_op(p.postOp, [&](auto opc) { ops_rows_out<T>(p, opc, natural, (const cx<T>*)nullptr, N, RW, rowsHere, rowOut0, nat0); });
 	}
 }
-template <typename T, typename SCH, int TPF, int FPW> void mixrad_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
-	constexpr int P = SCH::N + 1, NMAX = sizeof(T) == 4 ? 4096 : 2048;
-	if (prm.raderM <= 10) hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, 0>), grid, dim3(TPF * FPW), 0, s, prm);
-	else if constexpr (12 * P <= NMAX) hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, 1>), grid, dim3(TPF * FPW), 0, s, prm); // (a cofactor of 12 or more fits the longest row)
-}
-// the composite form exists for the fp32 Rader ROW instances whose prime leaves room for a cofactor (2 P <= the longest row) and whose tile fits the LDS
-template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> constexpr auto mixrad_ptr() -> void (*)(const PassParams&, dim3, hipStream_t) {
-	constexpr int P = SCH::N + 1, NMAX = sizeof(T) == 4 ? 4096 : 2048;
+// ---- cofactors up to 10 that fit the thread groups of the prime's instance, complex rows: every thread group owns ONE sub-sequence in ONE buffer — exchange
+// buffer of the stages, carrier of the spectrum and the sub-sequence itself, exactly as a row of the prime's own Rader kernel (kernel_mixconv.h) — so the LDS
+// and the occupancy are those of that kernel (a separate tile of rows halves them: 74 = 2 * 37 ran at 2.8 TB/s against 4.3 for the prime itself).
+// forceT = rows per workgroup = FPW / M.
+template <typename T, typename SCH, int TPF, int FPW>
+__global__ void __launch_bounds__(TPF * FPW) mixrad_small_kernel(const PassParams p) {
+	constexpr int L = SCH::N, P = L + 1, NT = TPF * FPW;
 	constexpr int EXPF = SCH::NS > 1 ? MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems() : 1;
-	constexpr int EX = (EXPF > SCH::N ? EXPF : SCH::N) | 1, ROWN = (int)mixrad_row_elems(P, FPW, sizeof(T) == 8, true);
-	if constexpr (RADER != 0 && COL == 0 && sizeof(T) == 4 && 2 * P <= NMAX && (size_t)(FPW * EX + ROWN) * sizeof(cx<T>) <= 160 * 1024) return &mixrad_launch<T, SCH, TPF, FPW>;
+	constexpr int SP = (EXPF > P ? EXPF : P) | 1;
+	constexpr bool waveOnly = (TPF <= 64) && (64 % TPF == 0);
+	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
+	__shared__ cx<T> lds[FPW * SP];
+	__shared__ cx<T> sDc[FPW];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t f = tid / TPF, tau = tid % TPF;
+	const uint32_t M = p.raderM, N = M * (uint32_t)P;
+	FastDiv divN, divM;
+	divN.d = N; divN.rcp = 1.0f / (float)N; divM.d = M; divM.rcp = 1.0f / (float)M;
+	const uint32_t RW = (uint32_t)FPW / M;
+	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+	const uint32_t tile = wg % p.tilesPerG0;
+	wg /= p.tilesPerG0;
+	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
+	const uint32_t f0 = tile * RW;
+	const uint32_t rowsHere = p.dim[0].count - f0 < RW ? p.dim[0].count - f0 : RW;
+	const GBuf gin = make_gbuf((const cx<T>*)p.in + ((int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride));
+	const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride));
+	const GBuf glut = make_gbuf(p.lut), gbh = make_gbuf(p.aux2), gtw = make_gbuf((const cx<T>*)p.aux2 + L);
+	const bool swI = p.bluesteinSwapIn != 0, swO = p.bluesteinSwapOut != 0;
+	// ---- 1. rows -> the groups' buffers: element M a + b of row r is element a of group r * M + b
+	{
+		const uint32_t inRowBytes = (uint32_t)p.dim[0].inStride * ES;
+		for (uint32_t e = tid; e < rowsHere * N; e += (uint32_t)NT) {
+			uint32_t r, n, a, b;
+			divN.divmod(e, r, n);
+			divM.divmod(n, a, b);
+			const cx<T> v = gb_load<T>(gin, r * inRowBytes + n * ES, 0);
+			lds[(r * M + b) * (uint32_t)SP + a] = swI ? cswap(v) : v;
+		}
+	}
+	VKFFT_SYNC();
+	// ---- 2. the Rader convolution of the group's sub-sequence, in its buffer (the flow of mixconv_kernel<RADER = 1>)
+	{
+		const uint32_t* const gp = (const uint32_t*)p.rader;
+		cx<T>* const row = lds + f * SP;
+		const bool live = f < rowsHere * M;
+		const cx<T> x0 = row[0];
+		auto fsync = [&]() { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); };
+		mc_stage<T, SCH, 0, TPF, 1, true, true, true>(row, glut, tau, waveOnly, [&](uint32_t t, uint32_t c) -> cx<T> { return live ? row[gp[t + c]] : cx<T>{(T)0, (T)0}; },
+		                                               [&](uint32_t t, uint32_t c, cx<T> v) {
+			                                               const uint32_t k = t + c;
+			                                               cx<T> w = cmul(v, gb_load<T>(gbh, t * ES, c * ES));
+			                                               if (k == 0u) { sDc[f] = cadd(x0, v); w = cadd(w, x0); } // X[0] = x0 + sum of the others
+			                                               row[k] = cswap(w);
+		                                               });
+		fsync();
+		mc_stage<T, SCH, 0, TPF, 1, true, true, true>(row, glut, tau, waveOnly, [&](uint32_t t, uint32_t c) -> cx<T> { return row[t + c]; },
+		                                               [&](uint32_t t, uint32_t c, cx<T> v) { row[gp[(uint32_t)L + t + c]] = cswap(v); });
+	}
+	VKFFT_SYNC();
+	// ---- 3. column twiddle, M-point butterfly, coalesced stores
+	const uint32_t outRowBytes = (uint32_t)p.dim[0].outStride * ES;
+	const T sc = (T)p.scale;
+#define VKFFT_MIXRAD_CASE(m) case m: mixrad_columns<T, m, P, NT, SP>(lds, M * (uint32_t)SP, sDc, N, rowsHere, gout, gtw, outRowBytes, swO, sc, tid, (cx<T>*)nullptr); break;
+	switch (M) {
+	VKFFT_MIXRAD_CASE(2) VKFFT_MIXRAD_CASE(3) VKFFT_MIXRAD_CASE(4) VKFFT_MIXRAD_CASE(5) VKFFT_MIXRAD_CASE(6) VKFFT_MIXRAD_CASE(7) VKFFT_MIXRAD_CASE(8)
+	VKFFT_MIXRAD_CASE(9) VKFFT_MIXRAD_CASE(10)
+	default: break;
+	}
+#undef VKFFT_MIXRAD_CASE
+}
+
+template <typename T, typename SCH, int TPF, int FPW> void mixrad_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
+	constexpr int P = SCH::N + 1;
+	const bool ops = prm.preOp != OP_NONE || prm.postOp != OP_NONE;
+	const int mode = mixrad_mode((uint32_t)P, (uint32_t)FPW, prm.raderM, ops);
+	if (mode == 1) hipLaunchKernelGGL((mixrad_small_kernel<T, SCH, TPF, FPW>), grid, dim3(TPF * FPW), 0, s, prm);
+	else if constexpr (12 * P <= (int)kMixradLongest) { if (mode == 2) hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW>), grid, dim3(TPF * FPW), 0, s, prm); }
+}
+// the composite forms exist for the fp32 Rader ROW instances whose prime leaves room for a cofactor (2 P <= the longest row)
+template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> constexpr auto mixrad_ptr() -> void (*)(const PassParams&, dim3, hipStream_t) {
+	constexpr int P = SCH::N + 1;
+	if constexpr (RADER != 0 && COL == 0 && sizeof(T) == 4 && 2 * P <= (int)kMixradLongest) return &mixrad_launch<T, SCH, TPF, FPW>;
 	else return nullptr;
 }
 

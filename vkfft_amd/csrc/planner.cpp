@@ -279,8 +279,9 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 				for (uint64_t q = 2; q * q <= rest; q++) while (rest % q == 0) { P = q; rest /= q; }
 				if (rest > 1) P = rest;
 				const uint64_t M = P ? b.L / P : 0;
-				if (P < 37 || !mixrad_cofactor_ok((uint32_t)M) || !mixconv_lookup(true, false, P, b.dp, &variant, &len, rad5, &fpw, &thr) || !mixrad_available(variant) ||
-				    !mixrad_fits((uint32_t)P, (uint32_t)fpw, b.dp, (uint32_t)b.L, (uint32_t)M, true)) return false;
+				if (P < 37 || !mixrad_cofactor_ok((uint32_t)M) || !mixconv_lookup(true, false, P, b.dp, &variant, &len, rad5, &fpw, &thr) || !mixrad_available(variant)) return false;
+				const int mode = mixrad_mode((uint32_t)P, (uint32_t)fpw, (uint32_t)M, true);
+				if (!mixrad_fits(mode, (uint32_t)P, (uint32_t)fpw, (uint32_t)M, true)) return false;
 				const uint64_t N = b.L;
 				if (!b.inLen) b.inLen = (uint32_t)N;
 				if (!b.outLen) b.outLen = (uint32_t)N;
@@ -290,7 +291,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 				b.auxOff2ForPre = bhatOff;
 				b.L = len; b.raderM = (uint32_t)M;
 				b.fastKernel = KERNEL_MIXCONV; b.fastVariant = variant; b.fastThreads = thr;
-				b.forceT = mixrad_rows((uint32_t)P, (uint32_t)fpw, b.dp, (uint32_t)N, (uint32_t)M, true);
+				b.forceT = mixrad_rows(mode, (uint32_t)P, (uint32_t)fpw, (uint32_t)M, true);
 				for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
 				return true;
 			}()) {
@@ -1038,17 +1039,25 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		const uint64_t M = P ? j.N / P : 0;
 		int v, r5[5], f, t; uint64_t len;
 		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
-		// taken where it was measured faster than the fused Bluestein kernel on the next power of two >= 2N - 1 (profiles/r04_all_lengths_2_320_*, r04_sample1000_*:
-		// 1.2-1.8x for primes up to 97 when the padding is 2.5x or more — 129 ... 200, 258 ... 400, 2670 —, 0.4-0.9x for the larger primes' instances and
-		// for lengths just below a power of two): a point costs 2.6 / 3.5 / 5 points of the padded power-of-two transform for P <= 100 / <= 130 / beyond
+		// taken where it was measured faster than the fused Bluestein kernel on the next power of two M2 >= 2N - 1 (profiles/r04_rader_stage_*.jsonl: every served
+		// length forced either way).  A point of the row costs c points of the padded power-of-two transform: the one-buffer kernel for cofactors up to 10
+		// c = 2 (74 ... 2570: 1.1-2.3x Bluestein wherever the padding is 2x or more; 0.9x at 122, 123, 254 right below a power of two), 3 where the prime's
+		// own convolution has a radix-13 stage (131, 157, 313, 521, 677: 939 = 3 * 313 and 1563 = 3 * 521 0.75x); the tiled kernel for the larger
+		// cofactors 3.4 and 5.7 (2670 1.7x, 3232 1.1x; 2020, 2032, 3144 0.6-0.7x).  Bluestein's 8192-point rows leave one workgroup per CU: 1.5 per point.
 		uint64_t M2 = 64; while (M2 < 2 * j.N - 1) M2 *= 2;
-		const double radCost = (P <= 100 ? 2.6 : P <= 130 ? 3.5 : 5.0) * (double)j.N;
 		const bool radForced = getenv("VKFFT_MI355X_MIXRAD") && atoi(getenv("VKFFT_MI355X_MIXRAD")) == 2; // (tests: always)
-		if (P >= 37 && (radForced || radCost < (double)M2) && mixrad_cofactor_ok((uint32_t)M) && (rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && mixconv_lookup(true, false, P, dp, &v, &len, r5, &f, &t) && mixrad_available(v)) {
+		bool radTake = P >= 37 && mixrad_cofactor_ok((uint32_t)M) && (rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && mixconv_lookup(true, false, P, dp, &v, &len, r5, &f, &t) && mixrad_available(v);
+		if (radTake) {
+			const int mode = mixrad_mode((uint32_t)P, (uint32_t)f, (uint32_t)M, false);
+			const bool slowRadix = (P - 1) % 13 == 0;
+			const double c = mode == 1 ? (slowRadix ? 3.0 : 2.0) : (slowRadix ? 5.7 : 3.4);
+			radTake = mixrad_fits(mode, (uint32_t)P, (uint32_t)f, (uint32_t)M, false) && (radForced || c * (double)j.N < (double)M2 * (M2 >= 8192 ? 1.5 : 1.0));
+		}
+		if (radTake) {
 			b.L = len; b.inLen = b.outLen = (uint32_t)j.N; b.opN = (uint32_t)j.N;
 			for (int k = 0; k < 5; k++) if (r5[k] > 1) b.radices.push_back((uint32_t)r5[k]);
 			b.fastKernel = KERNEL_MIXCONV; b.fastVariant = v; b.fastThreads = t;
-			b.forceT = mixrad_rows((uint32_t)P, (uint32_t)f, dp, (uint32_t)j.N, (uint32_t)M, false); // rows per workgroup (what the tile's LDS holds)
+			b.forceT = mixrad_rows(mixrad_mode((uint32_t)P, (uint32_t)f, (uint32_t)M, false), (uint32_t)P, (uint32_t)f, (uint32_t)M, false); // rows per workgroup
 			b.raderM = (uint32_t)M;
 			b.bsSwapIn = b.bsSwapOut = j.inverse; b.scale = j.scale;
 			b.inStrideJ = j.inStrideJ; b.outStrideJ = j.outStrideJ; b.dims = j.others;
