@@ -348,4 +348,16 @@ ZEROPAD_SEMANTICS_CASES = [
     dict(shape=(30, 16, 4), pads={0: (10, 20), 2: (2, 4)}, r2c=True, dp=True),
     dict(shape=(128,), pads={0: (64, 128)}, r2c=True),
     dict(shape=(45,), pads={0: (20, 45)}, r2c=True),                                  # odd rows: the full-length form, masks in real elements
+    # round 4: masks inside the one-pass Bluestein / Rader kernels and on plans of several passes (the zero-fill fallback is gone from these axes: a
+    # separate input buffer, which the fallback cannot serve, plans and stays bit-identical)
+    dict(shape=(47,), pads={0: (20, 47)}),                                            # fused Bluestein row kernel (pow2_blue_kernel)
+    dict(shape=(1046,), pads={0: (523, 1046)}, dp=True),
+    dict(shape=(37,), pads={0: (5, 30)}),                                             # Rader row (mixconv_kernel)
+    dict(shape=(74,), pads={0: (37, 74)}),                                            # 2 * 37: the Rader-stage kernel has no masks, the Bluestein kernel takes it
+    dict(shape=(547,), pads={0: (300, 547)}),
+    dict(shape=(16, 47), pads={0: (8, 16), 1: (20, 47)}),                             # strided axis: column Bluestein tiles (pow2_col_blue_kernel)
+    dict(shape=(8, 37, 3), pads={1: (17, 37)}),                                       # strided axis: Rader column tiles
+    dict(shape=(1 << 16,), pads={0: (1 << 15, 1 << 16)}),                             # two passes (the fused Four-Step kernel has no masks: separate passes)
+    dict(shape=(1 << 16,), pads={0: (1 << 14, 3 << 14)}),                             # an inner aligned range
+    dict(shape=(1 << 14, 4), pads={0: (1 << 13, 1 << 14), 1: (2, 4)}, dp=True),
 ]

@@ -560,3 +560,66 @@ def test_rader_stage_rows_with_padded_pitch_out_of_place_and_as_an_axis(emu_lib,
     app.inverse()
     app.delete()
     assert rel_l2(view(dst), view(orig)) < 8e-6
+
+
+ODD_DCT4 = [((3,), 4), ((5,), 4), ((9,), 3), ((15,), 3), ((45,), 3), ((105,), 2), ((37,), 3), ((47,), 3), ((111,), 3), ((1125,), 2), ((1451,), 2), ((243,), 2),
+            ((24, 45), 1), ((24, 239), 1), ((35, 7, 3), 1), ((19683,), 1), ((10007,), 1)]
+
+
+@pytest.mark.parametrize("shape,b", ODD_DCT4)
+@pytest.mark.parametrize("dp", [False, True])
+def test_dct4_dst4_of_odd_length_in_the_same_length_form(run, oracle, shape, b, dp):
+    """DCT-IV / DST-IV of odd length: signed permutation -> N-point transform -> one rotation by a multiple of pi/4 per output (vkFFT_R2R.h:414-481,
+    922-972, 1032) on every path that can carry it: fused-map instances, instance transforms between the generic maps (mixed-radix, Rader, Rader stage),
+    fused Bluestein (47, 1451: 4096 points, not 8192), strided axes, maps as passes (239 strided, 10007), several passes (3^9)"""
+    if dp and shape in ((19683,), (10007,)):
+        pytest.skip("long rows: fp32 only here (emulator time)")
+    parity.check_r2r(run, oracle, shape, b, dp, 4, False)
+    parity.check_r2r(run, oracle, shape, b, dp, 4, True)
+
+
+def test_dct4_of_an_odd_prime_length_pads_to_the_same_length_bluestein(run):
+    """1451 reals: the fused Bluestein kernel on 4096 points (2 * 1451 - 1 <= 4096), one launch"""
+    x = np.zeros(1451 * 2, dtype=np.float32)
+    h, ptr = run._alloc(x)
+    app = api.App([1451], 2, buffer_ptr=ptr, lib=run.lib, dct=4)
+    try:
+        n, names = app.launch_info()
+        assert n == 1 and "pow2_blue_r2r" in names, (n, names)
+    finally:
+        app.delete()
+
+
+@pytest.mark.parametrize("N", [13, 31, 55, 91, 169, 385, 37, 61, 127, 111, 205])
+@pytest.mark.parametrize("batch", [1, 2, 7])
+def test_two_real_rows_per_transform(run, oracle, monkeypatch, N, batch):
+    """PassParams::pairRows (the reference's mergeSequencesR2C, vkFFT_SharedMemory.h:40): rows of the full-length real forms travel two per complex transform
+    between the generic maps; odd row counts; the same plans with one row per transform agree"""
+    parity.check_r2c(run, oracle, (N,), batch, False)
+    for type, dst in [(1, False), (2, False), (3, False), (4, False), (2, True), (3, True), (4, True), (1, True)]:
+        parity.check_r2r(run, oracle, (N,), batch, False, type, dst)
+    rng = np.random.default_rng(N)
+    x = rng.uniform(-1, 1, N * batch).astype(np.float32)
+    a = run.transform(x, (N,), batch, both=True, dct=3)
+    monkeypatch.setenv("VKFFT_MI355X_NO_ROW_PAIRS", "1")
+    b = run.transform(x, (N,), batch, both=True, dct=3)
+    assert rel_l2(a[0], b[0]) < 1e-6 and rel_l2(a[1], b[1]) < 1e-6
+    if batch > 1 and N in (169, 37, 111):
+        assert not np.array_equal(a[0], b[0])  # (the paired plan really is another computation)
+
+
+@pytest.mark.parametrize("N", [9, 15, 25, 45, 105])
+@pytest.mark.parametrize("dp", [False, True])
+def test_two_real_rows_per_transform_preferred_over_a_fused_map_instance(run, oracle, monkeypatch, N, dp):
+    monkeypatch.setenv("VKFFT_MI355X_PAIR_PREFER", "1")
+    parity.check_r2c(run, oracle, (N,), 5, dp)
+    for type, dst in [(2, False), (3, False), (4, False), (4, True)]:
+        parity.check_r2r(run, oracle, (N,), 5, dp, type, dst)
+
+
+@pytest.mark.parametrize("shape,pads", [((45,), {0: (20, 45)}), ((91,), {0: (40, 91)})])
+def test_two_real_rows_per_transform_with_zero_padding(run, shape, pads):
+    import convpad
+    res = convpad.zeropad_semantics_case(run, shape, pads, r2c=True)
+    for k, v in res.items():
+        assert (v is True) if isinstance(v, bool) else v < 3e-6, (k, res)

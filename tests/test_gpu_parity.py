@@ -1091,3 +1091,43 @@ def test_every_cyclic_convolution_table_entry(run, oracle, chunk, monkeypatch):
             reps = max(1, (1 << 20) // (batch * N))
             yb, _ = run.transform(np.tile(x, reps), shape, batch * reps)
             assert np.array_equal(yb.view(np.uint8), np.tile(y, reps).view(np.uint8)), (dp, rader, col, v)
+
+
+@pytest.mark.parametrize("shape,b", [((3,), 4), ((9,), 3), ((45,), 33), ((105,), 2), ((37,), 31), ((47,), 3), ((111,), 3), ((1125,), 40), ((1451,), 50), ((243,), 2), ((3125,), 5),
+                                     ((24, 45), 3), ((24, 239), 1), ((35, 7, 3), 5), ((19683,), 2), ((10007,), 3), ((4095,), 3), ((8191,), 2)])
+@pytest.mark.parametrize("dp", [False, True])
+def test_dct4_dst4_of_odd_length_in_the_same_length_form(run, oracle, shape, b, dp):
+    """DCT-IV / DST-IV of odd length on the device: the same-length form (vkFFT_R2R.h:414-481, 922-972, 1032) on every path that carries it"""
+    parity.check_r2r(run, oracle, shape, b, dp, 4, False)
+    parity.check_r2r(run, oracle, shape, b, dp, 4, True)
+
+
+PAIRED_ROW_LENGTHS = [13, 19, 31, 55, 85, 91, 121, 169, 385, 1001, 37, 61, 127, 257, 111, 205, 265, 1285]
+
+
+@pytest.mark.parametrize("N", PAIRED_ROW_LENGTHS)
+@pytest.mark.parametrize("batch", [1, 5, 4099])
+def test_two_real_rows_per_transform_on_device(run, oracle, monkeypatch, N, batch):
+    """PassParams::pairRows (the reference's mergeSequencesR2C, vkFFT_SharedMemory.h:40): R2C / C2R of odd length, DCT / DST-I, -II, -III and odd -IV rows
+    travel two per complex transform between the generic maps (mixed-radix, Rader and Rader-stage instances); odd row counts leave the last slot half empty;
+    against the oracle, and against the plan with one row per transform"""
+    if N % 2:
+        parity.check_r2c(run, oracle, (N,), batch, False)
+    types = [(1, False), (2, False), (3, False), (2, True), (3, True)] + ([(4, False), (4, True)] if N % 2 else [])
+    for type, dst in types:
+        parity.check_r2r(run, oracle, (N,), batch, False, type, dst)
+    rng = np.random.default_rng(N)
+    x = rng.uniform(-1, 1, N * batch).astype(np.float32)
+    a = run.transform(x, (N,), batch, both=True, dct=2)
+    monkeypatch.setenv("VKFFT_MI355X_NO_ROW_PAIRS", "1")
+    b = run.transform(x, (N,), batch, both=True, dct=2)
+    assert rel_l2(a[0], b[0]) < 1e-6 and rel_l2(a[1], b[1]) < 1e-6
+
+
+@pytest.mark.parametrize("N", [9, 15, 25, 45, 75, 105, 175, 225, 343])
+def test_two_real_rows_per_transform_preferred_over_a_fused_map_instance(run, oracle, monkeypatch, N):
+    """VKFFT_MI355X_PAIR_PREFER=1: lengths that also have a fused-map instance (kernel_opfft.h) take the paired form"""
+    monkeypatch.setenv("VKFFT_MI355X_PAIR_PREFER", "1")
+    parity.check_r2c(run, oracle, (N,), 7, False)
+    for type, dst in [(2, False), (3, False), (4, False), (4, True)]:
+        parity.check_r2r(run, oracle, (N,), 7, False, type, dst)

@@ -167,6 +167,7 @@ struct PassParams {
 	uint32_t colMerge;   // mixconv_kernel column tiles: the tile index runs over dim[0] x dim[1] (column g of a tile = (g % dim[0].count, g / dim[0].count)): no partly
 	                     // filled tiles when dim[0].count is not a multiple of the tile width (prime planes); tilesPerG0 then counts the tiles of both
 	uint32_t raderM;     // mixrad_kernel (kernel_mixrad.h): cofactor M of a row of M * P points, P the Rader prime of the instance (0 / 1: not that kernel)
+	uint32_t pairRows;   // instance kernels between the generic maps (OPS = 1): two real rows per complex transform (kernel_generic.h ops_rows_in / ops_rows_out)
 	uint32_t bigSpan;    // pow2_col_kernel: the tile spans 2 GiB or more on one side: 64-bit per-lane addresses instead of a buffer resource per tile
 	// merged convolution along this axis (pow2_col_blue_kernel MODE 6; reference vkFFT_Convolution.h:125): convCf coordinate systems convSysStride elements
 	// apart are transformed, multiplied per frequency by the convM x convM kernel matrix (convM <= 1: every coordinate by its own kernel component) and

@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 		io.outOff = valid ? f * (uint32_t)p.dim[0].outStride * p.outElemBytes : kGbInvalid;
 		io.inSj = (uint32_t)p.inStrideJ * p.inElemBytes;
 		io.outSj = (uint32_t)p.outStrideJ * p.outElemBytes;
+		io.set_pad(p);
 		const uint32_t nat = g0 * p.opStride0 + g1 * p.opStride1;
 		cx<T> v[E];
 #pragma unroll

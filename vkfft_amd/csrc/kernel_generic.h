@@ -183,6 +183,21 @@ __device__ inline cx<T> pre_gather(const PassParams& p, const IO& io, uint32_t p
 			T a = io.ldr(i0), b = io.ldr(i1);
 			return cmul(cx<T>{a, b}, ((const cx<T>*)(p.preNat ? p.aux3 : p.aux))[pos]);
 		}
+		if ((p.blueN ? p.blueN : p.L) == N) {
+			// odd N, same-length form (vkFFT_R2R.h:414-481, 922-972): with r = 2n + 1 the kernel cos(pi r u / 4N), u = 2k + 1, is even in r and changes sign
+			// under r -> r + 4N, so the row extends to every n; sampled at n = 4 i + (N - 1) / 2, i.e. r = 8 i + N, it is the real sequence whose
+			// N-point DFT Z gives y[k] = 2 Re(e^{-i pi u / 4} Z[u mod N]) — no zero padding, no twiddle table
+			if (pos >= N) return zero;
+			const uint32_t m = 4 * pos + (N >> 1);
+			uint32_t src; bool neg = false;
+			if (m < N) src = m;
+			else if (m < 2 * N) { src = 2 * N - 1 - m; neg = true; }
+			else if (m < 3 * N) { src = m - 2 * N; neg = true; }
+			else if (m < 4 * N) src = 4 * N - 1 - m;
+			else src = m - 4 * N;
+			const T a = io.ldr(dst ? N - 1 - src : src);
+			return {neg ? -a : a, (T)0};
+		}
 		if (pos >= N) return zero; // L = 2N, zero padded
 		T a = io.ldr(dst ? N - 1 - pos : pos);
 		return cscale(((const cx<T>*)(p.preNat ? p.aux3 : p.aux))[pos], a);
@@ -291,6 +306,12 @@ __device__ inline void post_store(const PassParams& p, const IO& io, uint32_t k,
 			const uint32_t m = (k & 1) ? (N - 1 - k) >> 1 : k >> 1;
 			cx<T> c = cmul(rd(m), ((const cx<T>*)p.aux2)[m]);
 			v = (k & 1) ? (T)-2 * c.y : (T)2 * c.x;
+		} else if ((p.blueN ? p.blueN : p.L) == N) { // odd N, same-length form: y[k] = 2 Re(e^{-i pi u / 4} Z[u mod N]), u = 2k + 1
+			const uint32_t u = 2 * k + 1;
+			const cx<T> z = rd(u < N ? u : u - N);
+			const uint32_t r8 = u & 7u;
+			const T c = (r8 == 1 || r8 == 7) ? z.x : -z.x, s = (r8 == 1 || r8 == 3) ? z.y : -z.y;
+			v = (T)1.41421356237309504880168872420969807856967 * (c + s);
 		} else {
 			cx<T> c = cmul(rd(k), ((const cx<T>*)p.aux2)[k]);
 			v = (T)2 * c.x;
@@ -341,6 +362,8 @@ __device__ inline void post_scatter(const PassParams& p, const IO& io, const uin
 		if ((p.blueN ? p.blueN : p.L) * 2 == N) { // half-length form: FFT output m feeds outputs 2m and N-1-2m
 			post_store<T>(p, io, 2 * a, colIdx, nat, rd, op);
 			post_store<T>(p, io, N - 1 - 2 * a, colIdx, nat, rd, op);
+		} else if ((p.blueN ? p.blueN : p.L) == N) { // odd N, same-length form: FFT output a is Z[u mod N] of the one output with 2k + 1 = a (mod N)
+			if (a < N) post_store<T>(p, io, (a & 1) ? (a - 1) >> 1 : (a + N - 1) >> 1, colIdx, nat, rd, op);
 		} else if (a < N) post_store<T>(p, io, a, colIdx, nat, rd, op);
 		return;
 	}
@@ -531,40 +554,69 @@ __device__ inline cx<T>* run_stage_rader_fft(const PassParams& p, const StageDes
 // R2C / DCT rows between the instance transforms took 2x the time of the complex transform of the same length).  The loops stay rolled: unrolled,
 // they are 4-9x the code of the transform they surround, once per kernel instance.
 // divN divides by the row length, rows of the tile at lds + fi * SP, natural order.
+// Two real rows per transform (PassParams::pairRows; the reference's mergeSequencesR2C: vkFFT_SharedMemory.h:40, vkFFT_R2C.h:178,450, vkFFT_R2R.h:2083,3663): where
+// the pre-map of a row is a REAL sequence (R2C of odd length, DCT / DST-I, -II, odd -IV in their full-length forms) rows 2f and 2f + 1 travel as real and
+// imaginary part of ONE complex row, z = a + i b, and the post-map reads the two spectra back through the even / odd split X_a[q] = (Z[q] + conj Z[L-q]) / 2,
+// X_b[q] = (Z[q] - conj Z[L-q]) / 2i.  Where the transform's RESULT is real (C2R of odd length, DCT / DST-III: Hermitian pre-maps) the same packing of the
+// pre-maps gives the two real rows as real and imaginary part of the result.  Half the transforms per row.  The second row is one more trip through the
+// SAME rolled loop body (one inlined copy of the map, as before).
+__host__ __device__ inline bool op_pair_result_is_real(uint32_t postOp) { return postOp == OP_C2R_FULL || postOp == OP_DCT3_POST || postOp == OP_DST3_POST; }
 template <typename T, typename OPC>
-// subM > 1: the row is stored sub-sequence-major (element M a + b at b * subP + a: kernel_mixrad.h)
+// subM > 1: the row is stored sub-sequence-major (element M a + b at b * subP + a: kernel_mixrad.h); nvalid counts ROWS (two per slot when paired)
 __device__ inline void ops_rows_in(const PassParams& p, OPC opc, const FastDiv divN, cx<T>* lds, uint32_t SP, uint32_t TOT, uint32_t nvalid, int64_t inBase, uint32_t nat0, uint32_t subM = 1, uint32_t subP = 0) {
 	const uint32_t tid = threadIdx.x, NT = blockDim.x;
 	const bool swI = p.swapIn != 0;
+	const uint32_t nh = p.pairRows ? 2u : 1u;
 #pragma unroll 1
 	for (uint32_t idx = tid; idx < TOT; idx += NT) {
 		uint32_t fi, pos;
 		divN.divmod(idx, fi, pos);
 		cx<T> v = {(T)0, (T)0};
-		if (fi < nvalid) {
-			Io64<T> io{p.in, p.out, inBase + (int64_t)fi * p.dim[0].inStride, 0, p.inStrideJ, p.outStrideJ};
-			io.set_pad(p);
-			v = pre_gather<T>(p, io, pos, nat0 + fi * p.opStride0, op_value(opc));
+#pragma unroll 1
+		for (uint32_t h = 0; h < nh; h++) {
+			const uint32_t row = fi * nh + h;
+			cx<T> a = {(T)0, (T)0};
+			if (row < nvalid) {
+				Io64<T> io{p.in, p.out, inBase + (int64_t)row * p.dim[0].inStride, 0, p.inStrideJ, p.outStrideJ};
+				io.set_pad(p);
+				a = pre_gather<T>(p, io, pos, nat0 + row * p.opStride0, op_value(opc));
+			}
+			v = h ? cx<T>{v.x - a.y, v.y + a.x} : a;
 		}
 		const uint32_t dst = subM > 1 ? (pos % subM) * subP + pos / subM : pos;
 		lds[fi * SP + dst] = swI ? cswap(v) : v;
 	}
 }
 // rows of the tile -> post-map -> global memory; fetch(fi, a) delivers element a of row fi (un-swapped); rows at lds + fi * SP unless `dc` (Rader: element 0 of a row lives in dc[fi])
+// Lc = length of the complex row (the mirror index of the paired split); nvalid counts ROWS
 template <typename T, typename OPC>
-__device__ inline void ops_rows_out(const PassParams& p, OPC opc, const cx<T>* lds, const cx<T>* dc, uint32_t SP, uint32_t FPW, uint32_t nvalid, int64_t outBase, uint32_t nat0) {
+__device__ inline void ops_rows_out(const PassParams& p, OPC opc, const cx<T>* lds, const cx<T>* dc, uint32_t SP, uint32_t FPW, uint32_t nvalid, int64_t outBase, uint32_t nat0, uint32_t Lc = 0) {
 	const uint32_t tid = threadIdx.x, NT = blockDim.x;
 	const uint32_t total = p.outLen * FPW;
 	const bool swO = p.swapOut != 0;
+	const uint32_t nh = p.pairRows ? 2u : 1u;
+	const bool realResult = op_pair_result_is_real(op_value(opc));
 #pragma unroll 1
 	for (uint32_t idx = tid; idx < total; idx += NT) {
 		uint32_t fi, k;
 		p.divOutLen.divmod(idx, fi, k);
-		if (fi >= nvalid) continue;
-		auto rd = [&](uint32_t a) -> cx<T> { const cx<T> v = (dc && a == 0u) ? dc[fi] : lds[fi * SP + a]; return swO ? cswap(v) : v; };
-		Io64<T> io{p.in, p.out, 0, outBase + (int64_t)fi * p.dim[0].outStride, p.inStrideJ, p.outStrideJ};
-		io.set_pad(p);
-		post_store<T>(p, io, k, 0u, nat0 + fi * p.opStride0, rd, op_value(opc));
+#pragma unroll 1
+		for (uint32_t h = 0; h < nh; h++) {
+			const uint32_t row = fi * nh + h;
+			if (row >= nvalid) break;
+			auto rd = [&](uint32_t a) -> cx<T> {
+				cx<T> v = (dc && a == 0u) ? dc[fi] : lds[fi * SP + a];
+				if (swO) v = cswap(v);
+				if (nh == 1u) return v;
+				if (realResult) return cx<T>{h ? v.y : v.x, (T)0};
+				cx<T> m = a == 0u ? v : lds[fi * SP + (Lc - a)];
+				if (swO && a != 0u) m = cswap(m);
+				return h ? cx<T>{(T)0.5 * (v.y + m.y), (T)0.5 * (m.x - v.x)} : cx<T>{(T)0.5 * (v.x + m.x), (T)0.5 * (v.y - m.y)};
+			};
+			Io64<T> io{p.in, p.out, 0, outBase + (int64_t)row * p.dim[0].outStride, p.inStrideJ, p.outStrideJ};
+			io.set_pad(p);
+			post_store<T>(p, io, k, 0u, nat0 + row * p.opStride0, rd, op_value(opc));
+		}
 	}
 }
 

@@ -52,7 +52,8 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 	wg /= p.tilesPerG0;
 	const bool merge = COL && p.colMerge != 0;
 	const uint32_t g1 = merge ? 0u : wg % p.dim[1].count, g2 = merge ? wg : wg / p.dim[1].count;
-	const uint32_t f0 = tile * FPW;
+	const uint32_t rowMult = (OPS != 0 && p.pairRows) ? 2u : 1u; // two real rows per transform (kernel_generic.h)
+	const uint32_t f0 = tile * FPW * rowMult;
 	const GBuf glut = make_gbuf(p.lut), gbh = make_gbuf(OPS ? p.aux3 : p.aux2);
 	// element j of this thread's transform: byte offset laneIn + j*sJin (rows: sJin = ES); guarded by `valid` at every use
 	const uint32_t sJin = COL ? (uint32_t)p.inStrideJ * ES : ES, sJout = COL ? (uint32_t)p.outStrideJ * ES : ES;
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 	if constexpr (RADER) {
 		constexpr uint32_t n = (uint32_t)L + 1u;
 		const uint32_t* const gp = (const uint32_t*)p.rader;
-		const uint32_t rowsHere = p.dim[0].count - f0 < (uint32_t)FPW ? p.dim[0].count - f0 : (uint32_t)FPW;
+		const uint32_t rowsHere = p.dim[0].count - f0 < (uint32_t)FPW * rowMult ? p.dim[0].count - f0 : (uint32_t)FPW * rowMult;
 		const bool denseIn = !COL && p.dim[0].inStride == (int64_t)n, denseOut = !COL && p.dim[0].outStride == (int64_t)n;
 		// ---- the row as it lies in memory -> LDS (dense rows: the tile is one contiguous run)
 		if constexpr (OPS != 0) {
@@ -93,12 +94,13 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 			dispatch_pre_op(p.preOp, [&](auto opc) { ops_rows_in<T>(p, opc, divN, rows, (uint32_t)SP, (uint32_t)FPW * n, rowsHere, inB, f0 * p.opStride0 + g1 * p.opStride1); });
 		} else if (denseIn) {
 			for (uint32_t e = tid; e < rowsHere * n; e += (uint32_t)NT) {
-				const cx<T> v = gb_load<T>(gin, e * ES, 0);
-				rows[(e / n) * SP + e % n] = swI ? cswap(v) : v;
+				const uint32_t j = e % n;
+				const cx<T> v = gb_load<T>(gin, (j - p.padInL < p.padInN) ? kGbInvalid : e * ES, 0); // (zero padding: the padded range is not read, vkFFT_Zeropad.h:28)
+				rows[(e / n) * SP + j] = swI ? cswap(v) : v;
 			}
 		} else {
 			for (uint32_t j = tau; j < n; j += (uint32_t)TPF) {
-				const cx<T> v = gb_load<T>(gin, valid ? laneIn + j * sJin : kGbInvalid, 0);
+				const cx<T> v = gb_load<T>(gin, (valid && !(j - p.padInL < p.padInN)) ? laneIn + j * sJin : kGbInvalid, 0);
 				row[j * LS] = swI ? cswap(v) : v;
 			}
 		}
@@ -119,21 +121,21 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 		auto fin = [&](cx<T> v) { if (swO) v = cswap(v); if (sc != (T)1) v = cscale(v, sc); return v; };
 		if constexpr (OPS != 0) {
 			const int64_t outB = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride;
-			dispatch_post_op(p.postOp, [&](auto opc) { ops_rows_out<T>(p, opc, rows, sDc, (uint32_t)SP, (uint32_t)FPW, rowsHere, outB, f0 * p.opStride0 + g1 * p.opStride1); });
+			dispatch_post_op(p.postOp, [&](auto opc) { ops_rows_out<T>(p, opc, rows, sDc, (uint32_t)SP, (uint32_t)FPW, rowsHere, outB, f0 * p.opStride0 + g1 * p.opStride1, n); });
 		} else if (denseOut) {
 			for (uint32_t e = tid; e < rowsHere * n; e += (uint32_t)NT) {
 				const uint32_t r = e / n, j = e % n;
-				gb_store<T>(gout, e * ES, 0, fin(j == 0u ? sDc[r] : rows[r * SP + j]));
+				gb_store<T>(gout, (j - p.padOutL < p.padOutN) ? kGbInvalid : e * ES, 0, fin(j == 0u ? sDc[r] : rows[r * SP + j]));
 			}
 		} else {
-			for (uint32_t j = tau; j < n; j += (uint32_t)TPF) gb_store<T>(gout, valid ? laneOut + j * sJout : kGbInvalid, 0, fin(j == 0u ? sDc[f] : row[j * LS]));
+			for (uint32_t j = tau; j < n; j += (uint32_t)TPF) gb_store<T>(gout, (valid && !(j - p.padOutL < p.padOutN)) ? laneOut + j * sJout : kGbInvalid, 0, fin(j == 0u ? sDc[f] : row[j * LS]));
 		}
 	} else {
 		const uint32_t n = p.opN;
 		const GBuf gch = make_gbuf(p.aux);
 		mc_stage<T, SCH, 0, TPF, LS, !COL, false, true>(ex, glut, tau, waveOnly,
 		                                   [&](uint32_t t, uint32_t c) -> cx<T> {
-			                                   const bool in = t + c < n; // the rest is the zero padding: nothing is read
+			                                   const bool in = t + c < n && !(t + c - p.padInL < p.padInN); // the rest is the zero padding: nothing is read (the caller's padded range included)
 			                                   cx<T> v = gb_load<T>(gin, in && valid ? laneIn + t * sJin : kGbInvalid, c * sJin);
 			                                   if (swI) v = cswap(v);
 			                                   return cmulc(v, gb_load<T>(gch, in ? t * ES : kGbInvalid, c * ES));
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 		                                   [&](uint32_t t, uint32_t c, cx<T> v) { row[(t + c) * LS] = cswap(cmul(v, gb_load<T>(gbh, t * ES, c * ES))); });
 		fsync();
 		mc_stage<T, SCH, 0, TPF, LS, !COL, true, false>(ex, glut, tau, waveOnly, fromRow, [&](uint32_t t, uint32_t c, cx<T> v) {
-			if (t + c < n) {
+			if (t + c < n && !(t + c - p.padOutL < p.padOutN)) {
 				cx<T> y = cmulc(cswap(v), gb_load<T>(gch, t * ES, c * ES));
 				if (swO) y = cswap(y);
 				if (sc != (T)1) y = cscale(y, sc);

@@ -133,8 +133,10 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
 	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
-	const uint32_t f0 = tile * RW;
-	const uint32_t rowsHere = p.dim[0].count - f0 < RW ? p.dim[0].count - f0 : RW;
+	const uint32_t rowMult = (ops && p.pairRows) ? 2u : 1u; // two real rows per complex row of the tile (kernel_generic.h)
+	const uint32_t f0 = tile * RW * rowMult;
+	const uint32_t realRowsHere = p.dim[0].count - f0 < RW * rowMult ? p.dim[0].count - f0 : RW * rowMult;
+	const uint32_t rowsHere = (realRowsHere + rowMult - 1u) / rowMult; // complex rows of the tile
 	const GBuf gin = make_gbuf((const cx<T>*)p.in + ((int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride));
 	const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride));
 	const GBuf glut = make_gbuf(p.lut), gbh = make_gbuf(ops ? p.aux3 : p.aux2), gtw = make_gbuf((const cx<T>*)(ops ? p.aux3 : p.aux2) + L);
@@ -144,7 +146,7 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	const uint32_t nat0 = f0 * p.opStride0 + g1 * p.opStride1;
 	// ---- 1. rows -> LDS, sub-sequence-major
 	if (ops) {
-		dispatch_pre_op(p.preOp, [&](auto opc) { ops_rows_in<T>(p, opc, divN, rowbuf, N, rowsHere * N, rowsHere, rowIn0, nat0, M, (uint32_t)P); });
+		dispatch_pre_op(p.preOp, [&](auto opc) { ops_rows_in<T>(p, opc, divN, rowbuf, N, rowsHere * N, realRowsHere, rowIn0, nat0, M, (uint32_t)P); });
 	} else {
 		const uint32_t inRowBytes = (uint32_t)p.dim[0].inStride * ES;
 		for (uint32_t e = tid; e < rowsHere * N; e += (uint32_t)NT) {
@@ -199,7 +201,7 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 #undef VKFFT_MIXRAD_CASE
 	if (ops) {
 		VKFFT_SYNC();
-		dispatch_post_op(p.postOp, [&](auto opc) { ops_rows_out<T>(p, opc, natural, (const cx<T>*)nullptr, N, RW, rowsHere, rowOut0, nat0); });
+		dispatch_post_op(p.postOp, [&](auto opc) { ops_rows_out<T>(p, opc, natural, (const cx<T>*)nullptr, N, RW, realRowsHere, rowOut0, nat0, N); });
 	}
 }
 // ---- cofactors up to 10 that fit the thread groups of the prime's instance, complex rows: every thread group owns ONE sub-sequence in ONE buffer — exchange

@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 		cx<T> v[E];
 #pragma unroll
 		for (int m = 0; m < EH; m++) { // points >= n are the zero padding (n <= M/2: they include every m >= E/2)
-			cx<T> x = gb_load<T>(gin, tau + m * TPF < n ? laneIn : kGbInvalid, (uint32_t)(m * TPF) * ES);
+			const uint32_t pos = tau + m * TPF; // (zero padding, vkFFT_Zeropad.h:28: a point of the padded range is not read)
+			cx<T> x = gb_load<T>(gin, (pos < n && !(pos - p.padInL < p.padInN)) ? laneIn : kGbInvalid, (uint32_t)(m * TPF) * ES);
 			if (p.bluesteinSwapIn) x = cswap(x);
 			v[m] = cmulc(x, ch[m]);
 		}
@@ -145,7 +146,8 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 			cx<T> x = cmulc(cswap(v[m]), ch[m]);
 			if (p.bluesteinSwapOut) x = cswap(x);
 			if (sc != (T)1) x = cscale(x, sc);
-			gb_store<T>(gout, tau + m * TPF < n ? laneOut : kGbInvalid, (uint32_t)(m * TPF) * ES, x);
+			const uint32_t pos = tau + m * TPF; // (... nor written)
+			gb_store<T>(gout, (pos < n && !(pos - p.padOutL < p.padOutN)) ? laneOut : kGbInvalid, (uint32_t)(m * TPF) * ES, x);
 		}
 		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); }
 	}
@@ -367,7 +369,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 #pragma unroll
 		for (int m = 0; m < E / 2; m++) { // opN <= M/2: rows of the upper half are padding
 			const uint32_t pos = tau + m * TPF;
-			cx<T> x = gb_load<T>(gin, pos < n ? laneIn : kGbInvalid, m * stepIn);
+			cx<T> x = gb_load<T>(gin, (pos < n && !(pos - p.padInL < p.padInN)) ? laneIn : kGbInvalid, m * stepIn);
 			if (p.bluesteinSwapIn) x = cswap(x);
 			v[m] = cmulc(x, gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0));
 		}
@@ -386,7 +388,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * TC) pow2_col
 			cx<T> y = cmulc(cswap(v[m]), gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0));
 			if (p.bluesteinSwapOut) y = cswap(y);
 			if (sc != (T)1) y = cscale(y, sc);
-			gb_store<T>(gout, pos < n ? laneOut : kGbInvalid, m * stepOut, y);
+			gb_store<T>(gout, (pos < n && !(pos - p.padOutL < p.padOutN)) ? laneOut : kGbInvalid, m * stepOut, y);
 		}
 	} else if constexpr (MODE == 6 || MODE == 7) { // (7: the narrow-tile instance of 1024 points whose 512 threads have the registers for a kernel matrix)
 		// Merged convolution along this (strided) axis — the reference's convolution-merged last axis (vkFFT_Convolution.h:125-447, vkFFT_RunApp.h:235-345):

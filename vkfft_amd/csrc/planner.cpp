@@ -182,6 +182,15 @@ static void make_mixrad_tables(uint64_t P, uint64_t M, bool dp, Arena& ar, size_
 	for (uint64_t b = 1; b < M; b++) for (uint64_t k = 0; k < P; k++) ar.putc(bhatOff, L + (b - 1) * P + k, unit_root((b * k) % N, N), dp);
 }
 
+// Real-transform families that can carry TWO rows per complex transform (kernel_generic.h ops_rows_in / ops_rows_out): the pre-map of a row is a real
+// sequence (R2C of odd length, DCT / DST-I, -II and odd -IV in their full-length forms) or the result is real (C2R of odd length, DCT / DST-III).
+constexpr int kPairPreferDefault = 0;
+static bool pairable_family(uint32_t pre, uint32_t post, uint64_t cplxLen, uint32_t opN) {
+	auto fam = [&](uint32_t a, uint32_t c) { return pre == a && post == c; };
+	const bool odd4 = (fam(OP_DCT4_PRE, OP_DCT4_POST) || fam(OP_DST4_PRE, OP_DST4_POST)) && cplxLen == opN;
+	return fam(OP_R2C_FULL, OP_R2C_FULL) || fam(OP_C2R_FULL, OP_C2R_FULL) || fam(OP_DCT2_PRE, OP_DCT2_POST) || fam(OP_DST2_PRE, OP_DST2_POST) || fam(OP_DCT3_PRE, OP_DCT3_POST) ||
+	       fam(OP_DST3_PRE, OP_DST3_POST) || fam(OP_DCT1_PRE, OP_DCT1_POST) || fam(OP_DST1_PRE, OP_DST1_POST) || odd4;
+}
 static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	PassBuild b = bIn;
 	size_t mixconvTabOff = (size_t)-1;
@@ -236,14 +245,21 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	                                 (b.postOp == OP_NONE || b.postOp == OP_R2C_EVEN_POST || b.postOp == OP_R2C_FULL || b.postOp == OP_C2R_FULL));
 	// (short real rows: the instance transform between the interpreter's maps moves the tile as one contiguous run; measured against the fused-map
 	// kernels, whose threads read a short row 4 or 8 bytes at a time — VKFFT_MI355X_MIXED_OPS_MAX = longest complex length that prefers it)
+	uint64_t opsCplxLen = 0; // complex length of a pass that runs an instance transform between the generic maps (0: not that form)
 	bool preferMixedOps = false;
 	{
 		// measured (tools/tune_mixed_ops.py, profiles/r03_short_real_rows_fused_maps_vs_instance_between_maps.jsonl): complex lengths 8 and 16 (R2C / DCT of 16 and
 		// 32 reals) run 1.1-5x faster between the maps; from 20 on the fused-map kernels win (only the powers of two were measured: the others keep their fused-map kernel)
 		const uint64_t lim = getenv("VKFFT_MI355X_MIXED_OPS_MAX") ? (uint64_t)atoll(getenv("VKFFT_MI355X_MIXED_OPS_MAX")) : 16;
 		int v, r5[5], f, t;
-		preferMixedOps = lim && b.L >= 8 && b.L <= lim && (b.L & (b.L - 1)) == 0 && !b.colIn && !b.colOut && !padMask && b.inStrideJ == 1 && b.outStrideJ == 1 && (b.preOp != OP_NONE || b.postOp != OP_NONE) &&
-		                 mixed_row_lookup(b.L, b.dp, &v, r5, &f, &t);
+		// (round 4: the other lengths of that range too — their fused-map instances are one thread per row, radix-10 / 14 / 15 butterflies fed by loads a row pitch
+		// apart per lane: DCT-IV of 20 and 30 reals ran at 0.19 / 0.14x the reference, DCT-II of 28 at 0.22x, profiles/r04_dct4_rows_5_400_*)
+		const bool rowOp = !b.colIn && !b.colOut && !padMask && b.inStrideJ == 1 && b.outStrideJ == 1 && (b.preOp != OP_NONE || b.postOp != OP_NONE);
+		preferMixedOps = lim && b.L >= 8 && b.L <= lim && rowOp && mixed_row_lookup(b.L, b.dp, &v, r5, &f, &t);
+		// two real rows per transform exist only between the generic maps (PassParams::pairRows): VKFFT_MI355X_PAIR_PREFER=1 sends the pairable families there
+		// even where a fused-map instance exists (measurement switch)
+		const int pairPrefer = getenv("VKFFT_MI355X_PAIR_PREFER") ? atoi(getenv("VKFFT_MI355X_PAIR_PREFER")) : kPairPreferDefault;
+		if (!preferMixedOps && pairPrefer && rowOp && pairable_family(b.preOp, b.postOp, b.L, b.opN) && mixed_row_lookup(b.L, b.dp, &v, r5, &f, &t)) preferMixedOps = true;
 	}
 	if (b.allowOp && opMaskOK && !preferMixedOps && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && (b.colIn == b.colOut || transOut) && b.radices.empty()
 	    && !(b.preOp == OP_NONE && b.postOp == OP_NONE && !b.colIn)) {
@@ -269,6 +285,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		    !getenv("VKFFT_MI355X_NO_MIXED_OPS")) {
 			int variant, rad5[5], fpw, thr;
 			uint64_t len = 0;
+			opsCplxLen = b.L;
 			if (mixed_row_lookup(b.L, b.dp, &variant, rad5, &fpw, &thr)) {
 				b.fastKernel = KERNEL_MIXED_ROW; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
 				for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
@@ -463,6 +480,14 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	const uint64_t padded = p.padShift >= 31 ? b.L : b.L + (b.L >> p.padShift);
 	p.ldsElems = (uint32_t)((padded + 1) * p.Tp);
 	p.tilesPerG0 = (uint32_t)((dims[0].count + T - 1) / T);
+	if (opsCplxLen && b.fastKernel != KERNEL_GENERIC && !getenv("VKFFT_MI355X_NO_ROW_PAIRS")) {
+		// two real rows per complex transform (the reference's mergeSequencesR2C, vkFFT_SharedMemory.h:40): the families whose pre-map is a real sequence
+		// (post-map through the even / odd split) or whose result is real (kernel_generic.h ops_rows_in / ops_rows_out); the tile holds 2 T rows
+		if (pairable_family(b.preOp, b.postOp, opsCplxLen, b.opN)) {
+			p.pairRows = 1;
+			p.tilesPerG0 = (uint32_t)((dims[0].count + 2 * (uint64_t)T - 1) / (2 * (uint64_t)T));
+		}
+	}
 	const bool mergeable = (b.fastKernel == KERNEL_MIXCONV && b.colIn) ||
 	                       ((b.fastKernel == KERNEL_OPFFT || (b.fastKernel == KERNEL_POW2_COL && !b.bigSpan)) && b.colIn && b.colOut && b.preOp == OP_NONE && b.midOp == OP_NONE &&
 	                        b.postOp == OP_NONE && !b.realIn && !b.realOut);
@@ -692,6 +717,8 @@ struct MultiPassIO {
 	// transform's pre / post map to the ROW, addressed by the natural FFT index (PassParams::preNat / postNat)
 	bool natural = false, firstRealIn = false, lastRealOut = false;
 	uint32_t natOutLen = 0, blueN = 0;
+	// zero padding by the natural index, ranges aligned with the split (plan_c2c_axis): read mask of the first pass, write mask of the last
+	uint64_t padInL = 0, padInN = 0, padOutL = 0, padOutN = 0;
 };
 
 static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<uint64_t>& sp, const MultiPassIO& io, Arena& ar, std::vector<PassPlan>& passes) {
@@ -714,6 +741,7 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 	const uint64_t M = N / n0;
 	// pass A: x[n0][M] columns, FFT over n0, twiddle, store transposed Y^T[m][k0] into T1
 	PassBuild a = proto;
+	a.padInL = (uint32_t)(io.padInL / M); a.padInN = (uint32_t)(io.padInN / M); a.padOutL = a.padOutN = 0; // (aligned ranges only: plan_c2c_axis)
 	a.L = n0; a.inStrideJ = (int64_t)M; a.outStrideJ = 1;
 	a.colIn = true; a.colOut = false;
 	a.dims = dimsFor({M, 1, (int64_t)n0}, {}, 0, 1);
@@ -730,6 +758,7 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 	if (sp.size() == 2) {
 		// pass B: T1[m][k0]: FFT over m (stride n0) for T adjacent k0; X[k0 + n0*k1]
 		PassBuild c = proto;
+		c.padInL = c.padInN = 0; c.padOutL = (uint32_t)(io.padOutL / n0); c.padOutN = (uint32_t)(io.padOutN / n0);
 		c.L = M; c.inStrideJ = (int64_t)n0; c.outStrideJ = (int64_t)n0;
 		c.colIn = c.colOut = true;
 		c.dims = dimsFor({n0, 1, 1}, {}, 1, 0);
@@ -747,6 +776,7 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 		const uint64_t n1 = sp[1], n2 = sp[2];
 		// pass B (in place on T1): layout [m = i1*n2 + i2][k0]; FFT over i1 (stride n2*n0); tiled dim c = i2*n0 + k0
 		PassBuild bb = proto;
+		bb.padInL = bb.padInN = bb.padOutL = bb.padOutN = 0;
 		bb.L = n1; bb.inStrideJ = bb.outStrideJ = (int64_t)(n2 * n0);
 		bb.colIn = bb.colOut = true;
 		bb.dims = dimsFor({n2 * n0, 1, 1}, {}, 1, 1);
@@ -756,6 +786,7 @@ static int emit_multipass(const PassBuild& proto, uint64_t N, const std::vector<
 		PassPlan pb; r = finish_pass(bb, ar, pb); if (r) return r;
 		// pass C: T1 [k1][i2][k0]: FFT over i2 (stride n0); out X[k0 + n0*(k1 + n1*k2)]
 		PassBuild c = proto;
+		c.padInL = c.padInN = 0; c.padOutL = (uint32_t)(io.padOutL / (n0 * n1)); c.padOutN = (uint32_t)(io.padOutN / (n0 * n1));
 		c.L = n2; c.inStrideJ = (int64_t)n0; c.outStrideJ = (int64_t)(n1 * n0);
 		c.colIn = c.colOut = true;
 		c.dims = dimsFor({n0, 1, 1}, {{n1, (int64_t)(n2 * n0), (int64_t)n0}}, 1, 0);
@@ -986,7 +1017,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	// zero padding along this axis: served by the single-pass kernels that can skip elements (finish_pass); everything else reports kPadUnsupported
 	const bool padded = j.padInN || j.padOutN;
 	b.padInL = j.padInL; b.padInN = j.padInN; b.padOutL = j.padOutL; b.padOutN = j.padOutN;
-	if (padded && (!smoothOK || j.N > (unit ? rowCap : max_col_len(dp, d.maxLds, 1)))) return kPadUnsupported;
+	// (round 4: the one-pass Bluestein / Rader kernels skip the padded range too, and so do plans of several passes when the range is aligned with their split)
 
 	{ // a supported length that neither fits one pass nor splits into supported factors (large Rader primes) also goes to Bluestein
 		const uint64_t cap1 = unit ? rowCap : max_col_len(dp, d.maxLds, 1);
@@ -1011,13 +1042,13 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		int v, r5[5], f, t;
 		nativeInstance = unit ? mixed_row_lookup(j.N, dp, &v, r5, &f, &t) : opfft_lookup(j.N, dp, true, false, OP_NONE, OP_NONE, &v, r5, &f, &t);
 	}
-	if (unit && !padded && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && (!smooth13(j.N) || smoothNoInstance)) {
+	if (unit && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && (!smooth13(j.N) || smoothNoInstance)) {
 		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
 		uint64_t Mp = 64; while (Mp < 2 * j.N - 1) Mp *= 2; // measured: the power-of-two padded length wins even at 1.6x the {1,3,5}*2^k one
 		int v, bits[4], fpw, thr;
 		if ((rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && pow2_blue_lookup(ilog2(Mp), dp, &v, bits, &fpw, &thr)) fusedM = Mp;
 	}
-	if (!unit && !padded && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !j.others.empty()
+	if (!unit && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !j.others.empty()
 	    && j.others[0].inStride == 1 && j.others[0].outStride == 1) {
 		// strided axes of non-smooth length (prime x prime planes): the one-pass column Bluestein kernel on the power-of-two padded length beats
 		// the interpreter's Rader / Bluestein stages by 3-6x (measured on the reference's sample-7 systems)
@@ -1075,7 +1106,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	}
 	struct { bool use = false, rader = false, col = false; int variant = -1; uint64_t len = 0; int rad[5] = {1, 1, 1, 1, 1}; int fpw = 0, thr = 0; } mc;
 	const bool colTile = !unit && !j.others.empty() && j.others[0].inStride == 1 && j.others[0].outStride == 1;
-	if ((unit || colTile) && !padded && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && (!smooth13(j.N) || (unit && smoothNoInstance))) {
+	if ((unit || colTile) && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && (!smooth13(j.N) || (unit && smoothNoInstance))) {
 		const int mode = getenv("VKFFT_MI355X_MIXCONV") ? atoi(getenv("VKFFT_MI355X_MIXCONV")) : 1; // (read per plan: tests switch it)
 		// measured (tools/tune_mixconv.py, profiles/r03_mixconv_*): time per point relative to the power-of-two kernels
 		const double kCostRader = getenv("VKFFT_MI355X_MIXCONV_COST_RADER") ? atof(getenv("VKFFT_MI355X_MIXCONV_COST_RADER")) : 1.9;
@@ -1183,6 +1214,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	}
 	if (!smoothOK || fusedM) {
 		// Bluestein (chirp-z) through a padded smooth length M >= 2N-1
+		if (padded && !fusedM) return kPadUnsupported; // (the interpreter's and the multi-pass Bluestein plans do not skip elements)
 		const uint64_t N = j.N;
 		uint64_t M = fusedM ? fusedM : d.forceBluesteinSize ? d.forceBluesteinSize : next_smooth(2 * N - 1, d.fixMaxRadixBluestein ? d.fixMaxRadixBluestein : 7);
 		uint64_t cap = unit ? rowCap : max_col_len(dp, d.maxLds, 1);
@@ -1397,6 +1429,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		out.uploadsPerAxis[j.axisIndex] = 1;
 		return 0;
 	}
+	if (padded && j.N > (unit ? rowCap : max_col_len(dp, d.maxLds, 1)) && !unit) return kPadUnsupported; // (strided multi-pass plans do not skip elements)
 	if (!unit) {
 		// multi-pass along a strided axis: needs a unit-stride companion dimension (others[0]) to tile over
 		if (j.others.empty() || j.others[0].inStride != 1 || j.others[0].outStride != 1) return 3002;
@@ -1413,9 +1446,16 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	}
 
 	// ---- Four-Step on a unit-stride axis: N = n0 * M, recursively M = n1 * n2 -------------------------
-	if (emit_fused(d, j, ar, out, passes)) return 0;
+	if (!padded && emit_fused(d, j, ar, out, passes)) return 0;
 	std::vector<uint64_t> sp;
 	if (!choose_split(j.N, dp, d.maxLds, dmax, !d.disableFastKernels, sp)) return 3002;
+	if (padded) {
+		// zero padding on an axis of several passes (vkFFT_Zeropad.h:28-182 masks every upload by the natural index): element j of a first-pass column is the
+		// point j * M + m and output k of a last-pass column the frequency k0 + (N / len) k, so a range whose ends are multiples of those strides is a range of
+		// j (of k) alone and the per-pass masks of the column kernels apply; other ranges fall back
+		const uint64_t sIn = j.N / sp[0], sOut = j.N / sp.back();
+		if ((j.padInN && (j.padInL % sIn || j.padInN % sIn)) || (j.padOutN && (j.padOutL % sOut || j.padOutN % sOut))) return kPadUnsupported;
+	}
 	out.uploadsPerAxis[j.axisIndex] = (uint32_t)sp.size();
 	for (size_t i = 0; i < sp.size(); i++) out.axisSplit[j.axisIndex][i] = sp[sp.size() - 1 - i];
 	MultiPassIO io;
@@ -1424,6 +1464,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	for (auto& o : io.othersOut) o.inStride = o.outStride;
 	io.inRole = j.inRole; io.outRole = j.outRole;
 	io.swapIn = io.swapOut = j.inverse; io.scale = j.scale;
+	io.padInL = j.padInL; io.padInN = j.padInN; io.padOutL = j.padOutL; io.padOutN = j.padOutN;
 	int r = emit_multipass(b, j.N, sp, io, ar, passes);
 	if (r) return r;
 	uint64_t nsub = 1;
@@ -1452,6 +1493,25 @@ static int make_r2c_pair_pass(uint64_t N, bool dp, bool inverse, const std::vect
 	pair.kernel = KERNEL_R2C_PAIR; pair.dp = dp; pair.inRole = pair.outRole = cplxRole;
 	pair.inElemBytes = pair.outElemBytes = (int)es; pair.threads = 256; pair.label = inverse ? "c2r-pair" : "r2c-pair";
 	return 0;
+}
+
+// Real rows whose complex length has a prime factor above 31 that the interpreter would take as a direct O(p^2) Rader stage (47, 59: p - 1 is not smooth) or
+// that no instance kernel serves (a Rader prime with an unserved cofactor): measured at 0.12-0.26x the reference (R2C / DCT rows of 94, 118, 235, 295, 376
+// reals, profiles/r04_*_rows_*) — the fused Bluestein kernel of the real transforms (kernel_blue_r2r.h) takes them instead.
+static bool real_row_prefers_bluestein(uint64_t L, bool dp) {
+	if (L < 2 || L > 4096) return false;
+	uint64_t P = 0, rest = L;
+	for (uint64_t q = 2; q * q <= rest; q++) while (rest % q == 0) { P = q; rest /= q; }
+	if (rest > 1) P = rest;
+	if (P <= 31) return false;
+	int v, r5[5], f, t; uint64_t len;
+	if (mixed_row_lookup(L, dp, &v, r5, &f, &t)) return false;
+	if (P == L) return !mixconv_lookup(true, false, P, dp, &v, &len, r5, &f, &t);
+	if (getenv("VKFFT_MI355X_MIXRAD") && atoi(getenv("VKFFT_MI355X_MIXRAD")) == 0) return true;
+	const uint64_t M = L / P;
+	if (!dp && P >= 37 && mixrad_cofactor_ok((uint32_t)M) && mixconv_lookup(true, false, P, dp, &v, &len, r5, &f, &t) && mixrad_available(v) &&
+	    mixrad_fits(mixrad_mode((uint32_t)P, (uint32_t)f, (uint32_t)M, true), (uint32_t)P, (uint32_t)f, (uint32_t)M, true)) return false;
+	return true;
 }
 
 // ---- real transforms: coverage path -------------------------------------------------------------------------
@@ -1560,7 +1620,15 @@ static int plan_r2c_axis0_fused(const TransformDesc& d, bool inverse, const std:
 	uint64_t blueM = 0; // padded length of the Bluestein-wrapped full-length form (kernel_blue_r2r.h), 0: not used
 	int blueVariant = 0, blueBits[4] = {0, 0, 0, 0}, blueFpw = 0, blueThr = 0;
 	if (padReal && (!is_supported_len(b.L, dmax) || b.L > max_row_len(dp, d.maxLds))) return kPadUnsupported;
-	if (!is_supported_len(b.L, dmax)) {
+	bool blueByChoice = false; // the length is within the interpreter's reach, the fused Bluestein kernel is the faster form (real_row_prefers_bluestein)
+	if (is_supported_len(b.L, dmax) && !d.disableFastKernels && !padReal && real_row_prefers_bluestein(b.L, dp) && !getenv("VKFFT_MI355X_NO_REAL_BLUE_CHOICE")) {
+		uint64_t Mp = 64; while (Mp < 2 * N - 1) Mp *= 2;
+		uint64_t pitch = N + 2;
+		if (!othersReal.empty()) pitch = (uint64_t)std::max<int64_t>(std::llabs(othersReal[0].inStride), 2 * std::llabs(othersCplx[0].inStride));
+		int v, bits[4], fpw, thr;
+		blueByChoice = Mp <= (dp ? 4096u : 8192u) && (pitch * 64 + 2 * N) * (dp ? 8 : 4) < 0x7FFFFF00ull && pow2_blue_r2r_lookup(ilog2(Mp), dp, inverse ? OP_C2R_FULL : OP_R2C_FULL, &v, bits, &fpw, &thr);
+	}
+	if (!is_supported_len(b.L, dmax) || blueByChoice) {
 		// the (half) length has a prime factor outside the radix / Rader stages: full-length "callback" form (real -> (x, 0),
 		// keep the first N/2+1 outputs; vkFFT_R2C.h:27) around a fused Bluestein transform of length N
 		if (d.disableFastKernels) return 3003;
@@ -1716,7 +1784,9 @@ static int plan_r2r_axis(const TransformDesc& d, int type, bool dst, uint64_t N,
 		break;
 	case 2: m.Lm = N; m.preOp = dst ? OP_DST2_PRE : OP_DCT2_PRE; m.postOp = dst ? OP_DST2_POST : OP_DCT2_POST; m.postAux = quarter(); break;
 	case 3: m.Lm = N; m.preOp = dst ? OP_DST3_PRE : OP_DCT3_PRE; m.postOp = dst ? OP_DST3_POST : OP_DCT3_POST; m.preAux3 = quarter(); m.cinverse = true; break;
-	default: { // type 4: zero-padded 2N form, its maps are element-wise
+	default: { // type 4: odd lengths in the same-length form (no tables), even ones in the zero-padded 2N form; both maps are element-wise
+		m.preOp = dst ? OP_DST4_PRE : OP_DCT4_PRE; m.postOp = dst ? OP_DST4_POST : OP_DCT4_POST;
+		if ((N & 1) && N >= 3) { m.Lm = N; break; }
 		m.Lm = 2 * N; m.preOp = dst ? OP_DST4_PRE : OP_DCT4_PRE; m.postOp = dst ? OP_DST4_POST : OP_DCT4_POST;
 		m.preAux3 = quarter();
 		const size_t a2 = ar.alloc(N * es);
@@ -1795,17 +1865,31 @@ static int plan_r2r_axis_fused(const TransformDesc& d, int type, bool dst, uint6
 			for (uint64_t n = 0; n < N / 2; n++) { ar.putc(aux, n, unit_root(4 * n + 1, 8 * N), dp); ar.putc(aux2, n, unit_root(n, 2 * N), dp); }
 			b.auxOff = aux; b.aux2Off = aux2;
 		} else {
-			b.L = 2 * N;
-			size_t aux = ar.alloc(N * es), aux2 = ar.alloc(N * es);
-			for (uint64_t n = 0; n < N; n++) { ar.putc(aux, n, unit_root(n, 4 * N), dp); ar.putc(aux2, n, unit_root(2 * n + 1, 8 * N), dp); }
-			b.auxOff = aux; b.aux2Off = aux2;
+			// odd length: the same-length form (vkFFT_R2R.h:414-481, 922-972, 1032) — a signed permutation of the row, an N-point transform, one
+			// rotation by a multiple of pi/4 per output (kernel_generic.h); no tables.  (Rounds 1-3 zero-padded to 2N complex points.)
+			b.L = N;
+			if (N < 3) { // a single point stays on the zero-padded two-point form
+				b.L = 2 * N;
+				size_t aux = ar.alloc(N * es), aux2 = ar.alloc(N * es);
+				for (uint64_t n = 0; n < N; n++) { ar.putc(aux, n, unit_root(n, 4 * N), dp); ar.putc(aux2, n, unit_root(2 * n + 1, 8 * N), dp); }
+				b.auxOff = aux; b.aux2Off = aux2;
+			}
 		}
 		break;
 	}
 	default: return 3004;
 	}
 	b.label = dst ? "dst" : "dct";
-	if (!is_supported_len(b.L, dmax)) {
+	bool blueByChoice = false; // within the interpreter's reach, but the fused Bluestein kernel is the faster form (real_row_prefers_bluestein)
+	if (is_supported_len(b.L, dmax) && unit && !d.disableFastKernels && real_row_prefers_bluestein(b.L, dp) && !getenv("VKFFT_MI355X_NO_REAL_BLUE_CHOICE")) {
+		const uint64_t Lb = (type == 2 || type == 3) ? N : b.L;
+		uint64_t Mp = 64; while (Mp < 2 * Lb - 1) Mp *= 2;
+		const uint64_t rowPitch = others.empty() ? N : (uint64_t)std::max<int64_t>(std::llabs(others[0].inStride), std::llabs(others[0].outStride));
+		const uint32_t pre = type == 2 ? (uint32_t)OP_DCT2_PRE : type == 3 ? (uint32_t)OP_DCT3_PRE : b.preOp;
+		int v, bits[4], fpw, thr;
+		blueByChoice = Mp <= (dp ? 4096u : 8192u) && (rowPitch * 64 + 2 * N) * (dp ? 8 : 4) < 0x7FFFFF00ull && pow2_blue_r2r_lookup(ilog2(Mp), dp, pre, &v, bits, &fpw, &thr);
+	}
+	if (!is_supported_len(b.L, dmax) || blueByChoice) {
 		// the embedding length has a prime factor outside the radix / Rader stages (e.g. DST-I of 100: 202 = 2 * 101): the
 		// real transform's maps around a fused Bluestein transform of the embedding length (kernel_blue_r2r.h), unit-stride rows
 		if (!unit || d.disableFastKernels) return 3004;
@@ -1847,6 +1931,9 @@ static int plan_r2r_axis_fused(const TransformDesc& d, int type, bool dst, uint6
 			io.swapIn = io.swapOut = type == 3;
 			if (b.auxOff == (size_t)-1) { size_t aux = ar.alloc(N * es); for (uint64_t k = 0; k < N; k++) ar.putc(aux, k, unit_root(k, 4 * N), dp); b.auxOff = aux; }
 			io.firstAux = type == 3 ? b.auxOff : (size_t)-1; io.lastAux = b.auxOff;
+		} else if (type == 4 && (N & 1) && N >= 3) { // odd length: same-length form, element-wise maps without tables
+			Lm = N;
+			io.firstPre = b.preOp; io.lastPost = b.postOp;
 		} else if (type == 4) { // zero-padded 2N form: its maps are element-wise
 			Lm = 2 * N;
 			size_t aux = ar.alloc(N * es), aux2 = ar.alloc(N * es);
