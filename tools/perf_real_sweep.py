@@ -23,7 +23,8 @@ if os.path.exists(fn):
 saved_ref = perf_configs.ref
 for i, n in enumerate(lengths):
     rec = {"kind": kind, "N": n}
-    for tag, env in (("default", {}), ("one_row_per_transform", {"VKFFT_MI355X_NO_ROW_PAIRS": "1"}), ("pairs_preferred", {"VKFFT_MI355X_PAIR_PREFER": "1"})):
+    modes = (("default", {}), ("one_row_per_transform", {"VKFFT_MI355X_NO_ROW_PAIRS": "1"}), ("pairs_preferred", {"VKFFT_MI355X_PAIR_PREFER": "1"}))
+    for tag, env in (modes if n % 2 else modes[:1]):  # (rows of even length run their half-length forms: nothing to pair)
         for k in ("VKFFT_MI355X_NO_ROW_PAIRS", "VKFFT_MI355X_PAIR_PREFER"):
             os.environ.pop(k, None)
         os.environ.update(env)

@@ -14,6 +14,7 @@
 // run time.  The hand-specialised power-of-two kernels in kernel_pow2.h replace this kernel on the
 // headline path; this one provides coverage.
 #pragma once
+#include <type_traits>
 #include "butterflies.h"
 #include "memops.h"
 
@@ -563,17 +564,21 @@ __device__ inline cx<T>* run_stage_rader_fft(const PassParams& p, const StageDes
 __host__ __device__ inline bool op_pair_result_is_real(uint32_t postOp) { return postOp == OP_C2R_FULL || postOp == OP_DCT3_POST || postOp == OP_DST3_POST; }
 template <typename T, typename OPC>
 // subM > 1: the row is stored sub-sequence-major (element M a + b at b * subP + a: kernel_mixrad.h); nvalid counts ROWS (two per slot when paired)
-__device__ inline void ops_rows_in(const PassParams& p, OPC opc, const FastDiv divN, cx<T>* lds, uint32_t SP, uint32_t TOT, uint32_t nvalid, int64_t inBase, uint32_t nat0, uint32_t subM = 1, uint32_t subP = 0) {
+__device__ __attribute__((always_inline)) inline void ops_rows_in(const PassParams& p, OPC opc, const FastDiv divN, cx<T>* lds, uint32_t SP, uint32_t TOT, uint32_t nvalid, int64_t inBase, uint32_t nat0, uint32_t subM = 1, uint32_t subP = 0) {
 	const uint32_t tid = threadIdx.x, NT = blockDim.x;
 	const bool swI = p.swapIn != 0;
-	const uint32_t nh = p.pairRows ? 2u : 1u;
+	// (pairs only where the operation is a compile-time constant: with the run-time operation — the DST members, DCT-I / DST-I — the body with the second trip
+	// and the split outgrows the inliner, and ONE out-of-line copy costs every kernel of the family a call frame: 1.4 KB of scratch, 131 VGPRs, 5-10x the time)
+	constexpr bool kCanPair = !std::is_same<OPC, uint32_t>::value;
+	const uint32_t nh = (kCanPair && p.pairRows) ? 2u : 1u;
+	// (the second row of a pair is a second sweep of the SAME loop, added into what the first one laid down — every thread meets its own elements again, no
+	// barrier; the two trips nested inside one sweep cost the instances 20 VGPRs)
 #pragma unroll 1
-	for (uint32_t idx = tid; idx < TOT; idx += NT) {
-		uint32_t fi, pos;
-		divN.divmod(idx, fi, pos);
-		cx<T> v = {(T)0, (T)0};
+	for (uint32_t h = 0; h < nh; h++) {
 #pragma unroll 1
-		for (uint32_t h = 0; h < nh; h++) {
+		for (uint32_t idx = tid; idx < TOT; idx += NT) {
+			uint32_t fi, pos;
+			divN.divmod(idx, fi, pos);
 			const uint32_t row = fi * nh + h;
 			cx<T> a = {(T)0, (T)0};
 			if (row < nvalid) {
@@ -581,37 +586,42 @@ __device__ inline void ops_rows_in(const PassParams& p, OPC opc, const FastDiv d
 				io.set_pad(p);
 				a = pre_gather<T>(p, io, pos, nat0 + row * p.opStride0, op_value(opc));
 			}
-			v = h ? cx<T>{v.x - a.y, v.y + a.x} : a;
+			const uint32_t dst = subM > 1 ? (pos % subM) * subP + pos / subM : pos;
+			cx<T>* const q = lds + fi * SP + dst;
+			if (h == 0u) *q = swI ? cswap(a) : a;
+			else { const cx<T> s = *q; *q = swI ? cx<T>{s.x + a.x, s.y - a.y} : cx<T>{s.x - a.y, s.y + a.x}; } // z + i a (in the swapped frame: swap(z + i a))
 		}
-		const uint32_t dst = subM > 1 ? (pos % subM) * subP + pos / subM : pos;
-		lds[fi * SP + dst] = swI ? cswap(v) : v;
 	}
 }
 // rows of the tile -> post-map -> global memory; fetch(fi, a) delivers element a of row fi (un-swapped); rows at lds + fi * SP unless `dc` (Rader: element 0 of a row lives in dc[fi])
 // Lc = length of the complex row (the mirror index of the paired split); nvalid counts ROWS
 template <typename T, typename OPC>
-__device__ inline void ops_rows_out(const PassParams& p, OPC opc, const cx<T>* lds, const cx<T>* dc, uint32_t SP, uint32_t FPW, uint32_t nvalid, int64_t outBase, uint32_t nat0, uint32_t Lc = 0) {
+__device__ __attribute__((always_inline)) inline void ops_rows_out(const PassParams& p, OPC opc, const cx<T>* lds, const cx<T>* dc, uint32_t SP, uint32_t FPW, uint32_t nvalid, int64_t outBase, uint32_t nat0, uint32_t Lc = 0) {
 	const uint32_t tid = threadIdx.x, NT = blockDim.x;
 	const uint32_t total = p.outLen * FPW;
 	const bool swO = p.swapOut != 0;
-	const uint32_t nh = p.pairRows ? 2u : 1u;
+	constexpr bool kCanPair = !std::is_same<OPC, uint32_t>::value;
+	const uint32_t nh = (kCanPair && p.pairRows) ? 2u : 1u;
 	const bool realResult = op_pair_result_is_real(op_value(opc));
 #pragma unroll 1
-	for (uint32_t idx = tid; idx < total; idx += NT) {
-		uint32_t fi, k;
-		p.divOutLen.divmod(idx, fi, k);
+	for (uint32_t h = 0; h < nh; h++) {
 #pragma unroll 1
-		for (uint32_t h = 0; h < nh; h++) {
+		for (uint32_t idx = tid; idx < total; idx += NT) {
+			uint32_t fi, k;
+			p.divOutLen.divmod(idx, fi, k);
 			const uint32_t row = fi * nh + h;
-			if (row >= nvalid) break;
+			if (row >= nvalid) continue;
 			auto rd = [&](uint32_t a) -> cx<T> {
 				cx<T> v = (dc && a == 0u) ? dc[fi] : lds[fi * SP + a];
 				if (swO) v = cswap(v);
-				if (nh == 1u) return v;
-				if (realResult) return cx<T>{h ? v.y : v.x, (T)0};
-				cx<T> m = a == 0u ? v : lds[fi * SP + (Lc - a)];
-				if (swO && a != 0u) m = cswap(m);
-				return h ? cx<T>{(T)0.5 * (v.y + m.y), (T)0.5 * (m.x - v.x)} : cx<T>{(T)0.5 * (v.x + m.x), (T)0.5 * (v.y - m.y)};
+				if constexpr (kCanPair) {
+					if (nh == 1u) return v;
+					if (realResult) return cx<T>{h ? v.y : v.x, (T)0};
+					const uint32_t ma = a ? Lc - a : 0u; // (both operands of the split come from LDS: a select between a register pair and memory went through scratch)
+					cx<T> m = (dc && ma == 0u) ? dc[fi] : lds[fi * SP + ma];
+					if (swO) m = cswap(m);
+					return h ? cx<T>{(T)0.5 * (v.y + m.y), (T)0.5 * (m.x - v.x)} : cx<T>{(T)0.5 * (v.x + m.x), (T)0.5 * (v.y - m.y)};
+				} else return v;
 			};
 			Io64<T> io{p.in, p.out, 0, outBase + (int64_t)row * p.dim[0].outStride, p.inStrideJ, p.outStrideJ};
 			io.set_pad(p);

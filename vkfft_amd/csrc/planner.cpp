@@ -188,8 +188,11 @@ constexpr int kPairPreferDefault = 0;
 static bool pairable_family(uint32_t pre, uint32_t post, uint64_t cplxLen, uint32_t opN) {
 	auto fam = [&](uint32_t a, uint32_t c) { return pre == a && post == c; };
 	const bool odd4 = (fam(OP_DCT4_PRE, OP_DCT4_POST) || fam(OP_DST4_PRE, OP_DST4_POST)) && cplxLen == opN;
-	return fam(OP_R2C_FULL, OP_R2C_FULL) || fam(OP_C2R_FULL, OP_C2R_FULL) || fam(OP_DCT2_PRE, OP_DCT2_POST) || fam(OP_DST2_PRE, OP_DST2_POST) || fam(OP_DCT3_PRE, OP_DCT3_POST) ||
-	       fam(OP_DST3_PRE, OP_DST3_POST) || fam(OP_DCT1_PRE, OP_DCT1_POST) || fam(OP_DST1_PRE, OP_DST1_POST) || odd4;
+	// (the members whose operation the kernels hold as a compile-time constant — dispatch_pre_op / dispatch_post_op; the DST members and DCT-I / DST-I run through the
+	// run-time switch, where the paired loop body would not inline: kernel_generic.h)
+	const bool odd4c = fam(OP_DCT4_PRE, OP_DCT4_POST) && cplxLen == opN;
+	(void)odd4;
+	return fam(OP_R2C_FULL, OP_R2C_FULL) || fam(OP_C2R_FULL, OP_C2R_FULL) || fam(OP_DCT2_PRE, OP_DCT2_POST) || fam(OP_DCT3_PRE, OP_DCT3_POST) || odd4c;
 }
 static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	PassBuild b = bIn;
