@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Appends / rewrites the "## Round 4, second session" section of profiles/README.md from the tracked `r04b_*` evidence files.
+Fails when the bench line, the kernel stats and the PMC summary were not taken on the same sources."""
+import json, math, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+d = json.load(open(f"{P}/r04b_bench.json")); d0 = json.load(open(f"{P}/r04_bench.json"))
+pmc = json.load(open(f"{P}/r04b_pmc_traffic.json"))
+ks_hash = re.search(r"sources ([0-9a-f]{16})", open(f"{P}/r04b_bench_kernel_stats.csv").readline()).group(1)
+if ks_hash != pmc["source_hash"]:
+    sys.exit(f"kernel stats were taken on sources {ks_hash}, the PMC summary on {pmc['source_hash']}: re-collect both on one build")
+ps, ps0 = d["per_size"], d0["per_size"]
+rows = "".join(f"| {k} | {round(ps0[str(k)]['alg_GBps'])} | {round(ps[str(k)]['alg_GBps'])} | {round(ps[str(k)]['fwd_only_alg_GBps'])} |\n" for k in range(8, 23))
+def g(xs): return math.exp(sum(math.log(x) for x in xs) / len(xs)) if xs else float("nan")
+sw = ""
+for which, old in (("r2c", "r04_r2c_rows_4_400"), ("dct2", "r04_dct2_rows_4_400"), ("dct4", "r04_dct4_rows_5_400")):
+    recs = [json.loads(l) for l in open(f"{P}/r04b_{which}_rows_three_plans.jsonl") if l.startswith("{")]
+    ratio, ratio_old, gain, same = [], [], [], []
+    for r in recs:
+        ref = r.get("ref_ms", r.get("ref_ms_round4_sweep"))
+        if ref is None or "default_ms" not in r: continue
+        ratio.append(ref / r["default_ms"])
+        if "ours_ms_round4_sweep" in r: ratio_old.append(r["ref_ms_round4_sweep"] / r["ours_ms_round4_sweep"])
+        if "one_row_per_transform_ms" in r: gain.append(r["one_row_per_transform_ms"] / r["default_ms"])
+        if "ref_ms" in r: same.append(r["ref_ms"] / r["default_ms"])
+    sw += (f"| `r04b_{which}_rows_three_plans.jsonl` | {len(ratio)} | {g(ratio):.3f} | {sum(1 for x in ratio if x < 0.5)} | {sum(1 for x in ratio if x < 0.7)} | {min(ratio):.2f} | {g(ratio_old):.3f} | "
+           f"{g(gain):.2f} | {len(same)}: {g(same):.3f} |\n")
+s = open(f"{P}/README.md").read()
+tag = "## Round 4, second session"
+if tag in s:
+    s = s[:s.index(tag)]
+s = s.rstrip("\n") + f'''
+
+{tag}
+
+Files `r04b_*`: the bench line, the kernel stats and the PMC traffic of the FINAL round-4 sources (`{pmc['source_hash']}`, `vkfft_amd.api.source_hash()`; the first session's `r04_*` files stay as
+the record of the build they were taken on).  Bench line: **{d['value']/1000:.2f} TFLOP/s, {d['ms_per_step']:.2f} ms per step** (copy rate of that box {d['roofline']['copy_GBps_same_box']/1000:.2f} TB/s);
+after the timed loop the buffer equals its initial contents to {d['roundtrip_rel_l2']:.2e} relative L2 over {d['roundtrip_pairs']} transform pairs (limit {d['roundtrip_limit_rel_l2']:.1e}).
+The power-of-two kernels did not change in this session; the table shows the box-to-box spread of the pool against the first session's line.
+
+| log2 N | first session (alg. GB/s, paired) | this build (paired) | this build, forward only |
+|---|---|---|---|
+{rows}
+| file | what | command |
+|---|---|---|
+| `r04b_bench.json` | bench.py JSON line of the final build | `python bench.py` |
+| `r04b_bench_kernel_stats.csv` | per-kernel time of the headline benchmark | `cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline` |
+| `r04b_pmc_traffic.json` | bytes per launch at the L2↔fabric boundary (FETCH_SIZE × 2 per the gfx950 rule + WRITE_SIZE, separate passes) | `rocprofv3 --pmc FETCH_SIZE --kernel-trace … python tools/pmc_probe.py`, same with `WRITE_SIZE`; `python tools/summarize_profiles.py r04b r04b` |
+| `r04b_gpu_suite.log` | tail of `pytest -m gpu` on the device | `python -m pytest tests -m gpu -q -n 8` |
+| `r04b_{{r2c,dct2,dct4}}_rows_three_plans.jsonl` | real rows of 4 … 400 reals (R2C, DCT-II: step 3; DCT-IV 5 … 400: step 5), pair time in ms of three plans per odd length — default (two rows per transform), `VKFFT_MI355X_NO_ROW_PAIRS=1` (one row per transform), `VKFFT_MI355X_PAIR_PREFER=1` (pairs also where a fused-map instance exists) — the reference timed in the same process on every 6th length (`ref_ms`), the first session's sweep of the same lengths beside it (`ref_ms_round4_sweep`, `ours_ms_round4_sweep`: the reference's times reproduce within 2 %) | `python tools/perf_real_sweep.py <r2c|dct2|dct4> 6` |
+| `r04b_real_rows_selected.jsonl` | DCT-IV 1451 / 1125 / 235 / 30 / 20, R2C and DCT-II 235 / 169 / 28, R2C 4095 / 4096, DCT-II 4096 with the reference in the same process | `python tools/perf_real_rows.py 14:1451 …` |
+| `r04b_real_rows_with_an_out_of_line_map_loop.jsonl` | the same sweeps on the FIRST build of the paired loops, kept as a record of a compiler hazard: one out-of-line copy of `ops_rows_out` (the run-time-operation instantiation outgrew the inliner) gave every kernel of the family a call frame — 1440 bytes of scratch, 131 VGPRs — and 5–10 × the time on every length between the maps, paired or not; `-Rpass-analysis=kernel-resource-usage` over the whole library is the check that was missing | `python tools/perf_real_sweep.py …` |
+
+Real rows beside the reference (ratio = this library ÷ reference, geometric mean over the sweep; the reference's time is the same-process one where it was taken, else the first session's):
+
+| file | lengths | this build | < 0.5 | < 0.7 | worst | first session | gain of the pairs on odd lengths | same-process reference only |
+|---|---|---|---|---|---|---|---|---|
+{sw}'''
+open(f"{P}/README.md", "w").write(s + "\n")
+print("profiles/README.md: second-session section written")

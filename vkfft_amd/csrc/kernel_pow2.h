@@ -113,6 +113,16 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 	for (int m = 0; m < EH; m++) { const uint32_t pos = tau + m * TPF; ch[m] = gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0); }
 #pragma unroll
 	for (int m = 0; m < E; m++) bh[m] = gb_load<T>(gbh, (tau + m * TPF) * ES, 0);
+	// which of this thread's points are read / written: inside the sequence and outside the caller's zero-padded range (vkFFT_Zeropad.h:28).  The points do not
+	// depend on the tile, so the tests are made once, one bit per point — as compares inside the loop the four range operands cost the 8192-point
+	// instance 60 scalar-register spills (2049 ... 4096-point rows 11 % slower, profiles/r04b_sample1000_*)
+	uint32_t rdMask = 0, wrMask = 0;
+#pragma unroll
+	for (int m = 0; m < EH; m++) {
+		const uint32_t pos = tau + m * TPF;
+		if (pos < n && !(pos - p.padInL < p.padInN)) rdMask |= 1u << m;
+		if (pos < n && !(pos - p.padOutL < p.padOutN)) wrMask |= 1u << m;
+	}
 	const uint32_t tiles = p.tilesPerG0 * p.dim[1].count * p.dim[2].count;
 	const T sc = (T)p.scale;
 	for (uint32_t wgi = blockIdx.x; wgi < tiles; wgi += gridDim.x) {
@@ -129,8 +139,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 		cx<T> v[E];
 #pragma unroll
 		for (int m = 0; m < EH; m++) { // points >= n are the zero padding (n <= M/2: they include every m >= E/2)
-			const uint32_t pos = tau + m * TPF; // (zero padding, vkFFT_Zeropad.h:28: a point of the padded range is not read)
-			cx<T> x = gb_load<T>(gin, (pos < n && !(pos - p.padInL < p.padInN)) ? laneIn : kGbInvalid, (uint32_t)(m * TPF) * ES);
+			cx<T> x = gb_load<T>(gin, ((rdMask >> m) & 1u) ? laneIn : kGbInvalid, (uint32_t)(m * TPF) * ES);
 			if (p.bluesteinSwapIn) x = cswap(x);
 			v[m] = cmulc(x, ch[m]);
 		}
@@ -146,8 +155,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 			cx<T> x = cmulc(cswap(v[m]), ch[m]);
 			if (p.bluesteinSwapOut) x = cswap(x);
 			if (sc != (T)1) x = cscale(x, sc);
-			const uint32_t pos = tau + m * TPF; // (... nor written)
-			gb_store<T>(gout, (pos < n && !(pos - p.padOutL < p.padOutN)) ? laneOut : kGbInvalid, (uint32_t)(m * TPF) * ES, x);
+			gb_store<T>(gout, ((wrMask >> m) & 1u) ? laneOut : kGbInvalid, (uint32_t)(m * TPF) * ES, x);
 		}
 		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); }
 	}
