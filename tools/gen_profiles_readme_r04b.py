@@ -25,6 +25,11 @@ for which, old in (("r2c", "r04_r2c_rows_4_400"), ("dct2", "r04_dct2_rows_4_400"
         if "ref_ms" in r: same.append(r["ref_ms"] / r["default_ms"])
     sw += (f"| `r04b_{which}_rows_three_plans.jsonl` | {len(ratio)} | {g(ratio):.3f} | {sum(1 for x in ratio if x < 0.5)} | {sum(1 for x in ratio if x < 0.7)} | {min(ratio):.2f} | {g(ratio_old):.3f} | "
            f"{g(gain):.2f} | {len(same)}: {g(same):.3f} |\n")
+def gm(fn):
+    r = [json.loads(l) for l in open(f"{P}/{fn}") if l.startswith("{")]
+    return g([x["alg_GBps"] / x["ref_alg_GBps"] for x in r if x.get("ref_alg_GBps")])
+cfg, s1000 = gm("r04b_config34_with_reference_same_call.jsonl"), gm("r04b_sample1000_sampling_with_reference_same_call.jsonl")
+cfg0, s10000 = gm("r04_config34_with_reference_same_call.jsonl"), gm("r04_sample1000_sampling_with_reference_same_call.jsonl")
 s = open(f"{P}/README.md").read()
 tag = "## Round 4, second session"
 if tag in s:
@@ -46,9 +51,10 @@ The power-of-two kernels did not change in this session; the table shows the box
 | `r04b_bench.json` | bench.py JSON line of the final build | `python bench.py` |
 | `r04b_bench_kernel_stats.csv` | per-kernel time of the headline benchmark | `cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline` |
 | `r04b_pmc_traffic.json` | bytes per launch at the L2↔fabric boundary (FETCH_SIZE × 2 per the gfx950 rule + WRITE_SIZE, separate passes) | `rocprofv3 --pmc FETCH_SIZE --kernel-trace … python tools/pmc_probe.py`, same with `WRITE_SIZE`; `python tools/summarize_profiles.py r04b r04b` |
-| `r04b_gpu_suite.log` | tail of `pytest -m gpu` on the device | `python -m pytest tests -m gpu -q -n 8` |
+| `r04b_gpu_suite.log` | `pytest -m gpu` on the device in three steps (commands inside): the full suite one build before the final one (634 passed, 1 skipped, 4 failed on a test that compared a small and a large batch bit for bit on units of THREE rows — with two rows per transform the third row's partner differs, so its last bits do; the check repeats pair-aligned units now), those four again (4 passed), and the tests of the paths the last two kernel fixes touch on the final sources (145 passed) | see the file |
+| `r04b_config34_with_reference_same_call.jsonl`, `r04b_sample1000_sampling_with_reference_same_call.jsonl` | configs 3 / 4 and the sampling of sample 1000 on the final sources: geometric mean {cfg:.3f} / {s1000:.3f} × the reference (first session {cfg0:.3f} / {s10000:.3f}); the build before the last (padding tests inside the loop of the 8192-point Bluestein kernel: 60 scalar-register spills) ran the sampling at 0.942 | `python tools/perf_configs.py`, `python tools/perf_sample1000.py 60` |
 | `r04b_{{r2c,dct2,dct4}}_rows_three_plans.jsonl` | real rows of 4 … 400 reals (R2C, DCT-II: step 3; DCT-IV 5 … 400: step 5), pair time in ms of three plans per odd length — default (two rows per transform), `VKFFT_MI355X_NO_ROW_PAIRS=1` (one row per transform), `VKFFT_MI355X_PAIR_PREFER=1` (pairs also where a fused-map instance exists) — the reference timed in the same process on every 6th length (`ref_ms`), the first session's sweep of the same lengths beside it (`ref_ms_round4_sweep`, `ours_ms_round4_sweep`: the reference's times reproduce within 2 %) | `python tools/perf_real_sweep.py <r2c|dct2|dct4> 6` |
-| `r04b_real_rows_selected.jsonl` | DCT-IV 1451 / 1125 / 235 / 30 / 20, R2C and DCT-II 235 / 169 / 28, R2C 4095 / 4096, DCT-II 4096 with the reference in the same process | `python tools/perf_real_rows.py 14:1451 …` |
+| `r04b_real_rows_selected.jsonl` | DCT-IV 1451 / 1125 / 235 / 30 / 20, R2C and DCT-II 235 / 169 / 28, R2C 4095 / 4096, DCT-II 4096 with the reference in the same process (taken one build before the final one, sources `d125190384712dd0`) | `python tools/perf_real_rows.py 14:1451 …` |
 | `r04b_real_rows_with_an_out_of_line_map_loop.jsonl` | the same sweeps on the FIRST build of the paired loops, kept as a record of a compiler hazard: one out-of-line copy of `ops_rows_out` (the run-time-operation instantiation outgrew the inliner) gave every kernel of the family a call frame — 1440 bytes of scratch, 131 VGPRs — and 5–10 × the time on every length between the maps, paired or not; `-Rpass-analysis=kernel-resource-usage` over the whole library is the check that was missing | `python tools/perf_real_sweep.py …` |
 
 Real rows beside the reference (ratio = this library ÷ reference, geometric mean over the sweep; the reference's time is the same-process one where it was taken, else the first session's):
