@@ -623,3 +623,29 @@ def test_two_real_rows_per_transform_with_zero_padding(run, shape, pads):
     res = convpad.zeropad_semantics_case(run, shape, pads, r2c=True)
     for k, v in res.items():
         assert (v is True) if isinstance(v, bool) else v < 3e-6, (k, res)
+
+
+@pytest.mark.parametrize("N", [13, 55, 169, 37, 111, 28])
+def test_two_real_rows_per_transform_against_one_row_per_transform(run, monkeypatch, N):
+    """the body of the device test with the chip full, on an odd number of rows: paired plan against the plan with one row per transform (R2C, DCT-II / -III / -IV)"""
+    batch = 33
+    rng = np.random.default_rng(N)
+    x = rng.uniform(-1, 1, N * batch).astype(np.float32)
+    kinds = [dict(dct=2), dict(dct=3)] + ([dict(dct=4)] if N % 2 else [])
+    if N % 2:
+        buf = np.zeros((batch, 2 * (N // 2 + 1)), np.float32); buf[:, :N] = x.reshape(batch, N)
+        kinds.append(dict(r2c=True))
+    for kw in kinds:
+        data = buf.reshape(-1) if kw.get("r2c") else x
+        monkeypatch.delenv("VKFFT_MI355X_NO_ROW_PAIRS", raising=False)
+        a = run.transform(data, (N,), batch, both=True, **kw)
+        monkeypatch.setenv("VKFFT_MI355X_NO_ROW_PAIRS", "1")
+        b = run.transform(data, (N,), batch, both=True, **kw)
+        monkeypatch.delenv("VKFFT_MI355X_NO_ROW_PAIRS", raising=False)
+        fa, fb = a[0].astype(np.float64), b[0].astype(np.float64)
+        if kw.get("r2c"):
+            fa = fa.reshape(batch, -1); fb = fb.reshape(batch, -1)
+            assert rel_l2(a[1].reshape(batch, -1)[:, :N], b[1].reshape(batch, -1)[:, :N]) < 1e-6, (N, kw)
+        else:
+            assert rel_l2(a[1], b[1]) < 1e-6, (N, kw)
+        assert rel_l2(fa, fb) < 1e-6, (N, kw)

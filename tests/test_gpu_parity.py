@@ -1106,22 +1106,43 @@ PAIRED_ROW_LENGTHS = [13, 19, 31, 55, 85, 91, 121, 169, 385, 1001, 37, 61, 127, 
 
 
 @pytest.mark.parametrize("N", PAIRED_ROW_LENGTHS)
-@pytest.mark.parametrize("batch", [1, 5, 4099])
+@pytest.mark.parametrize("batch", [1, 5])
 def test_two_real_rows_per_transform_on_device(run, oracle, monkeypatch, N, batch):
-    """PassParams::pairRows (the reference's mergeSequencesR2C, vkFFT_SharedMemory.h:40): R2C / C2R of odd length, DCT / DST-I, -II, -III and odd -IV rows
-    travel two per complex transform between the generic maps (mixed-radix, Rader and Rader-stage instances); odd row counts leave the last slot half empty;
-    against the oracle, and against the plan with one row per transform"""
+    """PassParams::pairRows (the reference's mergeSequencesR2C, vkFFT_SharedMemory.h:40): R2C / C2R of odd length, DCT-II, -III and odd -IV rows travel two per
+    complex transform between the generic maps (mixed-radix, Rader and Rader-stage instances), the DST members and DCT-I one per transform; odd row counts leave the
+    last slot half empty; against the oracle, and against the plan with one row per transform"""
     if N % 2:
         parity.check_r2c(run, oracle, (N,), batch, False)
     types = [(1, False), (2, False), (3, False), (2, True), (3, True)] + ([(4, False), (4, True)] if N % 2 else [])
     for type, dst in types:
         parity.check_r2r(run, oracle, (N,), batch, False, type, dst)
+
+
+@pytest.mark.parametrize("N", PAIRED_ROW_LENGTHS)
+def test_two_real_rows_per_transform_with_the_chip_full(run, oracle, monkeypatch, N):
+    """a chip-filling odd number of rows: the paired plan against the plan with one row per transform (the oracle's O(N^2) restatement is kept to the small batches
+    above), R2C and DCT-II / -III / -IV, forward and inverse"""
+    batch = ((1 << 21) // N) | 1
     rng = np.random.default_rng(N)
     x = rng.uniform(-1, 1, N * batch).astype(np.float32)
-    a = run.transform(x, (N,), batch, both=True, dct=2)
-    monkeypatch.setenv("VKFFT_MI355X_NO_ROW_PAIRS", "1")
-    b = run.transform(x, (N,), batch, both=True, dct=2)
-    assert rel_l2(a[0], b[0]) < 1e-6 and rel_l2(a[1], b[1]) < 1e-6
+    kinds = [dict(dct=2), dict(dct=3)] + ([dict(dct=4)] if N % 2 else [])
+    if N % 2:
+        buf = np.zeros((batch, 2 * (N // 2 + 1)), np.float32); buf[:, :N] = x.reshape(batch, N)
+        kinds.append(dict(r2c=True))
+    for kw in kinds:
+        data = buf.reshape(-1) if kw.get("r2c") else x
+        monkeypatch.delenv("VKFFT_MI355X_NO_ROW_PAIRS", raising=False)
+        a = run.transform(data, (N,), batch, both=True, **kw)
+        monkeypatch.setenv("VKFFT_MI355X_NO_ROW_PAIRS", "1")
+        b = run.transform(data, (N,), batch, both=True, **kw)
+        monkeypatch.delenv("VKFFT_MI355X_NO_ROW_PAIRS", raising=False)
+        fa, fb = a[0].astype(np.float64), b[0].astype(np.float64)
+        if kw.get("r2c"):  # the pad slots of the in-place rows are not part of the result
+            fa = fa.reshape(batch, -1); fb = fb.reshape(batch, -1)
+            assert rel_l2(a[1].reshape(batch, -1)[:, :N], b[1].reshape(batch, -1)[:, :N]) < 1e-6, (N, kw)
+        else:
+            assert rel_l2(a[1], b[1]) < 1e-6, (N, kw)
+        assert rel_l2(fa, fb) < 1e-6, (N, kw)
 
 
 @pytest.mark.parametrize("N", [9, 15, 25, 45, 75, 105, 175, 225, 343])
