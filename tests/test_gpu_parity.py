@@ -1122,7 +1122,7 @@ def test_two_real_rows_per_transform_on_device(run, oracle, monkeypatch, N, batc
 def test_two_real_rows_per_transform_with_the_chip_full(run, oracle, monkeypatch, N):
     """a chip-filling odd number of rows: the paired plan against the plan with one row per transform (the oracle's O(N^2) restatement is kept to the small batches
     above), R2C and DCT-II / -III / -IV, forward and inverse"""
-    batch = ((1 << 21) // N) | 1
+    batch = ((1 << 19) // N) | 1  # (2^19 reals: every CU busy, a second of host work per length)
     rng = np.random.default_rng(N)
     x = rng.uniform(-1, 1, N * batch).astype(np.float32)
     kinds = [dict(dct=2), dict(dct=3)] + ([dict(dct=4)] if N % 2 else [])
