@@ -1,0 +1,64 @@
+"""Compiler-hazard guard (CPU, needs hipcc): a few representative kernel instances are compiled for gfx950 and their code-object metadata is checked.
+Neither the emulator nor any parity test can see these hazards, and both have happened:
+  * a device function that outgrows the inliner is emitted ONCE out of line, and every kernel that calls it gets a call frame — 1.4 KB of scratch, 130 VGPRs —
+    (round 4: the map loops between the instance transforms; 5-10x the time on 1 668 kernels);
+  * operands of per-element tests kept live across a persistent tile loop spill scalar registers in the instance that is already at the limit
+    (round 4: the 8192-point Bluestein row kernel, 60 lane moves, 11 %)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+SRC = r'''
+#include "kernel_mixed.h"
+#include "kernel_pow2.h"
+namespace vkfft_mi355x {
+static const MixedVariant kTable[] = {
+VKFFT_MX(float, false, 13, 13, 1, 1, 1, 13, 20)
+VKFFT_MX(float, false, 11, 1, 1, 1, 1, 1, 64)
+VKFFT_MX(float, false, 19, 8, 1, 1, 1, 10, 32)
+VKFFT_MX(double, true, 9, 5, 1, 1, 1, 9, 16)
+};
+const MixedVariant* resource_probe_table(int* count) { *count = 4; return kTable; }
+template __global__ void pow2_blue_kernel<float, Pow2Sched<4, 3, 3, 3>, 1>(const PassParams);
+}
+'''
+
+
+def _kernels(asm):
+    """{mangled name: (body text, private segment bytes, vgprs)} of every kernel in a device assembly listing"""
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", asm):
+        meta[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    out = {}
+    for name, (priv, vgpr) in meta.items():
+        i = asm.find("\n" + name + ":")
+        j = asm.find(".amdhsa_kernel", i)
+        out[name] = (asm[i:j] if i >= 0 else "", priv, vgpr)
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_representative_kernels_have_no_call_frames_scratch_or_spill_storms(tmp_path):
+    src = tmp_path / "probe.hip"
+    src.write_text(SRC)
+    asm = tmp_path / "probe.s"
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "-fPIC", f"-I{ROOT}/include", f"-I{ROOT}/vkfft_amd/csrc", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+                           str(src), "-o", str(asm)], stderr=subprocess.DEVNULL)
+    text = asm.read_text()
+    ks = _kernels(text)
+    assert len(ks) >= 9, sorted(ks)
+    assert "s_swappc_b64" not in text, "a device function is called out of line: every kernel that calls it pays a call frame"
+    for name, (body, priv, vgpr) in ks.items():
+        if "mixed_row_kernel" in name:
+            assert priv == 0, (name, priv)
+            assert "scratch_" not in body, name
+            assert vgpr <= 128, (name, vgpr)
+        if "pow2_blue_kernel" in name:
+            lanes = len(re.findall(r"v_readlane_b32|v_writelane_b32", body))
+            assert priv == 0 and lanes <= 24, (name, priv, lanes)

@@ -55,6 +55,7 @@ The power-of-two kernels did not change in this session; the table shows the box
 | `r04b_config34_with_reference_same_call.jsonl`, `r04b_sample1000_sampling_with_reference_same_call.jsonl` | configs 3 / 4 and the sampling of sample 1000 on the final sources: geometric mean {cfg:.3f} / {s1000:.3f} × the reference (first session {cfg0:.3f} / {s10000:.3f}); the build before the last (padding tests inside the loop of the 8192-point Bluestein kernel: 60 scalar-register spills) ran the sampling at 0.942 | `python tools/perf_configs.py`, `python tools/perf_sample1000.py 60` |
 | `r04b_{{r2c,dct2,dct4}}_rows_three_plans.jsonl` | real rows of 4 … 400 reals (R2C, DCT-II: step 3; DCT-IV 5 … 400: step 5), pair time in ms of three plans per odd length — default (two rows per transform), `VKFFT_MI355X_NO_ROW_PAIRS=1` (one row per transform), `VKFFT_MI355X_PAIR_PREFER=1` (pairs also where a fused-map instance exists) — the reference timed in the same process on every 6th length (`ref_ms`), the first session's sweep of the same lengths beside it (`ref_ms_round4_sweep`, `ours_ms_round4_sweep`: the reference's times reproduce within 2 %) | `python tools/perf_real_sweep.py <r2c|dct2|dct4> 6` |
 | `r04b_real_rows_selected.jsonl` | DCT-IV 1451 / 1125 / 235 / 30 / 20, R2C and DCT-II 235 / 169 / 28, R2C 4095 / 4096, DCT-II 4096 with the reference in the same process (taken one build before the final one, sources `d125190384712dd0`) | `python tools/perf_real_rows.py 14:1451 …` |
+| `r04b_kernel_resources.json` | registers, scratch and occupancy of ALL 7 178 kernel instances of the final sources (per family: VGPR range, instances with scratch, waves per SIMD; the instances with scratch listed): the register-lean rows 128 VGPRs, the pipelined fused kernels 241–256, `mixed_row_kernel<OPS = 1>` 28 of 1 670 instances with 20–36 bytes of scratch (radix 23 … 31 butterflies), no out-of-line call anywhere; `tests/test_kernel_resources.py` keeps a sample of it in the CPU suite | `make CXXFLAGS='… -Rpass-analysis=kernel-resource-usage' 2> log; python tools/kernel_resources.py profiles/r04b_kernel_resources.json log` |
 | `r04b_real_rows_with_an_out_of_line_map_loop.jsonl` | the same sweeps on the FIRST build of the paired loops, kept as a record of a compiler hazard: one out-of-line copy of `ops_rows_out` (the run-time-operation instantiation outgrew the inliner) gave every kernel of the family a call frame — 1440 bytes of scratch, 131 VGPRs — and 5–10 × the time on every length between the maps, paired or not; `-Rpass-analysis=kernel-resource-usage` over the whole library is the check that was missing | `python tools/perf_real_sweep.py …` |
 
 Real rows beside the reference (ratio = this library ÷ reference, geometric mean over the sweep; the reference's time is the same-process one where it was taken, else the first session's):
