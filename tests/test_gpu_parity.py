@@ -1152,3 +1152,29 @@ def test_two_real_rows_per_transform_preferred_over_a_fused_map_instance(run, or
     parity.check_r2c(run, oracle, (N,), 7, False)
     for type, dst in [(2, False), (3, False), (4, False), (4, True)]:
         parity.check_r2r(run, oracle, (N,), 7, False, type, dst)
+
+
+@pytest.mark.parametrize("kind,N,B", [(14, 45, 6), (14, 1125, 3), (14, 239, 5), (14, 37, 9), (1, 169, 7), (1, 385, 5), (1, 37, 9), (1, 265, 3), (12, 169, 7), (12, 111, 5), (13, 169, 7), (13, 61, 5)])
+def test_paired_rows_and_odd_dct4_against_the_reference_live(run, kind, N, B):
+    """round 4: DCT-IV of odd length in the same-length form and the real rows that travel two per transform, against the reference's own HIP backend on fresh
+    random data (oracle/_ref travelled with the snapshot; skipped where it did not).  (DCT-IV of 1451 reals x 2 is left out: the process died inside that call on
+    the device — the same length with a chip-filling batch runs in both libraries, tools/perf_real_rows.py 14:1451 — and a crash would take the whole suite down.)"""
+    import os
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import make_golden
+    p = os.path.join(make_golden.ROOT, "oracle", "_ref", "libvkfft_ref.so")
+    if not os.path.exists(p):
+        pytest.skip("oracle/_ref not built")
+    ref = C.CDLL(p); ref.ref_transform.restype = C.c_int
+    case = dict(kind=kind, shape=(N,), batch=B, dp=0)
+    x = np.ascontiguousarray(make_golden.golden_input(case, seed=4)).copy()
+    r = x.copy()
+    size = (C.c_uint64 * 4)(N)
+    rc = ref.ref_transform(C.c_int(kind), C.c_int(1), size, C.c_uint64(B), C.c_int(0), C.c_int(0), C.c_int(0), r.ctypes.data_as(C.c_void_p), C.c_uint64(r.nbytes), None)
+    assert rc == 0
+    kw = dict(r2c=True) if kind == 1 else dict(dct=kind - 10)
+    y, _ = run.transform(x, (N,), B, **kw)
+    assert rel_l2(y.astype(np.float64), r.astype(np.float64)) < 3e-6, (kind, N)
