@@ -207,7 +207,7 @@ void FN(oracle_c2r_rows)(const REAL* in, REAL* out, uint64_t N, uint64_t rows, u
  *   type 2: even/odd reorder, same-length C2C, 2 Re(e^{-i pi k/2N} V_k)   vkFFT_R2R.h:193-229, :784-859
  *   type 3: the transpose of type 2 (pre-twiddle, inverse C2C, un-reorder) vkFFT_R2R.h:193-229, :784-859
  *   type 4: even N through an N/2-point C2C with pre/post twiddles   vkFFT_R2R.h:368,414, :861-1031
- *           odd N through a zero-padded 2N-point C2C (same result) */
+ *           odd N in the same-length form: signed permutation, N-point C2C of the real sequence, +-Re +-Im   vkFFT_R2R.h:414-481, :922-972, :1032-1272 */
 void FN(oracle_dct_strided)(REAL* data, uint64_t N, int64_t stride, int type) {
 	CPX* v = (CPX*)calloc(2 * N + 2, sizeof(CPX));
 	REAL* x = (REAL*)malloc(N * sizeof(REAL));
@@ -239,10 +239,31 @@ void FN(oracle_dct_strided)(REAL* data, uint64_t N, int64_t stride, int type) {
 				CPX c = FN(cmul)(v[k], FN(tw)((long double)k, (long double)(2 * N), -1));
 				data[(ptrdiff_t)(2 * k) * stride] = 2 * c.x; data[(ptrdiff_t)(N - 1 - 2 * k) * stride] = -2 * c.y;
 			}
-		} else {
+		} else if (N < 3) {
 			for (size_t n = 0; n < N; n++) { CPX w = FN(tw)((long double)n, (long double)(4 * N), -1); v[n].x = w.x * x[n]; v[n].y = w.y * x[n]; }
 			FN(c2c_strided)(v, 2 * N, 1, -1, 0);
 			for (size_t k = 0; k < N; k++) { CPX w = FN(tw)((long double)(2 * k + 1), (long double)(8 * N), -1); data[(ptrdiff_t)k * stride] = 2 * FN(cmul)(w, v[k]).x; }
+		} else {
+			/* odd N: the reference's same-length form — read map vkFFT_R2R.h:414-481 (position i takes element 4 i + N/2 of the row continued
+			 * evenly about -1/2 and with a sign change every 2N), signs :922-972, an N-point transform of that REAL sequence, write map and the
+			 * +-Re +-Im combination times sqrt 2 :549-699, :1032-1272.  In closed form: with r = 2n + 1 and u = 2k + 1 the kernel
+			 * cos(pi r u / 4N) sampled at r = 8 i + N is cos(2 pi i u / N + pi u / 4), so y[k] = 2 Re(e^{-i pi u / 4} Z[u mod N]). */
+			for (size_t i = 0; i < N; i++) {
+				const size_t m = 4 * i + N / 2;
+				REAL val;
+				if (m < N) val = x[m];
+				else if (m < 2 * N) val = -x[2 * N - 1 - m];
+				else if (m < 3 * N) val = -x[m - 2 * N];
+				else if (m < 4 * N) val = x[4 * N - 1 - m];
+				else val = x[m - 4 * N];
+				v[i].x = val; v[i].y = 0;
+			}
+			FN(c2c_strided)(v, N, 1, -1, 0);
+			for (size_t k = 0; k < N; k++) {
+				const size_t u = 2 * k + 1;
+				CPX w = FN(tw)((long double)(u % 8), (long double)8, -1);
+				data[(ptrdiff_t)k * stride] = 2 * FN(cmul)(w, v[u % N]).x;
+			}
 		}
 	}
 	free(v); free(x);

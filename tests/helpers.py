@@ -14,7 +14,7 @@ TOL = {
 # Per-element bounds — the reference's own metric (sample_11_precision_VkFFT_single.cpp:289-331: max / average |delta| and |delta|/|ref| per element
 # against the double-precision truth; it prints them and asserts nothing).  Stated in ULPs of the output's RMS, ulp = eps(dtype) * rms(ref):
 #   max |delta|            <= MAX_ULP ulp   (one wrong element in 2^27 moves the relative L2 by 1e-4 of nothing; it moves this by 10^6 ulp)
-#   mean |delta| / |ref|   <= AVG_EPS_ULP * eps   (complex outputs only: for real outputs E[1/|ref|] diverges)
+#   mean |delta| / |ref|   <= AVG_EPS_ULP * eps   (complex outputs only: for real outputs E[1/|ref|] diverges; elements below 2^-10 of the RMS are left out)
 MAX_ULP = {("c2c", False): 64, ("c2c", True): 72, ("bluestein", False): 192, ("bluestein", True): 216, ("real", False): 128, ("real", True): 216}
 AVG_EPS_ULP = {("c2c", False): 24, ("c2c", True): 27, ("bluestein", False): 72, ("bluestein", True): 81, ("real", False): 48, ("real", True): 81}
 
@@ -28,7 +28,7 @@ def element_errors(y, ref):
     d = np.abs(y.astype(np.complex128 if np.iscomplexobj(ref) else np.float64) - ref.astype(np.complex128 if np.iscomplexobj(ref) else np.float64))
     mag = np.abs(ref.astype(np.complex128 if np.iscomplexobj(ref) else np.float64))
     rms = max(float(np.sqrt(np.mean(mag ** 2))), 1e-300)
-    nz = mag > 0
+    nz = mag > rms * 2.0 ** -10  # (elements 60 dB below the RMS are left out of the mean: with a reference value next to zero the quotient is unbounded — seen once in 1 700 fuzz cases, a 13 x 2 R2C plane of 14 bins: mean 48.8 eps from ONE bin)
     return float(d.max() / (eps * rms)), float(np.mean(d[nz] / mag[nz]) / eps) if nz.any() else 0.0
 
 

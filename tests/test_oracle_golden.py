@@ -51,6 +51,20 @@ def test_oracle_r2r(oracle, type, dst, shape):
     assert rel_l2(oracle.r2r(x, shape, 2, type, dst), oracle.truth_r2r(x, shape, 2, type, dst)) < 1e-13
 
 
+@pytest.mark.parametrize("N", [3, 5, 7, 9, 11, 13, 15, 21, 45, 105, 239, 1125, 1451])
+@pytest.mark.parametrize("dst", [False, True])
+def test_oracle_dct4_of_odd_length_same_length_form(oracle, N, dst):
+    """the reference's same-length algorithm for DCT-IV / DST-IV of odd length (vkFFT_R2R.h:414-481, 922-972, 1032-1272) as the oracle restates it, in both
+    precisions against the double truth (also inside a plane)"""
+    rng = np.random.default_rng(N)
+    x = rng.uniform(-1, 1, 3 * N)
+    assert rel_l2(oracle.r2r(x, (N,), 3, 4, dst), oracle.truth_r2r(x, (N,), 3, 4, dst)) < 1e-13
+    assert rel_l2(oracle.r2r(x.astype(np.float32), (N,), 3, 4, dst), oracle.truth_r2r(x.astype(np.float32), (N,), 3, 4, dst)) < 2e-6
+    if N <= 45:
+        y = rng.uniform(-1, 1, 2 * N * 6)
+        assert rel_l2(oracle.r2r(y, (N, 6), 2, 4, dst), oracle.truth_r2r(y, (N, 6), 2, 4, dst)) < 1e-13
+
+
 def _truth_for_case(oracle, mod, case, x):
     """double-precision ground truth of a golden case, in the buffer layout the library returns."""
     shape, b = case["shape"], case["batch"]
