@@ -166,6 +166,13 @@ def main():
     other.copy_(buf)
     copy_ms = min(timed(lambda: other.copy_(buf), 10) for _ in range(2))
     copy_GBps = GIB2 / (copy_ms * 1e-3) / 1e9
+    # ... and the library's own streaming copy (16 bytes per lane, non-temporal on both sides: extension vkfftMI355XStreamCopy)
+    lib = api.load()
+    own = lambda: lib.vkfftMI355XStreamCopy(other.data_ptr(), buf.data_ptr(), 8 << TOTAL_LOG2, stream if stream else None)
+    own()
+    own_ms = min(timed(own, 10) for _ in range(2))
+    own_GBps = GIB2 / (own_ms * 1e-3) / 1e9
+    copy_ok = bool(torch.equal(other, buf))
     del other
     for k in range(KMIN, KMAX + 1):
         ms = timed(lambda: (apps[k].forward(), apps[k].inverse()), reps)
@@ -196,7 +203,8 @@ def main():
     roofline = dict(bound="hbm", kernel=dom, time_share=round(fam_time[dom] / sum(fam_time.values()), 3), size_log2N=kd,
                     launches_per_transform=per_size[kd]["launches"], launch_ms=round(launch_ms, 5),
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                    copy_GBps_same_box=round(copy_GBps, 1), frac_of_copy=round(achieved / copy_GBps, 4), traffic=None)
+                    copy_GBps_same_box=round(copy_GBps, 1), copy_GBps_own_float4=round(own_GBps, 1) if copy_ok else None,
+                    frac_of_copy=round(achieved / max(copy_GBps, own_GBps), 4), traffic=None)
     # HBM-side bytes per launch from the PMC passes (tools/pmc_probe.py -> tools/summarize_profiles.py); valid only for the build they were
     # collected on, so the newest summary is used only when its source hash is the one of the sources this library was built from
     import glob
@@ -208,9 +216,14 @@ def main():
         if pj.get("source_hash") != api.source_hash():
             roofline["traffic_source"] = f"null: {os.path.basename(prof)} was collected on other sources ({pj.get('source_hash')} vs {api.source_hash()})"
             break
-        roofline["traffic"] = pj.get(dom.split("<")[0], {}).get("bytes_per_launch")
-        roofline["traffic_source"] = (f"profiles/{os.path.basename(prof)} (rocprofv3 --pmc, separate passes, sources {pj.get('source_hash')}; "
-                                      "L2<->fabric requests: Infinity-Cache hits included)")
+        inst = pj.get("by_log2N", {}).get(str(kd))  # the instance bench.py launches at the size the roofline names (not a family's largest figure)
+        if inst and dom.split("<")[0] in inst.get("kernel", ""):
+            roofline["traffic"] = inst.get("bytes_per_launch")
+            roofline["traffic_fetch"] = inst.get("fetch_bytes_corrected"); roofline["traffic_write"] = inst.get("write_bytes")
+            roofline["traffic_source"] = (f"profiles/{os.path.basename(prof)} by_log2N[{kd}] = {inst.get('kernel', '')[:90]} (rocprofv3 --pmc, separate passes, sources "
+                                          f"{pj.get('source_hash')}; L2<->fabric requests: Infinity-Cache hits included)")
+        else:
+            roofline["traffic_source"] = f"null: {os.path.basename(prof)} holds no counters for the instance launched at 2^{kd}"
         break
 
     # ---- CPU baseline (rank 0, N=1 only) ------------------------------------------------------------------------

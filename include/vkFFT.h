@@ -395,6 +395,11 @@ VKFFT_API void vkfftMI355XStructSizes(pfUINT out[4]);
  * kernel families, comma separated, into names[0..cap) (NUL terminated, truncated if cap is too small; names may be NULL). */
 VKFFT_API int vkfftMI355XDescribePlan(const VkFFTApplication* app, int inverse, char* names, pfUINT cap);
 
+/* Extension (not in the reference; measurement only): the library's own streaming device-to-device copy of `bytes` bytes (a multiple of 16, both
+ * pointers 16-byte aligned), 16 bytes per lane, enqueued on `stream` (a hipStream_t, NULL = the default stream).  bench.py times it beside the
+ * transforms: what a plain copy of the same buffer reaches on the same GPU is the practical ceiling of the HBM roofline.  Returns a VkFFTResult. */
+VKFFT_API int vkfftMI355XStreamCopy(void* dst, const void* src, pfUINT bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -243,7 +243,7 @@ CONV_ZEROPAD_CASES = [
 ]
 
 
-def zeropad_semantics_case(run, shape, pads, *, r2c=False, dp=False, seed=0):
+def zeropad_semantics_case(run, shape, pads, *, r2c=False, dp=False, seed=0, kernel=None):
     """What the reference's zero padding promises besides the values (vkFFT_Zeropad.h:28, vkFFT_Plan_FFT.h:522-560, API guide "Zero padding parameters"):
     the padded range of the SOURCE is never read — so it is never written either, also when the source is a separate input buffer —, the inverse of
     a spatially padded plan does not write the padded range of its result, and sequences inside the padded range of an axis still to come are not
@@ -273,6 +273,8 @@ def zeropad_semantics_case(run, shape, pads, *, r2c=False, dp=False, seed=0):
         for i in range(nd):
             acc *= shape[i]; strides[i] = acc
         app = api.App(list(shape), 1, buffer_ptr=pout, isInputFormatted=1, inputBuffer=pin, inputBufferStride=strides, **kw)
+        if kernel is not None:  # the kernel family the plan is expected to take (extension vkfftMI355XDescribePlan)
+            out["kernel_" + kernel] = bool(kernel in app.launch_info()[1])
         app.forward()
         out["fwd_out_of_place"] = rel_l2(run._fetch(hout, ct).reshape(x.shape), want)
         out["input_untouched"] = bool((run._fetch(hin, ct).reshape(x.shape).view(rt) == x.view(rt)).all())
@@ -360,4 +362,8 @@ ZEROPAD_SEMANTICS_CASES = [
     dict(shape=(1 << 16,), pads={0: (1 << 15, 1 << 16)}),                             # two passes (the fused Four-Step kernel has no masks: separate passes)
     dict(shape=(1 << 16,), pads={0: (1 << 14, 3 << 14)}),                             # an inner aligned range
     dict(shape=(1 << 14, 4), pads={0: (1 << 13, 1 << 14), 1: (2, 4)}, dp=True),
+    # round 5 (advisor): padded rows that only the fused power-of-two Bluestein kernel serves (padded length = the interpreter's whole LDS and more)
+    dict(shape=(8150,), pads={0: (4075, 8150)}, kernel="pow2_blue_kernel"),
+    dict(shape=(4093,), pads={0: (2000, 4093)}, dp=True, kernel="pow2_blue_kernel"),
+    dict(shape=(1021,), pads={0: (500, 1021)}, kernel="pow2_blue_kernel"),
 ]

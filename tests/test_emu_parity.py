@@ -333,7 +333,7 @@ def test_fused_fourstep_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
 
 
-@pytest.mark.parametrize("k,variant", [(13, v) for v in range(6)] + [(14, v) for v in range(6)] + [(15, v) for v in range(4)])
+@pytest.mark.parametrize("k,variant", [(13, v) for v in range(7)] + [(14, v) for v in range(7)] + [(15, v) for v in range(5)])
 def test_register_lean_rows_every_variant(run, oracle, monkeypatch, k, variant):
     """kernel_pow2_lean.h: 32 points per thread, real / imaginary planes exchanged one after the other, in-place DIF butterflies, twiddles in chunks (with
     and without the prefetch across the exchange) — every registered shape of 2^13, 2^14 and the one-pass 2^15, next to the round-1 kernels they replace"""
@@ -366,12 +366,12 @@ def test_register_lean_row_strides_padding_and_scale(run, oracle):
     assert convpad.zeropad_case(run, (N,), {0: (N // 2, N)}, batch=2) < 3e-6
 
 
-@pytest.mark.parametrize("k,variant,batch", [(15, 0, 5), (15, 1, 5), (15, 2, 5), (16, 1, 3), (16, 2, 3), (17, 1, 3), (17, 2, 3), (18, 1, 3), (18, 2, 3), (19, 1, 2), (19, 2, 2),
-                                             (20, 1, 2), (20, 2, 2), (21, 0, 1), (21, 2, 1), (22, 0, 1), (22, 1, 1)])
+@pytest.mark.parametrize("k,variant,batch", [(15, 0, 5), (15, 1, 5), (15, 2, 5), (15, 3, 5), (16, 1, 3), (16, 2, 3), (16, 3, 3), (17, 1, 3), (17, 2, 3), (17, 3, 3), (18, 1, 3), (18, 2, 3), (18, 3, 3),
+                                             (19, 1, 2), (19, 2, 2), (19, 3, 2), (20, 1, 2), (20, 2, 2), (20, 3, 2), (21, 0, 1), (21, 1, 1), (21, 2, 1), (21, 3, 1), (22, 0, 1), (22, 1, 1), (22, 2, 1)])
 def test_fused_fourstep_every_registered_shape(run, oracle, monkeypatch, k, variant, batch):
-    """every shape in the fused Four-Step registry besides the defaults the other tests run: index 0 = what ships (2^16 ... 2^20: the software-pipelined
-    form, kernel_pow2_fused_pipe.h; 2^21 / 2^22: the register-lean form with 2048-point tiles 16 columns wide), 1 = the round-2/3 shape, 2 = the
-    register-lean plane-split form (2^21: the second round-3 shape)"""
+    """every shape in the fused Four-Step registry besides the defaults the other tests run: index 0 = what ships (2^16 ... 2^20: the packed-pair
+    software-pipelined form, kernel_pow2_fused_pk.h; 2^21 / 2^22: packed-pair tiles of two halves, kernel_pow2_fused_pkh.h), then the round-4 pipelined form,
+    the round-2/3 shape and the register-lean plane-split form (2^21 / 2^22: the second orientation, the round-4 16-column shape, the round-3 shapes)"""
     monkeypatch.setenv(f"VKFFT_MI355X_FUV{k}", str(variant))
     monkeypatch.setenv("VKFFT_MI355X_ROW15", "0")
     if k <= 18:

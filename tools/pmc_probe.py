@@ -1,5 +1,5 @@
-"""Workload for the rocprofv3 PMC passes (one counter set per pass): a calibration copy of known size, then a few launches of the
-headline kernels on the 1 GiB buffer — single-pass row kernels, the fused Four-Step kernel, and the same sizes with the fusion off."""
+"""Workload for the rocprofv3 PMC passes (one counter set per pass): a calibration copy of known size, then two forward + inverse pairs of EVERY plan
+bench.py launches (2^8 ... 2^22 on the 1 GiB buffer, default plans), so that tools/summarize_profiles.py can key the traffic by instance."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,14 +10,16 @@ buf = torch.empty(2 << 27, dtype=torch.float32, device="cuda").uniform_(-1, 1)
 dst = torch.empty_like(buf)
 for _ in range(2):
     dst.copy_(buf)          # calibration: reads 1 GiB, writes 1 GiB
+lib = api.load()
+for _ in range(2):
+    lib.vkfftMI355XStreamCopy(dst.data_ptr(), buf.data_ptr(), 8 << 27, None)
 torch.cuda.synchronize()
 del dst
-for fused in ("1", "0"):
-    os.environ["VKFFT_MI355X_FUSED"] = fused
-    for k in ((10, 12, 14, 15, 16, 18, 20, 22) if fused == "1" else (16, 20)):
-        N = 1 << k
-        app = api.App([N], (1 << 27) // N, buffer_ptr=buf.data_ptr(), normalize=True)
-        for _ in range(2):
-            app.forward(); app.inverse()
-        torch.cuda.synchronize()
-        app.delete()
+ks = [int(a) for a in sys.argv[1:]] or list(range(8, 23))
+for k in ks:
+    N = 1 << k
+    app = api.App([N], (1 << 27) // N, buffer_ptr=buf.data_ptr(), normalize=True)
+    for _ in range(2):
+        app.forward(); app.inverse()
+    torch.cuda.synchronize()
+    app.delete()

@@ -49,6 +49,20 @@ for kname, c in cnt.items():
     if "WRITE_SIZE" in c: e["write_bytes"] = c["WRITE_SIZE"] * 1024
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c: e["bytes_per_launch"] = e["fetch_bytes_corrected"] + e["write_bytes"]
     summ["kernels"][kname[:150]] = e
+# the instance of every size: log2 N from the template arguments of the kernel's name (row kernels: the bits of their schedule; fused kernels: the bits of
+# both factors; tiles of two halves: 20 + the two split flags) — bench.py reads by_log2N[size the roofline names]
+import re
+summ["by_log2N"] = {}
+for kname, e in summ["kernels"].items():
+    if "bytes_per_launch" not in e or "vkfft_mi355x::pow2_" not in kname: continue
+    m = re.search(r"pow2_fused_pkh_kernel<float, (\d), (\d)", kname)
+    if m: k = 20 + int(m.group(1)) + int(m.group(2))
+    else:
+        sch = re.findall(r"Pow2Sched<(\d+), (\d+), (\d+), (\d+)>", kname)
+        if not sch or "col" in kname or "blue" in kname: continue
+        k = sum(int(b) for t in sch for b in t)
+    summ["by_log2N"][str(k)] = dict(kernel=kname, bytes_per_launch=e["bytes_per_launch"], fetch_bytes_corrected=e["fetch_bytes_corrected"], write_bytes=e["write_bytes"],
+                                    algorithmic_bytes_per_transform=2.0 * (1 << 30))
 for fam in ("pow2_fused_kernel", "pow2_row_kernel", "pow2_col_kernel"):
     ks_ = [k for k in summ["kernels"] if fam in k and "bytes_per_launch" in summ["kernels"][k]]
     if ks_:

@@ -86,7 +86,7 @@ class VkFFTApplication(C.Structure):
 
 
 EXPORTS = ["initializeVkFFT", "VkFFTAppend", "deleteVkFFT", "VkFFTGetVersion", "getVkFFTErrorString",
-           "vkfftMI355XStructSizes", "vkfftMI355XDescribePlan"]
+           "vkfftMI355XStructSizes", "vkfftMI355XDescribePlan", "vkfftMI355XStreamCopy"]
 VKFFT_SUCCESS = 0
 _lib = None
 
@@ -130,6 +130,8 @@ def _bind(p):
     lib.vkfftMI355XStructSizes.argtypes = [C.POINTER(u64)]
     lib.vkfftMI355XDescribePlan.restype = C.c_int
     lib.vkfftMI355XDescribePlan.argtypes = [C.POINTER(VkFFTApplication), C.c_int, C.c_char_p, u64]
+    lib.vkfftMI355XStreamCopy.restype = C.c_int
+    lib.vkfftMI355XStreamCopy.argtypes = [C.c_void_p, C.c_void_p, u64, C.c_void_p]
     sizes = (u64 * 4)()
     lib.vkfftMI355XStructSizes(sizes)
     mine = [C.sizeof(VkFFTConfiguration), C.sizeof(VkFFTLaunchParams), C.sizeof(VkFFTPlan), C.sizeof(VkFFTApplication)]

@@ -80,6 +80,8 @@ VkFFTResult zero_padded_ranges(VkFFTApplication* app, bool inverse, void* base, 
 
 } // namespace
 
+namespace vkfft_mi355x { int launch_stream_copy(void* dst, const void* src, uint64_t bytes, hipStream_t stream); } // kernels_aux.hip
+
 extern "C" {
 
 VKFFT_API int VkFFTGetVersion(void) { return 10304; }
@@ -102,9 +104,15 @@ static void describe_passes(const VkFFTPlan* pl, char* names, pfUINT cap, size_t
 		launches += (int)rep;
 		if (!names || !cap) continue;
 		const char* nm = kname[q.kernel >= 0 && q.kernel < 14 ? q.kernel : 4];
+		if (q.kernel == KERNEL_POW2_FUSED) nm = pow2_fused_kernel_name(q.variant);       // (pow2_fused_kernel / _pipe_ / _pk_ / _pkh_)
+		else if (q.kernel == KERNEL_POW2_ROW) nm = pow2_row_kernel_name(q.variant);      // (pow2_row_kernel / pow2_row_lean_kernel / pow2_row_lean_pk_kernel)
 		int w = snprintf(names + pos, pos < cap ? (size_t)cap - pos : 0, "%s%s<%s>", pos ? "," : "", nm, q.dp ? "double" : "float");
 		if (w > 0) pos = std::min<size_t>(pos + (size_t)w, (size_t)cap - 1);
 	}
+}
+
+VKFFT_API int vkfftMI355XStreamCopy(void* dst, const void* src, pfUINT bytes, void* stream) {
+	return vkfft_mi355x::launch_stream_copy(dst, src, (uint64_t)bytes, (hipStream_t)stream) == 0 ? VKFFT_SUCCESS : VKFFT_ERROR_FAILED_TO_LAUNCH_KERNEL;
 }
 
 VKFFT_API int vkfftMI355XDescribePlan(const VkFFTApplication* app, int inverse, char* names, pfUINT cap) {

@@ -195,6 +195,7 @@ constexpr uint32_t kFusedMaxQueues = 8;
 struct FusedParams {
 	const void* in; void* out; void* scratch; uint32_t* ctr;
 	const void* lutA; const void* lutB; const void* tw4; // stage twiddles of the two factors, two-level Four-Step table
+	const void* rowTab;   // packed-pair kernels (kernel_pow2_pk.h): n0 16-byte entries (1, Re w_N^k, 0, Im w_N^k), k < n0 (fp32 only, else nullptr)
 	int64_t inBatchStride, outBatchStride; // complex elements between consecutive transforms
 	uint32_t fsLoBits;
 	uint32_t n0, n1, batch;

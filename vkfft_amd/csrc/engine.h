@@ -35,7 +35,7 @@ struct PassPlan {
 	size_t lutOff = (size_t)-1, auxOff = (size_t)-1, aux2Off = (size_t)-1, aux3Off = (size_t)-1, raderOff = (size_t)-1;
 	// fused Four-Step launch (KERNEL_POW2_FUSED): parameter block (pointers bound at launch) and its extra arena offsets
 	FusedParams fused = {};
-	size_t fusedLutBOff = (size_t)-1, fusedCtrOff = (size_t)-1;
+	size_t fusedLutBOff = (size_t)-1, fusedCtrOff = (size_t)-1, fusedRowTabOff = (size_t)-1;
 	int fusedWgPerCu = 0; // 0: what the occupancy query reports
 	bool auxIsKernel = false; // merged convolution pass: aux2 is bound to the caller's kernel buffer at launch (LaunchBuffers::kernel)
 	std::string label;
@@ -127,6 +127,9 @@ bool pow2_blue_lookup(uint32_t log2m, bool dp, int* variant, int bits[4], int* f
 // fused Four-Step of 2^log2n = 2^la * 2^lb (kernels_fused.hip)
 bool pow2_fused_lookup(uint32_t log2n, bool dp, int mode, int* variant, int* la, int* lb, int bitsA[4], int bitsB[4], int* tca, int* tcb, int* threads, int* wgPerCu);
 int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t stream);
+// the __global__ function behind a registry entry (vkfftMI355XDescribePlan: bench labels, rocprofv3 kernel names)
+const char* pow2_fused_kernel_name(int variant);
+const char* pow2_row_kernel_name(int variant);
 bool mixed_row_lookup(uint64_t n, bool dp, int* variant, int rad[5], int* fpw, int* threads);
 int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 // one-kernel cyclic convolution (kernel_mixconv.h), unit-stride rows or (col) tiles of neighbouring columns of a strided axis.  rader: the instance of prime p (transform length p - 1); otherwise the Bluestein instance with

@@ -155,6 +155,7 @@ inline unsigned pow2_num_cus() { // CUs of the CURRENT device (plans are made an
 struct Pow2Variant {
 	int log2n; bool dp; int bits[4]; int fpw; int threads; // fpw: FFTs per workgroup (row) / columns per workgroup (col)
 	void (*launch)(const PassParams&, dim3, hipStream_t);
+	const char* name = nullptr; // the __global__ function behind the entry when it is not the family's first (vkfftMI355XDescribePlan, bench labels)
 };
 
 } // namespace vkfft_mi355x

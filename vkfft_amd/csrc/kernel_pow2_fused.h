@@ -358,6 +358,7 @@ struct Pow2FusedVariant {
 	int log2n; bool dp; int mode; int la, lb; int bitsA[4], bitsB[4]; int tca, tcb, threads, wgPerCu; // la, lb: log2 of the two factors; wgPerCu: workgroups per CU the kernel is launched with (resources, or a measured cap below them)
 	void (*launch)(const FusedParams&, dim3, hipStream_t);
 	const void* fn;
+	const char* name = nullptr; // the __global__ function behind the entry when it is not pow2_fused_kernel (vkfftMI355XDescribePlan, bench labels)
 };
 
 template <typename T, typename SA, int TCA, typename SB, int TCB, int MODE, int TWL, int CPT, int LEAN = 0> void pow2_fused_launch(const FusedParams& prm, dim3 grid, hipStream_t s) {

@@ -249,6 +249,7 @@ int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, cons
 			f.out = (char*)bufs.base[pp.outRole] + pp.outOffset * pp.outElemBytes;
 			f.scratch = bufs.base[ROLE_TEMP];
 			f.lutA = ar + pp.lutOff; f.lutB = ar + pp.fusedLutBOff; f.tw4 = ar + pp.auxOff;
+			f.rowTab = pp.fusedRowTabOff != (size_t)-1 ? ar + pp.fusedRowTabOff : nullptr;
 			f.ctr = (uint32_t*)((char*)plan.dArena + pp.fusedCtrOff);
 			if (sweep) { f.reverse = *sweep & 1u; *sweep ^= 1u; }
 			int r = launch_pow2_fused(pp, f, stream);

@@ -13,6 +13,16 @@ namespace vkfft_mi355x {
 
 constexpr int kConvMaxMatrix = 8;
 
+static unsigned pow2_num_cus_aux() { // CUs of the current device
+#if defined(VKFFT_HOSTEMU)
+	return 4;
+#else
+	int dev = 0, v = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return 256;
+	return (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? (unsigned)v : 256u;
+#endif
+}
+
 template <typename T> __global__ void __launch_bounds__(256) conv_pointwise_kernel(const ConvParams p) {
 	const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (e >= p.systemStride) return;
@@ -162,6 +172,34 @@ int launch_transpose(const PassPlan& pp, const PassParams& prm, hipStream_t stre
 	if (blocks > 0x7fffffffull) return 4039;
 	if (pp.dp) hipLaunchKernelGGL(transpose_kernel<double>, dim3((uint32_t)blocks), dim3(256), 0, stream, prm);
 	else hipLaunchKernelGGL(transpose_kernel<float>, dim3((uint32_t)blocks), dim3(256), 0, stream, prm);
+	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
+
+// ---- the library's own streaming copy (extension vkfftMI355XStreamCopy): 16 bytes per lane, four transfers in flight per lane, non-temporal hint on
+// both sides, persistent grid — the practical HBM ceiling the roofline fractions of bench.py are quoted against next to torch's copy kernel
+struct alignas(16) Copy16 { uint32_t x, y, z, w; };
+__global__ void __launch_bounds__(256) stream_copy_kernel(const Copy16* __restrict__ src, Copy16* __restrict__ dst, const uint64_t n16) {
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#if defined(VKFFT_HOSTEMU)
+	for (; i < n16; i += stride) dst[i] = src[i];
+#else
+	typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+	const u4* s4 = (const u4*)src; u4* d4 = (u4*)dst;
+	for (; i + 3 * stride < n16; i += 4 * stride) {
+		const u4 a = __builtin_nontemporal_load(s4 + i), b = __builtin_nontemporal_load(s4 + i + stride), c = __builtin_nontemporal_load(s4 + i + 2 * stride), d = __builtin_nontemporal_load(s4 + i + 3 * stride);
+		__builtin_nontemporal_store(a, d4 + i); __builtin_nontemporal_store(b, d4 + i + stride); __builtin_nontemporal_store(c, d4 + i + 2 * stride); __builtin_nontemporal_store(d, d4 + i + 3 * stride);
+	}
+	for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + i), d4 + i);
+#endif
+}
+int launch_stream_copy(void* dst, const void* src, uint64_t bytes, hipStream_t stream) {
+	if (bytes % 16 || ((uintptr_t)dst | (uintptr_t)src) % 16) return 4039;
+	if (!bytes) return 0;
+	const uint64_t n16 = bytes / 16;
+	uint64_t grid = (uint64_t)pow2_num_cus_aux() * 8u;
+	if (grid > (n16 + 255) / 256) grid = (n16 + 255) / 256;
+	hipLaunchKernelGGL(stream_copy_kernel, dim3((uint32_t)grid), dim3(256), 0, stream, (const Copy16*)src, (Copy16*)dst, n16);
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
 }
 

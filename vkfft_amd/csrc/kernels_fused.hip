@@ -2,11 +2,14 @@
 #include "engine.h"
 #include "kernel_pow2_fused.h"
 #include "kernel_pow2_fused_pipe.h"
+#include "kernel_pow2_fused_pk.h"
+#include "kernel_pow2_fused_pkh.h"
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
 #include <algorithm>
 #include <atomic>
+#include <string>
 
 namespace vkfft_mi355x {
 
@@ -38,7 +41,24 @@ constexpr int fused_min(int a, int b) { return a < b ? a : b; }
 	{ (a0) + (a1) + (a2) + (b0) + (b1) + (b2), dp, 2, (a0) + (a1) + (a2), (b0) + (b1) + (b2), {a0, a1, a2, 0}, {b0, b1, b2, 0}, tca, tcb, \
 	  ((1 << ((a0) + (a1) + (a2))) >> Pow2Sched<a0, a1, a2, 0>::LOGE) * (tca) / 2, pow2_fused_pipe_wg_per_cu<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, twl, wgc>(), \
 	  &pow2_fused_pipe_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, 2, twl, wgc>, \
-	  (const void*)&pow2_fused_pipe_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, 2, twl, wgc> }
+	  (const void*)&pow2_fused_pipe_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, 2, twl, wgc>, "pow2_fused_pipe_kernel" }
+// the same on packed pairs (kernel_pow2_fused_pk.h, round 5): half the vector instructions, 150 registers
+#if defined(VKFFT_MI355X_DEV)
+#define VKFFT_FUK(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, wgc) VKFFT_FUKM(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, wgc, 2), VKFFT_FUKM(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, wgc, 6)
+#define VKFFT_FUH(splita, splitb, twl) VKFFT_FUHM(splita, splitb, twl, 2), VKFFT_FUHM(splita, splitb, twl, 6)
+#else
+#define VKFFT_FUK(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, wgc) VKFFT_FUKM(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, wgc, 2)
+#define VKFFT_FUH(splita, splitb, twl) VKFFT_FUHM(splita, splitb, twl, 2)
+#endif
+#define VKFFT_FUKM(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, wgc, mode) \
+	{ (a0) + (a1) + (a2) + (b0) + (b1) + (b2), dp, mode, (a0) + (a1) + (a2), (b0) + (b1) + (b2), {a0, a1, a2, 0}, {b0, b1, b2, 0}, tca, tcb, \
+	  ((1 << ((a0) + (a1) + (a2))) >> Pow2Sched<a0, a1, a2, 0>::LOGE) * (tca) / 2, pow2_fused_pk_wg_per_cu<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, twl, wgc>(), \
+	  &pow2_fused_pk_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, wgc>, \
+	  (const void*)&pow2_fused_pk_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, wgc>, "pow2_fused_pk_kernel" }
+// tiles of two halves on packed pairs (kernel_pow2_fused_pkh.h, round 5): 2^21 / 2^22, a 2048-point factor as two interleaved 1024-point halves + one radix-2 layer
+#define VKFFT_FUHM(splita, splitb, twl, mode) \
+	{ 20 + (splita) + (splitb), false, mode, 10 + (splita), 10 + (splitb), {4, 3, 3, splita}, {4, 3, 3, splitb}, (splita) ? 16 : 32, (splitb) ? 16 : 32, 512, 1, \
+	  &pow2_fused_pkh_launch<float, splita, splitb, mode, twl>, (const void*)&pow2_fused_pkh_kernel<float, splita, splitb, mode, twl>, "pow2_fused_pkh_kernel" }
 #define VKFFT_FUT(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, 1)
 #define VKFFT_FU(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 1)
 #define VKFFT_FU2(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 2) /* two columns per thread */
@@ -49,31 +69,39 @@ static const Pow2FusedVariant kPow2FusedVariants[] = {
 	// Round 4: the software-pipelined form (kernel_pow2_fused_pipe.h) for 2^16 ... 2^20: +4 % (2^18) ... +15 % (2^17) over the round-2/3 shapes that
 	// follow it (two adjacent columns per thread; one column per thread; register-lean plane-split form without the pipelining).
 	// 2^15 = 128 x 256 (only with VKFFT_MI355X_ROW15=0: 2^15 ships as ONE pass of the register-lean row kernel, 4.2 against 3.2-3.5 TB/s)
+	VKFFT_FUK(float, false, 4, 3, 0, 32, 4, 4, 0, 16, 1, 4),
 	VKFFT_FUP(float, false, 4, 3, 0, 32, 4, 4, 0, 16, 1, 4),
 	VKFFT_FU2(float, false, 4, 3, 0, 32, 4, 4, 0, 16),
 	VKFFT_FUL(float, false, 4, 3, 0, 32, 4, 4, 0, 16, 1),
 	// 2^16 = 256 x 256
+	VKFFT_FUK(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 1, 2),
 	VKFFT_FUP(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 1, 2),
 	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 4, 0, 32),
 	VKFFT_FUL(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 1),
 	// 2^17 = 256 x 512
+	VKFFT_FUK(float, false, 4, 4, 0, 32, 4, 3, 2, 16, 1, 2),
 	VKFFT_FUP(float, false, 4, 4, 0, 32, 4, 3, 2, 16, 1, 2),
 	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
 	VKFFT_FUL(float, false, 4, 4, 0, 32, 4, 3, 2, 16, 1),
 	// 2^18 = 512 x 512
+	VKFFT_FUK(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 2),
 	VKFFT_FUP(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 2),
 	VKFFT_FU2(float, false, 4, 3, 2, 16, 4, 3, 2, 16),
 	VKFFT_FULC(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 2),
 	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: 128 KiB tiles, one workgroup per CU (512 threads x 256 registers = the whole register file: one tile
 	// computing + one tile in flight); 8-column tiles (two workgroups per CU, 64-byte segments on the HBM side) measured 12 % slower, 2^20 as
 	// 512 x 2048 20 % slower, the plane-split form at two workgroups per CU without the pipelining 7-16 % slower (it is VALU/LDS-bound, r04 profile)
+	VKFFT_FUK(float, false, 4, 3, 2, 32, 4, 3, 3, 16, 1, 1),
 	VKFFT_FUP(float, false, 4, 3, 2, 32, 4, 3, 3, 16, 1, 1),
 	VKFFT_FU2(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
 	VKFFT_FUL(float, false, 4, 3, 2, 32, 4, 3, 3, 16, 0),
+	VKFFT_FUK(float, false, 4, 3, 3, 16, 4, 3, 3, 16, 1, 1),
 	VKFFT_FUP(float, false, 4, 3, 3, 16, 4, 3, 3, 16, 1, 1),
 	VKFFT_FU2(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
 	VKFFT_FUL(float, false, 4, 3, 3, 16, 4, 3, 3, 16, 0),
 	// register-lean (round 4): 2048-point tiles 16 columns wide (128-byte segments), 1024 threads, 139 KiB planes: 2^21 +4.5 %, 2^22 +29 % over the 8-column shapes below
+	// round 5: tiles of two halves, software-pipelined at half-tile granularity (2^21 = 2048 x 1024 — the other orientation measured the same —, 2^22 = 2048 x 2048)
+	VKFFT_FUH(1, 0, 1), VKFFT_FUH(1, 1, 1),
 	VKFFT_FUL(float, false, 4, 3, 3, 32, 4, 4, 3, 16, 0),
 	VKFFT_FUL(float, false, 4, 4, 3, 16, 4, 4, 3, 16, 0),
 	VKFFT_FUT(float, false, 5, 5, 0, 16, 5, 3, 3, 8, 0),
@@ -110,6 +138,11 @@ bool pow2_fused_lookup(uint32_t log2n, bool dp, int mode, int* variant, int* la,
 	*variant = found; *la = v.la; *lb = v.lb; *tca = v.tca; *tcb = v.tcb; *threads = v.threads; *wgPerCu = v.wgPerCu;
 	for (int k = 0; k < 4; k++) { bitsA[k] = v.bitsA[k]; bitsB[k] = v.bitsB[k]; }
 	return true;
+}
+
+const char* pow2_fused_kernel_name(int variant) {
+	if (variant < 0 || variant >= kNumPow2FusedVariants || !kPow2FusedVariants[variant].name) return "pow2_fused_kernel";
+	return kPow2FusedVariants[variant].name;
 }
 
 int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t stream) {
@@ -150,6 +183,11 @@ int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t st
 		double sum[12] = {};
 		for (uint64_t w = 0; w < grid; w++) for (int i = 0; i < 12; i++) sum[i] += (double)h[w * 12 + i];
 		const double nt = sum[7] > 0 ? sum[7] : 1;
+		if (v.name && (std::string(v.name) == "pow2_fused_pk_kernel" || std::string(v.name) == "pow2_fused_pkh_kernel")) // (the packed kernels' own phase cut)
+			fprintf(stderr, "[fused profile %s] grid %llu tickets/wg %.1f | cycles per ticket: S1 %.0f  decode+Breq %.0f  A-landed %.0f  waitA %.0f  A-stages %.0f  A-twiddle %.0f  A-turn+stores %.0f  stores-issued %.0f  drain %.0f  S3 %.0f  B-phase %.0f | total %.0f\n",
+			        v.name, (unsigned long long)grid, nt / grid, sum[0] / nt, sum[3] / nt, sum[1] / nt, sum[5] / nt, sum[8] / nt, sum[9] / nt, sum[10] / nt, sum[2] / nt, sum[6] / nt, sum[11] / nt, sum[4] / nt,
+			        (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6] + sum[8] + sum[9] + sum[10] + sum[11]) / nt);
+		else
 		fprintf(stderr, "[fused profile] grid %llu tickets/wg %.1f | cycles per ticket: S1 %.0f  A-load %.0f  A-stages %.0f A-twiddle %.0f A-transpose %.0f A-stores %.0f  B-load %.0f  B-compute %.0f  waitA %.0f waitB %.0f | total %.0f\n",
 		        (unsigned long long)grid, nt / grid, sum[0] / nt, sum[1] / nt, sum[8] / nt, sum[9] / nt, sum[10] / nt, sum[2] / nt, sum[3] / nt, sum[4] / nt, sum[5] / nt, sum[6] / nt, (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6] + sum[8] + sum[9] + sum[10]) / nt);
 		return 0;

@@ -2,6 +2,7 @@
 // unit, so that the other units that use the kernel templates (fused Four-Step, Bluestein-wrapped real transforms) do not compile them again.
 #include "engine.h"
 #include "kernel_pow2.h"
+#include "kernel_pow2_pk.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -28,7 +29,11 @@ template <typename T, typename SCH, int TC> void pow2_col_launch(const PassParam
 
 // register-lean rows (kernel_pow2_lean.h): 32 points per thread, one row per workgroup, wpe waves per SIMD, twiddles twg at a time
 #define VKFFT_P2L(T, dp, b0, b1, b2, b3, wpe, twg, pfn) \
-	{ (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, 1, ((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE), &pow2_row_lean_launch<T, Pow2Sched<b0, b1, b2, b3>, wpe, twg, pfn> }
+	{ (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, 1, ((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE), &pow2_row_lean_launch<T, Pow2Sched<b0, b1, b2, b3>, wpe, twg, pfn>, "pow2_row_lean_kernel" }
+
+// the same on packed (x, y) register pairs (kernel_pow2_pk.h, round 5)
+#define VKFFT_P2K(T, dp, b0, b1, b2, b3, wpe, twg) \
+	{ (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, 1, ((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE), &pow2_row_lean_pk_launch<T, Pow2Sched<b0, b1, b2, b3>, wpe, twg>, "pow2_row_lean_pk_kernel" }
 
 // first entry of each (log2n, dp) is the default; VKFFT_MI355X_P2V<log2n>=k selects the k-th (tuning)
 static const Pow2Variant kPow2Variants[] = {
@@ -45,11 +50,11 @@ static const Pow2Variant kPow2Variants[] = {
 	VKFFT_P2(float, false, 5, 5, 1, 0, 2), VKFFT_P2(float, false, 4, 4, 3, 0, 1), VKFFT_P2(float, false, 4, 4, 3, 0, 2), VKFFT_P2(float, false, 5, 5, 1, 0, 4), VKFFT_P2(float, false, 4, 4, 3, 0, 4),
 	VKFFT_P2(float, false, 4, 4, 4, 0, 1), VKFFT_P2(float, false, 5, 5, 2, 0, 1), VKFFT_P2(float, false, 4, 4, 4, 0, 2), VKFFT_P2(float, false, 5, 5, 2, 0, 2),
 	// 2^13 (P2V13 = 0 .. 5): register-lean rows, four 256-thread workgroups per CU; index 1 is the round-1..3 kernel (two 67 KiB workgroups per CU)
-	VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 16, 0), VKFFT_P2(float, false, 5, 4, 4, 0, 1), VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 16, 16), VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 8, 16), VKFFT_P2L(float, false, 5, 5, 3, 0, 4, 16, 16), VKFFT_P2(float, false, 4, 3, 3, 3, 1),
+	VKFFT_P2K(float, false, 5, 4, 4, 0, 4, 16), VKFFT_P2(float, false, 5, 4, 4, 0, 1), VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 16, 0), VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 16, 16), VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 8, 16), VKFFT_P2L(float, false, 5, 5, 3, 0, 4, 16, 16), VKFFT_P2(float, false, 4, 3, 3, 3, 1),
 	// 2^14: register-lean rows, two 512-thread workgroups per CU; index 1 is the round-1..3 kernel (one 135 KiB workgroup per CU)
-	VKFFT_P2L(float, false, 5, 5, 4, 0, 4, 16, 0), VKFFT_P2(float, false, 5, 5, 4, 0, 1), VKFFT_P2L(float, false, 5, 5, 4, 0, 4, 16, 16), VKFFT_P2L(float, false, 5, 5, 4, 0, 4, 8, 16), VKFFT_P2L(float, false, 5, 4, 5, 0, 4, 16, 16), VKFFT_P2(float, false, 4, 4, 3, 3, 1),
+	VKFFT_P2K(float, false, 5, 5, 4, 0, 4, 16), VKFFT_P2(float, false, 5, 5, 4, 0, 1), VKFFT_P2L(float, false, 5, 5, 4, 0, 4, 16, 0), VKFFT_P2L(float, false, 5, 5, 4, 0, 4, 16, 16), VKFFT_P2L(float, false, 5, 5, 4, 0, 4, 8, 16), VKFFT_P2L(float, false, 5, 4, 5, 0, 4, 16, 16), VKFFT_P2(float, false, 4, 4, 3, 3, 1),
 	// 2^15 in ONE pass: 1024 threads x 32 points in registers, the 135 KiB plane is all of a CU's LDS budget (VKFFT_MI355X_ROW15=0: the fused two-pass kernel)
-	VKFFT_P2L(float, false, 5, 5, 5, 0, 4, 16, 0), VKFFT_P2L(float, false, 5, 5, 5, 0, 4, 16, 16), VKFFT_P2L(float, false, 5, 5, 5, 0, 4, 16, 8), VKFFT_P2L(float, false, 5, 5, 5, 0, 4, 8, 16),
+	VKFFT_P2K(float, false, 5, 5, 5, 0, 4, 16), VKFFT_P2L(float, false, 5, 5, 5, 0, 4, 16, 0), VKFFT_P2L(float, false, 5, 5, 5, 0, 4, 16, 16), VKFFT_P2L(float, false, 5, 5, 5, 0, 4, 16, 8), VKFFT_P2L(float, false, 5, 5, 5, 0, 4, 8, 16),
 	// fp64
 	VKFFT_P2(double, true, 2, 0, 0, 0, 64),
 	VKFFT_P2(double, true, 3, 0, 0, 0, 64),
@@ -157,6 +162,11 @@ int launch_pow2_blue(const PassPlan& pp, const PassParams& prm, hipStream_t stre
 	if (grid64 > 0x7fffffffull || pp.variant < 0 || pp.variant >= kNumPow2BlueVariants) return 4039;
 	kPow2BlueVariants[pp.variant].launch(prm, dim3((uint32_t)grid64), stream);
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
+}
+
+const char* pow2_row_kernel_name(int variant) {
+	if (variant < 0 || variant >= kNumPow2Variants || !kPow2Variants[variant].name) return "pow2_row_kernel";
+	return kPow2Variants[variant].name;
 }
 
 int launch_pow2(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {

@@ -216,8 +216,8 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	}
 	// real transforms (fused pre/post map) and strided C2C of curated lengths: op-FFT family
 	const bool fusedBluestein = b.preOp == OP_BLUESTEIN_PRE && b.midOp == OP_BLUESTEIN_MID && b.postOp == OP_BLUESTEIN_POST && !b.colIn && b.auxOff2ForPre == (size_t)-1;
-	const bool padMask = b.padInN || b.padOutN; // (the interpreter, pow2_row / pow2_col and the op-FFT kernels honour the masks: Io64 / Io32 / explicit)
-	if (fusedBluestein && !padMask && b.allowOp && b.fastKernel == KERNEL_GENERIC && (b.L & (b.L - 1)) == 0 && !b.forceT && b.radices.empty()) { // power-of-two padded length: register-resident persistent kernel
+	const bool padMask = b.padInN || b.padOutN; // (the interpreter, pow2_row / pow2_col, the fused Bluestein kernels (rdMask / wrMask, round 4) and the op-FFT kernels honour the masks: Io64 / Io32 / explicit)
+	if (fusedBluestein && b.allowOp && b.fastKernel == KERNEL_GENERIC && (b.L & (b.L - 1)) == 0 && !b.forceT && b.radices.empty()) { // power-of-two padded length: register-resident persistent kernel
 		int variant, bits[4], fpw, thr;
 		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
 		const uint64_t span = (b.L + 64 * (uint64_t)std::max<int64_t>(std::llabs(d0.inStride), std::llabs(d0.outStride))) * (b.dp ? 16 : 8);
@@ -229,7 +229,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	}
 	// ... and its column form for strided axes (tiles of neighbouring columns, one pass)
 	const bool fusedBluesteinCol = b.preOp == OP_BLUESTEIN_PRE && b.midOp == OP_BLUESTEIN_MID && b.postOp == OP_BLUESTEIN_POST && b.colIn && b.colOut && b.auxOff2ForPre == (size_t)-1;
-	if (fusedBluesteinCol && !padMask && b.allowOp && b.fastKernel == KERNEL_GENERIC && (b.L & (b.L - 1)) == 0 && !b.forceT && b.radices.empty()) {
+	if (fusedBluesteinCol && b.allowOp && b.fastKernel == KERNEL_GENERIC && (b.L & (b.L - 1)) == 0 && !b.forceT && b.radices.empty()) {
 		int variant, bits[4], tc, thr;
 		const uint64_t esz = b.dp ? 16 : 8;
 		const HostDim d0 = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
@@ -856,7 +856,9 @@ static bool emit_fused(const TransformDesc& d, const AxisJob& j, Arena& ar, Dire
 	const uint64_t tpc = G << logTiles; // tickets per slot (= tiles per chunk and phase)
 	// queues: one per XCD when the ring that goes with it still fits the Infinity Cache (256 MiB, shared with what streams through),
 	// else one queue; as a last resort a shorter lag (some tiles will poll)
-	const uint64_t ringBudget = 224ull << 20;
+	// (2^22 fp32: a transform is 32 MiB, the budget decides between lag 3 / ring 6 and lag 4 / ring 8 — measured 2.73 against 3.04 TB/s with the tiles of two
+	// halves, profiles/r05_fused_lag_ring_pairs.jsonl: with lag 3 a tile waits 5-10 k cycles per ticket for the previous tenant of its ring slot)
+	const uint64_t ringBudget = fftBytes >= (32ull << 20) ? (256ull << 20) : (224ull << 20);
 	const uint64_t wgs = 256ull * (uint64_t)(d.fusedWgPerCu ? d.fusedWgPerCu : wgPerCu);
 	// measured (tools/tune_fused.py): completions are published up to a ticket late and the ticket rate rises with the speed of the
 	// kernel, so the window is taken generously: 3 windows where two or more workgroups share a CU, 2 with one workgroup per CU
@@ -899,6 +901,15 @@ static bool emit_fused(const TransformDesc& d, const AxisJob& j, Arena& ar, Dire
 		for (uint64_t i = 0; i < nlo; i++) ar.putc(off, i, unit_root(i, j.N), dp);
 		for (uint64_t i = 0; i < nhi; i++) ar.putc(off, nlo + i, unit_root(i * nlo, j.N), dp);
 		pp.auxOff = off; pp.fused.fsLoBits = lo;
+	}
+	if (!dp) { // row table of the packed-pair kernels (kernel_pow2_pk.h pk_fs_twiddle): (1, Re w_N^k, 0, Im w_N^k) for k < n0
+		const size_t off = ar.alloc(n0 * 16);
+		for (uint64_t k = 0; k < n0; k++) {
+			const cld w = unit_root(k, j.N);
+			ar.put<float>(off, 2 * k, cld(1.0L, std::real(w)));
+			ar.put<float>(off, 2 * k + 1, cld(0.0L, std::imag(w)));
+		}
+		pp.fusedRowTabOff = off;
 	}
 	pp.fusedCtrOff = ar.alloc((kFusedCtrDone + 2 * C) * sizeof(uint32_t)); // zero in the host image; the kernel leaves it zeroed
 	memset(ar.b.data() + pp.fusedCtrOff, 0, (kFusedCtrDone + 2 * C) * sizeof(uint32_t));
@@ -1382,7 +1393,9 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		b.colIn = b.colOut = !unit;
 		b.dims = j.others;
 		b.label = "bluestein";
-		PassPlan pp; int r = finish_pass(b, ar, pp); if (r) return r;
+		PassPlan pp; int r = finish_pass(b, ar, pp);
+		if (r) return padded ? kPadUnsupported : r; // (a padded row whose fused kernel was refused — span, table — must not die on the interpreter's LDS limit: zero-fill fallback)
+		if (padded && pp.kernel == KERNEL_GENERIC && M * (dp ? 16 : 8) * 2 > d.maxLds) return kPadUnsupported;
 		passes.push_back(pp);
 		out.uploadsPerAxis[j.axisIndex] = 1;
 		return 0;
