@@ -17,7 +17,7 @@
 
 extern "C" {
 
-// kind: 0 C2C, 1 R2C/C2R (in-place padded layout), 11..14 DCT-I..IV
+// kind: 0 C2C, 1 R2C/C2R (in-place padded layout), 11..14 DCT-I..IV, 21..24 DST-I..IV
 // dims: FFTdim, size[3]; batch; doublePrecision; inverse (0 fwd, 1 inv); normalize
 // data: host pointer, nbytes bytes, transformed in place (H2D, run, D2H).
 int ref_transform(int kind, int fftdim, const uint64_t* size, uint64_t batch, int dp, int inverse,
@@ -33,6 +33,7 @@ int ref_transform(int kind, int fftdim, const uint64_t* size, uint64_t batch, in
     cfg.doublePrecision = dp; cfg.normalize = normalize;
     if (kind == 1) cfg.performR2C = 1;
     if (kind >= 11 && kind <= 14) cfg.performDCT = kind - 10;
+    if (kind >= 21 && kind <= 24) cfg.performDST = kind - 20;
     VkFFTResult r = initializeVkFFT(&app, cfg);
     if (r != VKFFT_SUCCESS) { hipFree(buf); return (int)r; }
     if (uploads_out) for (int i = 0; i < fftdim; i++) uploads_out[i] = app.localFFTPlan->numAxisUploads[i];
@@ -58,6 +59,7 @@ int ref_transform_zeropad(int kind, int fftdim, const uint64_t* size, uint64_t b
     cfg.doublePrecision = dp;
     if (kind == 1) cfg.performR2C = 1;
     if (kind >= 11 && kind <= 14) cfg.performDCT = kind - 10;
+    if (kind >= 21 && kind <= 24) cfg.performDST = kind - 20;
     for (int i = 0; i < fftdim; i++) { cfg.performZeropadding[i] = flags[i]; cfg.fft_zeropad_left[i] = left[i]; cfg.fft_zeropad_right[i] = right[i]; }
     cfg.frequencyZeroPadding = frequency;
     VkFFTResult r = initializeVkFFT(&app, cfg);
@@ -135,6 +137,7 @@ double ref_bench_pair_zeropad_ms(int fftdim, const uint64_t* size, uint64_t batc
     cfg.doublePrecision = dp;
     if (kind == 1) cfg.performR2C = 1;
     if (kind >= 11 && kind <= 14) cfg.performDCT = kind - 10;
+    if (kind >= 21 && kind <= 24) cfg.performDST = kind - 20;
     if (flags) for (int i = 0; i < fftdim; i++) { cfg.performZeropadding[i] = flags[i]; cfg.fft_zeropad_left[i] = left[i]; cfg.fft_zeropad_right[i] = right[i]; }
     VkFFTResult r = initializeVkFFT(&app, cfg);
     if (r != VKFFT_SUCCESS) { hipFree(buf); return -(double)r; }

@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 
-# kind: 0 C2C, 1 R2C (in-place padded rows), 11..14 DCT-I..IV
+# kind: 0 C2C, 1 R2C (in-place padded rows), 11..14 DCT-I..IV, 21..24 DST-I..IV
 CASES = [
     dict(name="c2c_4096_f32_fwd", kind=0, shape=(4096,), batch=1, dp=0, inverse=0),   # BASELINE config 1
     dict(name="c2c_4096_f32_inv", kind=0, shape=(4096,), batch=1, dp=0, inverse=1),
@@ -39,12 +39,32 @@ CASES = [
     dict(name="dct4_64_f32", kind=14, shape=(64,), batch=2, dp=0, inverse=0),
     dict(name="dct2_32x16_f32", kind=12, shape=(32, 16), batch=1, dp=0, inverse=0),
     dict(name="dct2_64_f64", kind=12, shape=(64,), batch=1, dp=1, inverse=0),
+    # round 5: the holes the round-4 review named — DST I..IV, DCT-IV of odd length (same-length form), fp64 R2C, 3-D R2C, multi-upload lengths of the
+    # reference (2^20, 2^22), a composite with a Rader stage (2670 = 30 * 89), a Bluestein prime (15319), a 3-D fp64 volume, an inverse R2C (C2R)
+    dict(name="dst1_63_f32", kind=21, shape=(63,), batch=2, dp=0, inverse=0),
+    dict(name="dst2_64_f32", kind=22, shape=(64,), batch=2, dp=0, inverse=0),
+    dict(name="dst3_100_f32", kind=23, shape=(100,), batch=2, dp=0, inverse=0),
+    dict(name="dst4_64_f32", kind=24, shape=(64,), batch=2, dp=0, inverse=0),
+    dict(name="dst2_48_f64", kind=22, shape=(48,), batch=1, dp=1, inverse=0),
+    dict(name="dct4_45_f32", kind=14, shape=(45,), batch=3, dp=0, inverse=0),
+    dict(name="dct4_1125_f32", kind=14, shape=(1125,), batch=2, dp=0, inverse=0),
+    dict(name="dct3_100_f32", kind=13, shape=(100,), batch=2, dp=0, inverse=0),
+    dict(name="r2c_1024_f64", kind=1, shape=(1024,), batch=2, dp=1, inverse=0),
+    dict(name="r2c_243_f32", kind=1, shape=(243,), batch=2, dp=0, inverse=0),
+    dict(name="r2c_32x24x10_f32", kind=1, shape=(32, 24, 10), batch=1, dp=0, inverse=0),
+    dict(name="c2c_2p20_f32", kind=0, shape=(1 << 20,), batch=1, dp=0, inverse=0, sample=257),   # (stored: every 257th bin + the L2 norm of the whole result)
+    dict(name="c2c_2p22_f32", kind=0, shape=(1 << 22,), batch=1, dp=0, inverse=0, sample=1031),
+    dict(name="c2c_2p16_f32_inv", kind=0, shape=(1 << 16,), batch=2, dp=0, inverse=1),
+    dict(name="c2c_2670_f32", kind=0, shape=(2670,), batch=2, dp=0, inverse=0),
+    dict(name="c2c_15319_f32", kind=0, shape=(15319,), batch=1, dp=0, inverse=0),
+    dict(name="c2c_12x10x8_f64", kind=0, shape=(12, 10, 8), batch=1, dp=1, inverse=0),
+    dict(name="c2c_2p14_f64", kind=0, shape=(1 << 14,), batch=1, dp=1, inverse=0),
 ]
 
 
 def golden_input(case, seed=20260923):
     """Deterministic input of a case as the flat array that is handed to the library (padded layout for R2C)."""
-    rng = np.random.default_rng(seed + sum(case["shape"]) + 7 * case["kind"] + case["dp"])
+    rng = np.random.default_rng(seed + (sum(case["shape"]) + 7 * case["kind"] + case["dp"]) % (1 << 30))
     rt = np.float64 if case["dp"] else np.float32
     n = int(np.prod(case["shape"])) * case["batch"]
     if case["kind"] == 0:
@@ -73,7 +93,9 @@ if __name__ == "__main__":
                               C.c_int(c["inverse"]), C.c_int(0), x.ctypes.data_as(C.c_void_p), C.c_uint64(x.nbytes), up)
         print(c["name"], "rc", r, "uploads", list(up)[:len(c["shape"])], flush=True)
         if r == 0:
-            res[c["name"]] = x
+            res[c["name"]] = x[:: c["sample"]] if c.get("sample") else x
+            if c.get("sample"):
+                res[c["name"] + "__l2"] = np.array([np.linalg.norm(x.astype(np.complex128))])
             res[c["name"] + "__uploads"] = np.array(list(up), dtype=np.uint64)
     np.savez_compressed(out, **res)
     print("wrote", out, os.path.getsize(out), "bytes")

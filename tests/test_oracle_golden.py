@@ -75,6 +75,8 @@ def _truth_for_case(oracle, mod, case, x):
         rows = x.reshape(-1, 2 * (W // 2 + 1))[:, :W].astype(np.float64)
         full = rows.reshape([b] + list(shape)[::-1])
         return np.fft.rfftn(full, axes=tuple(range(1, 1 + len(shape)))).reshape(-1)
+    if case["kind"] >= 21:
+        return oracle.truth_r2r(x, shape, b, type=case["kind"] - 20, dst=True)
     return oracle.truth_r2r(x, shape, b, type=case["kind"] - 10)
 
 
@@ -88,6 +90,8 @@ def _oracle_for_case(oracle, case, x):
         X = oracle.r2c_rows(rows.reshape(-1), W, rows.shape[0])
         assert len(shape) == 1
         return X
+    if case["kind"] >= 21:
+        return oracle.r2r(x, shape, b, case["kind"] - 20, True)
     return oracle.r2r(x, shape, b, type=case["kind"] - 10)
 
 
@@ -107,9 +111,12 @@ def test_golden_reference_outputs_match_truth_and_oracle(oracle, golden):
             ref_c = ref_out
         truth = _truth_for_case(oracle, mod, case, x)
         tol = 1e-14 if dp else 3e-6
+        if case.get("sample"):  # long results are stored as every n-th bin + the norm of the whole
+            assert abs(np.linalg.norm(truth) / data[case["name"] + "__l2"][0] - 1) < 1e-6, case["name"]
+            truth = truth[:: case["sample"]]
         assert rel_l2(ref_c, truth) < tol, ("reference vs truth", case["name"])
-        if case["kind"] == 1 and len(case["shape"]) > 1:
-            continue
+        if (case["kind"] == 1 and len(case["shape"]) > 1) or case.get("sample") or int(np.prod(case["shape"])) > 40000:
+            continue  # (the scalar C restatement is pinned on the short cases; its multi-pass forms have their own tests)
         mine = _oracle_for_case(oracle, case, x)
         assert rel_l2(mine, truth) < tol, ("oracle vs truth", case["name"])
         assert rel_l2(mine, ref_c) < 2 * tol, ("oracle vs reference", case["name"])
