@@ -132,7 +132,7 @@ typedef struct {
 	pfUINT forceCallbackVersionRealTransforms;
 
 	pfUINT normalize;              /* 1: scale the inverse by 1/N (1/(2N), 1/(2(N-1)) for R2R) */
-	pfUINT disableReorderFourStep; /* 1: leave multi-pass output digit-permuted */
+	pfUINT disableReorderFourStep; /* reference: 1 = leave multi-upload output in its transposed order.  This library always returns natural order and says so: after initializeVkFFT app->configuration.disableReorderFourStep reads 0 */
 	pfINT useLUT;                  /* accepted; twiddles always come from double-precision LUTs here */
 	pfINT useLUT_4step;
 	pfUINT makeForwardPlanOnly;

@@ -60,7 +60,7 @@ def test_rader_stage_of_a_composite_length_on_device(run, oracle, monkeypatch, N
     assert rel_l2(y, yb) < 3e-6
 
 
-@pytest.mark.parametrize("k,variant", [(13, v) for v in range(7)] + [(14, v) for v in range(7)] + [(15, v) for v in range(5)])
+@pytest.mark.parametrize("k,variant", [(13, v) for v in range(7)] + [(14, v) for v in range(7)] + [(15, v) for v in range(5)] + [(9, 0), (10, 0), (11, 0), (12, 0), (9, 1), (12, 1)])
 def test_register_lean_rows_every_variant_on_device(run, oracle, monkeypatch, k, variant):
     """kernel_pow2_lean.h on the device: every registered shape of 2^13 / 2^14 / one-pass 2^15 (the defaults are index 0), a chip-filling batch against
     the small batch bit for bit, and the oracle"""

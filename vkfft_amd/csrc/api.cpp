@@ -246,7 +246,14 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 	if (c.numberBatches == 0) c.numberBatches = 1;
 	if (c.coordinateFeatures == 0) c.coordinateFeatures = 1;
 	if (c.numberKernels == 0) c.numberKernels = 1;
-	c.reorderFourStep = in.disableReorderFourStep ? 0 : 1;
+	// disableReorderFourStep: the reference leaves the result of a multi-upload transform in an (unspecified) transposed order to save its last transposition
+	// (vkFFT_InitializeApp.h:1312-1316, vkFFT_ReadWrite.h:1405-1424).  Here natural order costs nothing extra — the turn is part of the first pass — so the
+	// request is not honoured, and the caller is TOLD so: the application's own copy of the configuration reports what is in effect (reorder on, flag cleared);
+	// printMemoryLayout / VKFFT_MI355X_PRINT_PLAN print a line.  Natural order is one valid instance of the unspecified order for every forward -> pointwise ->
+	// inverse pipeline whose operands all come from this library.
+	if (in.disableReorderFourStep && (in.printMemoryLayout || getenv("VKFFT_MI355X_PRINT_PLAN")))
+		fprintf(stderr, "[vkfft_mi355x] disableReorderFourStep requested: not applied, results stay in natural order (app->configuration.disableReorderFourStep reads back 0)\n");
+	c.reorderFourStep = 1; c.disableReorderFourStep = 0;
 	if (in.userTempBuffer) {
 		if (in.tempBufferSize == nullptr) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_EMPTY_tempBufferSize; }
 		if (in.tempBuffer == nullptr) { memset(app, 0, sizeof(*app)); return VKFFT_ERROR_EMPTY_tempBuffer; }
@@ -561,6 +568,16 @@ VkFFTResult initialize_convolution(VkFFTApplication* app, const VkFFTConfigurati
 	if (!st->convFwd || !st->convInv) { deleteVkFFT(app); return VKFFT_ERROR_MALLOC_FAILED; }
 	VkFFTResult r = initializeVkFFT(st->convFwd, f);
 	if (r == VKFFT_SUCCESS) r = initializeVkFFT(st->convInv, b);
+	if (r == VKFFT_SUCCESS && st->convMid) {
+		// the plain inverse over ALL axes of a merged application (VkFFTAppend(app, 1)): built here, not at its first use — planning, allocation and the table
+		// upload do not belong inside a launch (stream capture, concurrent callers, and the caller's configuration storage may be gone by then)
+		st->convInvFull = (VkFFTApplication*)calloc(1, sizeof(VkFFTApplication));
+		if (!st->convInvFull) r = VKFFT_ERROR_MALLOC_FAILED;
+		else {
+			r = initializeVkFFT(st->convInvFull, st->convInvFullCfg);
+			if (r != VKFFT_SUCCESS) { free(st->convInvFull); st->convInvFull = nullptr; }
+		}
+	}
 	if (r != VKFFT_SUCCESS) { deleteVkFFT(app); return r; }
 	for (int i = 0; i < VKFFT_MAX_FFT_DIMENSIONS; i++) c.bufferStride[i] = st->convFwd->configuration.bufferStride[i];
 	app->firstAxis = 0; app->lastAxis = c.FFTdim - 1;
@@ -579,14 +596,7 @@ VkFFTResult append_convolution(VkFFTApplication* app, int inverse, VkFFTLaunchPa
 	if (lp) { inv.buffer = lp->buffer; inv.tempBuffer = lp->tempBuffer; inv.bufferOffset = lp->bufferOffset; inv.tempBufferOffset = lp->tempBufferOffset; }
 	if (inverse == 1) { // a plain inverse of the numberKernels results, over every axis
 		if (!st->convMid) return VkFFTAppend(st->convInv, 1, lp ? &inv : nullptr);
-		if (!st->convInvFull) { // (convInv omits the merged axis)
-			st->convInvFull = (VkFFTApplication*)calloc(1, sizeof(VkFFTApplication));
-			if (!st->convInvFull) return VKFFT_ERROR_MALLOC_FAILED;
-			VkFFTConfiguration full = st->convInvFullCfg;
-			full.buffer = c.buffer; full.tempBuffer = c.tempBuffer; full.stream = c.stream; full.bufferOffset = c.bufferOffset; full.tempBufferOffset = c.tempBufferOffset;
-			const VkFFTResult r0 = initializeVkFFT(st->convInvFull, full);
-			if (r0 != VKFFT_SUCCESS) { free(st->convInvFull); st->convInvFull = nullptr; return r0; }
-		}
+		if (!st->convInvFull) return VKFFT_ERROR_PLAN_NOT_INITIALIZED; // (built by initializeVkFFT: convInv omits the merged axis)
 		VkFFTLaunchParams full = inv;
 		if (!lp || !lp->buffer) full.buffer = c.buffer;
 		if (!full.tempBuffer && c.userTempBuffer) full.tempBuffer = c.tempBuffer;

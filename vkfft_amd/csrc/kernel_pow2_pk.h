@@ -458,29 +458,33 @@ __device__ inline void pka_lean_stages(pk2<T>* v, T* plane, const TW lut, const 
 	}
 }
 
-// ---- unit-stride rows of N = 2^13 ... 2^15 points: pow2_row_lean_kernel on (x, y) register pairs ----
-template <typename T, typename SCH, int WPE, int TWG>
-__global__ void __launch_bounds__((1 << SCH::LOGN) >> SCH::LOGE, WPE) pow2_row_lean_pk_kernel(const PassParams p) {
+// ---- unit-stride rows of N = 2^10 ... 2^15 points: pow2_row_lean_kernel on (x, y) register pairs, FPW rows per workgroup (one for 2^13 ... 2^15) ----
+template <typename T, typename SCH, int WPE, int TWG, int FPW = 1>
+__global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW, WPE) pow2_row_lean_pk_kernel(const PassParams p) {
 	constexpr int LOGN = SCH::LOGN, N = 1 << LOGN, LOGE = SCH::LOGE, E = 1 << LOGE, TPF = N / E;
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
-	__shared__ T plane[pow2_lean_plane_elems<SCH, 0>()];
-	const uint32_t tau = threadIdx.x;
+	constexpr int PL = (int)pow2_lean_plane_elems<SCH, 0>();
+	__shared__ T planes[FPW * PL];
+	const uint32_t tau = FPW > 1 ? threadIdx.x % (uint32_t)TPF : threadIdx.x, fl = FPW > 1 ? threadIdx.x / (uint32_t)TPF : 0u;
+	T* const plane = planes + fl * PL;
 	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
-	const uint32_t f0 = wg % p.tilesPerG0; // one row per tile
+	const uint32_t f0 = (wg % p.tilesPerG0) * (uint32_t)FPW + fl; // FPW consecutive rows per tile
 	wg /= p.tilesPerG0;
 	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
-	const GBuf gin = make_gbuf((const cx<T>*)p.in + ((int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride));
-	const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride));
+	const bool valid = FPW == 1 || f0 < p.dim[0].count; // (lanes of a row beyond the last one get the out-of-range offset: they load zeros and store nothing, and keep the barriers)
+	const GBuf gin = make_gbuf((const cx<T>*)p.in + ((int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)(FPW == 1 ? f0 : f0 - fl) * p.dim[0].inStride));
+	const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)(FPW == 1 ? f0 : f0 - fl) * p.dim[0].outStride));
 	const GBuf glut = make_gbuf(p.lut);
-	const uint32_t lane = tau * ES;
+	const uint32_t laneIn = !valid ? kGbInvalid : (tau + (FPW == 1 ? 0u : fl * (uint32_t)p.dim[0].inStride)) * ES;
+	const uint32_t laneOut = !valid ? kGbInvalid : (tau + (FPW == 1 ? 0u : fl * (uint32_t)p.dim[0].outStride)) * ES;
 	pk2<T> v[E];
 	auto ld = [&](uint32_t voff, uint32_t soff) { const cx<T> q = gb_load<T>(gin, voff, soff); return pk2<T>{q.x, q.y}; };
 	if (p.padInN) { // zero padding: points of the padded range get an out-of-range offset (they read as zero and are not fetched)
 #pragma unroll
-		for (int m = 0; m < E; m++) v[m] = ld((tau + (uint32_t)(m * TPF) - p.padInL < p.padInN) ? kGbInvalid : lane, (uint32_t)(m * TPF) * ES);
+		for (int m = 0; m < E; m++) v[m] = ld((tau + (uint32_t)(m * TPF) - p.padInL < p.padInN) ? kGbInvalid : laneIn, (uint32_t)(m * TPF) * ES);
 	} else {
 #pragma unroll
-		for (int m = 0; m < E; m++) v[m] = ld(lane, (uint32_t)(m * TPF) * ES);
+		for (int m = 0; m < E; m++) v[m] = ld(laneIn, (uint32_t)(m * TPF) * ES);
 	}
 	if (p.swapIn) { // inverse = conj . forward . conj
 #pragma unroll
@@ -495,14 +499,14 @@ __global__ void __launch_bounds__((1 << SCH::LOGN) >> SCH::LOGE, WPE) pow2_row_l
 	}
 	if (p.padOutN) { // (the padded range of the output is not written)
 #pragma unroll
-		for (int m = 0; m < E; m++) gb_store<T>(gout, (tau + (uint32_t)(m * TPF) - p.padOutL < p.padOutN) ? kGbInvalid : lane, (uint32_t)(m * TPF) * ES, cx<T>{v[m].x, v[m].y});
+		for (int m = 0; m < E; m++) gb_store<T>(gout, (tau + (uint32_t)(m * TPF) - p.padOutL < p.padOutN) ? kGbInvalid : laneOut, (uint32_t)(m * TPF) * ES, cx<T>{v[m].x, v[m].y});
 	} else {
 #pragma unroll
-		for (int m = 0; m < E; m++) gb_store<T>(gout, lane, (uint32_t)(m * TPF) * ES, cx<T>{v[m].x, v[m].y});
+		for (int m = 0; m < E; m++) gb_store<T>(gout, laneOut, (uint32_t)(m * TPF) * ES, cx<T>{v[m].x, v[m].y});
 	}
 }
-template <typename T, typename SCH, int WPE, int TWG> void pow2_row_lean_pk_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
-	hipLaunchKernelGGL((pow2_row_lean_pk_kernel<T, SCH, WPE, TWG>), grid, dim3((1 << SCH::LOGN) >> SCH::LOGE), 0, s, prm);
+template <typename T, typename SCH, int WPE, int TWG, int FPW = 1> void pow2_row_lean_pk_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
+	hipLaunchKernelGGL((pow2_row_lean_pk_kernel<T, SCH, WPE, TWG, FPW>), grid, dim3(((1 << SCH::LOGN) >> SCH::LOGE) * FPW), 0, s, prm);
 }
 
 } // namespace vkfft_mi355x

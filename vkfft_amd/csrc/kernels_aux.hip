@@ -178,19 +178,23 @@ int launch_transpose(const PassPlan& pp, const PassParams& prm, hipStream_t stre
 // ---- the library's own streaming copy (extension vkfftMI355XStreamCopy): 16 bytes per lane, four transfers in flight per lane, non-temporal hint on
 // both sides, persistent grid — the practical HBM ceiling the roofline fractions of bench.py are quoted against next to torch's copy kernel
 struct alignas(16) Copy16 { uint32_t x, y, z, w; };
+// a workgroup moves contiguous 32 KiB blocks: eight 16-byte transfers per lane in flight, lanes along the block (the access shape of the FFT kernels' tiles and of
+// tools/probe3.hip's k_copy, which measured 5.5-5.7 TB/s; a grid-stride form with four scattered transfers per lane measured 4.4-4.8)
 __global__ void __launch_bounds__(256) stream_copy_kernel(const Copy16* __restrict__ src, Copy16* __restrict__ dst, const uint64_t n16) {
-	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-	uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	constexpr uint64_t BLK16 = 256 * 8; // 16-byte units per block
+	const uint64_t nBlocks = n16 / BLK16;
 #if defined(VKFFT_HOSTEMU)
-	for (; i < n16; i += stride) dst[i] = src[i];
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 #else
-	typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-	const u4* s4 = (const u4*)src; u4* d4 = (u4*)dst;
-	for (; i + 3 * stride < n16; i += 4 * stride) {
-		const u4 a = __builtin_nontemporal_load(s4 + i), b = __builtin_nontemporal_load(s4 + i + stride), c = __builtin_nontemporal_load(s4 + i + 2 * stride), d = __builtin_nontemporal_load(s4 + i + 3 * stride);
-		__builtin_nontemporal_store(a, d4 + i); __builtin_nontemporal_store(b, d4 + i + stride); __builtin_nontemporal_store(c, d4 + i + 2 * stride); __builtin_nontemporal_store(d, d4 + i + 3 * stride);
+	for (uint64_t i = blockIdx.x; i < nBlocks; i += gridDim.x) {
+		const GBuf gs = make_gbuf(src + i * BLK16), gd = make_gbuf(dst + i * BLK16);
+		vk_u32x4 v[8];
+#pragma unroll
+		for (int j = 0; j < 8; j++) v[j] = __builtin_amdgcn_raw_buffer_load_b128(gs.r, threadIdx.x * 16u + j * 4096u, 0, 0);
+#pragma unroll
+		for (int j = 0; j < 8; j++) __builtin_amdgcn_raw_buffer_store_b128(v[j], gd.r, threadIdx.x * 16u + j * 4096u, 0, 0);
 	}
-	for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + i), d4 + i);
+	for (uint64_t i = nBlocks * BLK16 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i]; // tail
 #endif
 }
 int launch_stream_copy(void* dst, const void* src, uint64_t bytes, hipStream_t stream) {
@@ -198,7 +202,7 @@ int launch_stream_copy(void* dst, const void* src, uint64_t bytes, hipStream_t s
 	if (!bytes) return 0;
 	const uint64_t n16 = bytes / 16;
 	uint64_t grid = (uint64_t)pow2_num_cus_aux() * 8u;
-	if (grid > (n16 + 255) / 256) grid = (n16 + 255) / 256;
+	if (grid > (n16 + 2047) / 2048) grid = (n16 + 2047) / 2048;
 	hipLaunchKernelGGL(stream_copy_kernel, dim3((uint32_t)grid), dim3(256), 0, stream, (const Copy16*)src, (Copy16*)dst, n16);
 	return hipGetLastError() == hipSuccess ? 0 : 4039;
 }

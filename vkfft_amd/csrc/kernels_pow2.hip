@@ -35,6 +35,10 @@ template <typename T, typename SCH, int TC> void pow2_col_launch(const PassParam
 #define VKFFT_P2K(T, dp, b0, b1, b2, b3, wpe, twg) \
 	{ (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, 1, ((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE), &pow2_row_lean_pk_launch<T, Pow2Sched<b0, b1, b2, b3>, wpe, twg>, "pow2_row_lean_pk_kernel" }
 
+// ... several rows per workgroup (2^10 ... 2^12)
+#define VKFFT_P2KF(T, dp, b0, b1, b2, b3, wpe, twg, fpw) \
+	{ (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, fpw, ((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (fpw), &pow2_row_lean_pk_launch<T, Pow2Sched<b0, b1, b2, b3>, wpe, twg, fpw>, "pow2_row_lean_pk_kernel" }
+
 // first entry of each (log2n, dp) is the default; VKFFT_MI355X_P2V<log2n>=k selects the k-th (tuning)
 static const Pow2Variant kPow2Variants[] = {
 	// fp32
@@ -45,10 +49,12 @@ static const Pow2Variant kPow2Variants[] = {
 	VKFFT_P2(float, false, 3, 3, 0, 0, 32),
 	VKFFT_P2(float, false, 4, 3, 0, 0, 16), VKFFT_P2(float, false, 3, 2, 2, 0, 16),
 	VKFFT_P2(float, false, 4, 4, 0, 0, 8), VKFFT_P2(float, false, 4, 4, 0, 0, 16), VKFFT_P2(float, false, 3, 3, 2, 0, 8), VKFFT_P2(float, false, 3, 3, 2, 0, 4),
-	VKFFT_P2(float, false, 5, 4, 0, 0, 8), VKFFT_P2(float, false, 4, 3, 2, 0, 8), VKFFT_P2(float, false, 3, 3, 3, 0, 4), VKFFT_P2(float, false, 4, 3, 2, 0, 4), VKFFT_P2(float, false, 5, 4, 0, 0, 4),
-	VKFFT_P2(float, false, 5, 5, 0, 0, 8), VKFFT_P2(float, false, 4, 3, 3, 0, 4), VKFFT_P2(float, false, 4, 3, 3, 0, 2), VKFFT_P2(float, false, 5, 5, 0, 0, 4), VKFFT_P2(float, false, 5, 5, 0, 0, 2),
-	VKFFT_P2(float, false, 5, 5, 1, 0, 2), VKFFT_P2(float, false, 4, 4, 3, 0, 1), VKFFT_P2(float, false, 4, 4, 3, 0, 2), VKFFT_P2(float, false, 5, 5, 1, 0, 4), VKFFT_P2(float, false, 4, 4, 3, 0, 4),
-	VKFFT_P2(float, false, 4, 4, 4, 0, 1), VKFFT_P2(float, false, 5, 5, 2, 0, 1), VKFFT_P2(float, false, 4, 4, 4, 0, 2), VKFFT_P2(float, false, 5, 5, 2, 0, 2),
+	// round 5: 2^9 ... 2^12 on the packed (x, y) rows of kernel_pow2_pk.h, several rows per workgroup (A/B on one box, paired TB/s: 2^9 5.72 -> 6.09, 2^10 5.42 -> 6.07,
+	// 2^11 5.24 -> 5.69, 2^12 5.24 -> 5.67; 16 points per thread where there are three stages: 68-80 VGPRs, six to seven waves per SIMD; 2^8 stays: 6.07 against 5.99)
+	VKFFT_P2KF(float, false, 5, 4, 0, 0, 4, 16, 16), VKFFT_P2(float, false, 5, 4, 0, 0, 8), VKFFT_P2(float, false, 4, 3, 2, 0, 8), VKFFT_P2(float, false, 3, 3, 3, 0, 4), VKFFT_P2(float, false, 4, 3, 2, 0, 4), VKFFT_P2(float, false, 5, 4, 0, 0, 4),
+	VKFFT_P2KF(float, false, 5, 5, 0, 0, 4, 16, 8), VKFFT_P2(float, false, 5, 5, 0, 0, 8), VKFFT_P2(float, false, 4, 3, 3, 0, 4), VKFFT_P2(float, false, 4, 3, 3, 0, 2), VKFFT_P2(float, false, 5, 5, 0, 0, 4), VKFFT_P2(float, false, 5, 5, 0, 0, 2),
+	VKFFT_P2KF(float, false, 4, 4, 3, 0, 5, 16, 4), VKFFT_P2(float, false, 5, 5, 1, 0, 2), VKFFT_P2(float, false, 4, 4, 3, 0, 1), VKFFT_P2(float, false, 4, 4, 3, 0, 2), VKFFT_P2(float, false, 5, 5, 1, 0, 4), VKFFT_P2(float, false, 4, 4, 3, 0, 4),
+	VKFFT_P2KF(float, false, 4, 4, 4, 0, 5, 16, 1), VKFFT_P2(float, false, 4, 4, 4, 0, 1), VKFFT_P2(float, false, 5, 5, 2, 0, 1), VKFFT_P2(float, false, 4, 4, 4, 0, 2), VKFFT_P2(float, false, 5, 5, 2, 0, 2),
 	// 2^13 (P2V13 = 0 .. 5): register-lean rows, four 256-thread workgroups per CU; index 1 is the round-1..3 kernel (two 67 KiB workgroups per CU)
 	VKFFT_P2K(float, false, 5, 4, 4, 0, 4, 16), VKFFT_P2(float, false, 5, 4, 4, 0, 1), VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 16, 0), VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 16, 16), VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 8, 16), VKFFT_P2L(float, false, 5, 5, 3, 0, 4, 16, 16), VKFFT_P2(float, false, 4, 3, 3, 3, 1),
 	// 2^14: register-lean rows, two 512-thread workgroups per CU; index 1 is the round-1..3 kernel (one 135 KiB workgroup per CU)

@@ -289,7 +289,12 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 			int variant, rad5[5], fpw, thr;
 			uint64_t len = 0;
 			opsCplxLen = b.L;
-			if (mixed_row_lookup(b.L, b.dp, &variant, rad5, &fpw, &thr)) {
+			// (the maps inside the stages address the rows of a tile — up to 2 * FPW <= 128 of them — with 32-bit byte offsets from the tile's base: a row pitch that
+			// takes the tile past 2 GiB leaves the pass to the interpreter, as on the complex paths)
+			const HostDim d0o = b.dims.empty() ? HostDim{1, 0, 0} : b.dims[0];
+			const bool spanOK = (2 * b.L + 128 * (uint64_t)std::max<int64_t>(std::llabs(d0o.inStride), std::llabs(d0o.outStride))) * (b.dp ? 16 : 8) < 0x7FFFFF00ull;
+			if (!spanOK) { /* interpreter */ }
+			else if (mixed_row_lookup(b.L, b.dp, &variant, rad5, &fpw, &thr)) {
 				b.fastKernel = KERNEL_MIXED_ROW; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
 				for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
 			} else if (!b.dp && b.L >= 74 && b.L <= 4096 && !is_prime_u(b.L) && [&]() {
@@ -1416,7 +1421,15 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	}
 	// 2^15 fp32 as ONE pass of the register-lean row kernel (measured 4.2 TB/s against 3.2 for the fused two-pass kernel); VKFFT_MI355X_ROW15=0: two passes
 	const bool row15 = !(getenv("VKFFT_MI355X_ROW15") && atoi(getenv("VKFFT_MI355X_ROW15")) == 0);
-	if (j.N <= singleCap || (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N <= (dp ? 8192u : (row15 ? 32768u : 16384u)))) {
+	// (a power-of-two row beyond the interpreter's reach takes this branch only when its register-resident kernel is really there — table entry and 32-bit
+	// span —: otherwise the interpreter would be handed a row that does not fit LDS (error 3002) instead of the Four-Step plan below)
+	bool p2rowOK = false;
+	if (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N >= 4 && j.N <= (dp ? 8192u : (row15 ? 32768u : 16384u))) {
+		int variant, bits[4], fpw, thr;
+		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
+		p2rowOK = (rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && pow2_row_lookup(ilog2(j.N), dp, &variant, bits, &fpw, &thr);
+	}
+	if (j.N <= singleCap || p2rowOK) {
 		b.L = j.N;
 		if (unit && !padded && !d.disableFastKernels && ((j.N & (j.N - 1)) != 0 || j.N == 2)) { // curated non-power-of-two lengths (and N = 2): hand-specialised mixed-radix kernel
 			int variant, rad5[5], fpw, thr;
