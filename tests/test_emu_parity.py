@@ -353,13 +353,13 @@ def test_fused_fourstep_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
 
 
-@pytest.mark.parametrize("k,variant", [(13, v) for v in range(7)] + [(14, v) for v in range(7)] + [(15, v) for v in range(5)] + [(9, v) for v in range(6)] + [(10, v) for v in range(6)] + [(11, v) for v in range(6)] + [(12, v) for v in range(5)])
+@pytest.mark.parametrize("k,variant", [(k, v) for k in (9, 10, 11, 12) for v in range(2)] + [(k, v) for k in (13, 14, 15) for v in range(3)])
 def test_register_lean_rows_every_variant(run, oracle, monkeypatch, k, variant):
     """kernel_pow2_lean.h: 32 points per thread, real / imaginary planes exchanged one after the other, in-place DIF butterflies, twiddles in chunks (with
     and without the prefetch across the exchange) — every registered shape of 2^13, 2^14 and the one-pass 2^15, next to the round-1 kernels they replace"""
     monkeypatch.setenv(f"VKFFT_MI355X_P2V{k}", str(variant))
     N = 1 << k
-    B = 3 if k >= 13 else 21  # (2^9 ... 2^12: several rows per workgroup, the last tile partly filled)
+    B = (11 if variant == 0 else 3) if k == 15 else 3 if k >= 13 else 21  # (2^9 ... 2^12: several rows per workgroup, the last tile partly filled; 2^15 variant 0: persistent workgroups, several rows each)
     x = parity.seeded_complex(N * B, False, N + variant)
     y, z, up = run.transform(x, (N,), B, both=True)
     assert up == [1]
@@ -370,9 +370,10 @@ def test_register_lean_rows_every_variant(run, oracle, monkeypatch, k, variant):
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
 
 
-def test_register_lean_row_strides_padding_and_scale(run, oracle):
-    """the lean row kernel behind the general plan features: padded batch stride, zero padding (read and write masks), normalised inverse"""
-    N = 1 << 14
+@pytest.mark.parametrize("N", [1 << 10, 1 << 14, 1 << 15])
+def test_register_lean_row_strides_padding_and_scale(run, oracle, N):
+    """the packed row kernels behind the general plan features: padded batch stride, zero padding (read and write masks; 2^15: the pairs kernel has none and the
+    padded plan takes the one-row kernel), normalised inverse"""
     rng = np.random.default_rng(7)
     pitch = N + 24
     buf = (rng.uniform(-1, 1, (3, pitch)) + 1j * rng.uniform(-1, 1, (3, pitch))).astype(np.complex64)
@@ -385,10 +386,10 @@ def test_register_lean_row_strides_padding_and_scale(run, oracle):
     assert rel_l2(z[:, :N], buf[:, :N]) < 2e-6
     import convpad
     assert convpad.zeropad_case(run, (N,), {0: (N // 2, N)}, batch=2) < 3e-6
+    assert convpad.zeropad_case(run, (N,), {0: (N // 4 + 1, N // 2 + 3)}, batch=3) < 3e-6  # (an inner range with odd ends)
 
 
-@pytest.mark.parametrize("k,variant,batch", [(15, 0, 5), (15, 1, 5), (15, 2, 5), (15, 3, 5), (16, 1, 3), (16, 2, 3), (16, 3, 3), (17, 1, 3), (17, 2, 3), (17, 3, 3), (18, 1, 3), (18, 2, 3), (18, 3, 3),
-                                             (19, 1, 2), (19, 2, 2), (19, 3, 2), (20, 1, 2), (20, 2, 2), (20, 3, 2), (21, 0, 1), (21, 1, 1), (21, 2, 1), (21, 3, 1), (22, 0, 1), (22, 1, 1), (22, 2, 1)])
+@pytest.mark.parametrize("k,variant,batch", [(15, 0, 5), (15, 1, 5), (16, 1, 3), (17, 1, 3), (18, 1, 3), (19, 1, 2), (20, 1, 2), (21, 0, 1), (21, 1, 1), (22, 0, 1), (22, 1, 1)])
 def test_fused_fourstep_every_registered_shape(run, oracle, monkeypatch, k, variant, batch):
     """every shape in the fused Four-Step registry besides the defaults the other tests run: index 0 = what ships (2^16 ... 2^20: the packed-pair
     software-pipelined form, kernel_pow2_fused_pk.h; 2^21 / 2^22: packed-pair tiles of two halves, kernel_pow2_fused_pkh.h), then the round-4 pipelined form,

@@ -76,7 +76,7 @@ def test_headline_power_of_two_kernels_have_no_scratch(tmp_path):
     seen = 0
     for asm in (asm_rows, asm_fused):
         for name, (body, priv, vgpr) in _kernels(asm.read_text()).items():
-            if "pow2_row_lean_pk_kernel" in name or "pow2_fused_pk_kernel" in name or "pow2_fused_pkh_kernel" in name:
+            if "pow2_row_lean_pk_kernel" in name or "pow2_row_pairs_kernel" in name or "pow2_fused_pk_kernel" in name or "pow2_fused_pkh_kernel" in name:
                 seen += 1
                 assert priv == 0 and "scratch_" not in body, (name, priv)
     assert seen >= 11, seen  # three row lengths, six two-factor shapes, two shapes of two halves

@@ -1,7 +1,7 @@
 # round 5, call 9: several-rows-per-workgroup packed rows at 2^10 ... 2^12 against the shipping row kernels; streaming copy
-export TMPDIR=/tmp; O=gpurun_out/r05k; mkdir -p $O
-timeout 300 python tools/ab_r05.py 9 10 11 12 13 14 > $O/ab.jsonl 2> $O/ab.err
-timeout 300 python tools/ab_r05.py 9 10 11 12 13 14 >> $O/ab.jsonl 2>> $O/ab.err
+export TMPDIR=/tmp; O=gpurun_out/r05m; mkdir -p $O
+timeout 300 python tools/ab_r05.py 9 10 11 12 > $O/ab.jsonl 2> $O/ab.err
+timeout 300 python tools/ab_r05.py 9 10 11 12 >> $O/ab.jsonl 2>> $O/ab.err
 cut -c1-200 $O/ab.jsonl
 python - <<'PY'
 import torch, time, sys

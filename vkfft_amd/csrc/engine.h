@@ -118,7 +118,7 @@ int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, cons
 int launch_pow2(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 int launch_pow2_blue(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 int launch_pow2_col_blue(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
-bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads);
+bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads, bool padded = false); // padded: only kernels with zero-padding masks
 bool pow2_col_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* tc, int* threads);
 bool pow2_col_blue_lookup(uint32_t log2l, bool dp, int mode, int* variant, int bits[4], int* tc, int* threads); // multi-pass Bluestein passes 1..3
 bool pow2_blue_r2r_lookup(uint32_t log2m, bool dp, uint32_t pre, int* variant, int bits[4], int* fpw, int* threads); // Bluestein-wrapped DCT/DST/R2C

@@ -156,6 +156,7 @@ struct Pow2Variant {
 	int log2n; bool dp; int bits[4]; int fpw; int threads; // fpw: FFTs per workgroup (row) / columns per workgroup (col)
 	void (*launch)(const PassParams&, dim3, hipStream_t);
 	const char* name = nullptr; // the __global__ function behind the entry when it is not the family's first (vkfftMI355XDescribePlan, bench labels)
+	bool noPadMasks = false;    // the kernel has no zero-padding masks: a padded pass takes the next entry of its size
 };
 
 } // namespace vkfft_mi355x

@@ -424,7 +424,9 @@ __device__ inline void pka_lean_butterflies(pk2<T>* v, const TW lut, const uint3
 		for (int k = 0; k < R; k++) v[b + k * NB] = x[pow2_bitrev(k, LOGR)];
 	}
 }
-template <typename T, typename SCH, int SI, int TPF, int PART>
+// WAVE: a row's threads are lanes of ONE wavefront (TPF <= 64 divides 64): the exchange needs the wave's own LDS order only, no workgroup barrier — the waves of
+// a workgroup then run their rows independently of each other
+template <typename T, typename SCH, int SI, int TPF, int PART, bool WAVE>
 __device__ inline void pka_lean_exchange_part(pk2<T>* v, T* plane, const uint32_t tau) {
 	constexpr int LOGE = SCH::LOGE, E = 1 << LOGE, P = SCH::bits[0];
 	constexpr int LOGR = SCH::bits[SI], R = 1 << LOGR, NB = E / R;
@@ -438,7 +440,7 @@ __device__ inline void pka_lean_exchange_part(pk2<T>* v, T* plane, const uint32_
 #pragma unroll
 		for (int k = 0; k < R; k++) wp[pow2_lean_step<0, P>(k * S)] = PART ? v[b + k * NB].y : v[b + k * NB].x;
 	}
-	VKFFT_SYNC();
+	if constexpr (WAVE) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
 	const T* const rp = plane + pow2_lean_slot<0, P>(tau);
 #pragma unroll
 	for (int m = 0; m < E; m++) {
@@ -446,19 +448,19 @@ __device__ inline void pka_lean_exchange_part(pk2<T>* v, T* plane, const uint32_
 		if (PART) v[m].y = r; else v[m].x = r;
 	}
 }
-template <typename T, typename SCH, int SI, int TPF, typename TW, int TWG>
+template <typename T, typename SCH, int SI, int TPF, typename TW, int TWG, bool WAVE = false>
 __device__ inline void pka_lean_stages(pk2<T>* v, T* plane, const TW lut, const uint32_t tau) {
 	pka_lean_butterflies<T, SCH, SI, TPF, TW, TWG>(v, lut, tau);
 	if constexpr (SI + 1 < SCH::NS) {
-		pka_lean_exchange_part<T, SCH, SI, TPF, 0>(v, plane, tau);
-		VKFFT_SYNC();
-		pka_lean_exchange_part<T, SCH, SI, TPF, 1>(v, plane, tau);
-		if constexpr (SI + 2 < SCH::NS) VKFFT_SYNC();
-		pka_lean_stages<T, SCH, SI + 1, TPF, TW, TWG>(v, plane, lut, tau);
+		pka_lean_exchange_part<T, SCH, SI, TPF, 0, WAVE>(v, plane, tau);
+		if constexpr (WAVE) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
+		pka_lean_exchange_part<T, SCH, SI, TPF, 1, WAVE>(v, plane, tau);
+		if constexpr (SI + 2 < SCH::NS) { if constexpr (WAVE) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); }
+		pka_lean_stages<T, SCH, SI + 1, TPF, TW, TWG, WAVE>(v, plane, lut, tau);
 	}
 }
 
-// ---- unit-stride rows of N = 2^10 ... 2^15 points: pow2_row_lean_kernel on (x, y) register pairs, FPW rows per workgroup (one for 2^13 ... 2^15) ----
+// ---- unit-stride rows of N = 2^9 ... 2^15 points: pow2_row_lean_kernel on (x, y) register pairs, FPW rows per workgroup (one for 2^13 ... 2^15) ----
 template <typename T, typename SCH, int WPE, int TWG, int FPW = 1>
 __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW, WPE) pow2_row_lean_pk_kernel(const PassParams p) {
 	constexpr int LOGN = SCH::LOGN, N = 1 << LOGN, LOGE = SCH::LOGE, E = 1 << LOGE, TPF = N / E;
@@ -490,7 +492,9 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW, WPE) po
 #pragma unroll
 		for (int m = 0; m < E; m++) v[m].y = -v[m].y;
 	}
-	pka_lean_stages<T, SCH, 0, TPF, TwGlobal<T>, TWG>(v, plane, TwGlobal<T>{glut}, tau);
+	// (WAVE = false also where a row sits inside one wavefront: the wave-level ordering is a workgroup-scope fence, which waits for the wave's loads and stores
+	// to HBM as well — measured 4 % slower than the barrier at 2^9 / 2^10, profiles/r05_ab_small_sizes_*)
+	pka_lean_stages<T, SCH, 0, TPF, TwGlobal<T>, TWG, false>(v, plane, TwGlobal<T>{glut}, tau);
 	const T sc = (T)p.scale;
 	if (sc != (T)1 || p.swapOut) {
 		const pk2<T> f = {sc, p.swapOut ? -sc : sc};
@@ -507,6 +511,86 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW, WPE) po
 }
 template <typename T, typename SCH, int WPE, int TWG, int FPW = 1> void pow2_row_lean_pk_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
 	hipLaunchKernelGGL((pow2_row_lean_pk_kernel<T, SCH, WPE, TWG, FPW>), grid, dim3(((1 << SCH::LOGN) >> SCH::LOGE) * FPW), 0, s, prm);
+}
+
+// ---- unit-stride rows of 2^15 points as 2^14 PAIRS of neighbouring samples, software-pipelined over the rows (round 5) -------------------------------------------
+// The one-pass 2^15 row kernel above holds a row in 1024 threads x 64 data registers: no room for a second row, so load, compute and store of a row run in series
+// (4.0-4.3 TB/s; the stores alone keep the waves stalled at their issue for as long as the loads take).  Here a 16-byte load brings the samples (x[2i], x[2i+1]) —
+// the i-th points of the two interleaved half-length sequences of a decimation-in-time split — which are exactly the "two adjacent columns" of the packed-pair
+// stages: ONE 2^14-point transform on register pairs (SCH) gives E[k] and O[k] in the two lanes, and X[k] = E[k] + w^k O[k], X[k + 2^14] = E[k] - w^k O[k] is one layer in
+// registers.  512 threads x 256 registers hold a row (128) plus half of the next one: the workgroup is persistent, the first half of the next row travels during the
+// stages and the stores, the second half is requested behind the stores.
+template <typename T, typename SCH, int TWG>
+__global__ void __launch_bounds__((1 << SCH::LOGN) >> SCH::LOGE, 2) pow2_row_pairs_kernel(const PassParams p) {
+	constexpr int LOGN2 = SCH::LOGN, N2 = 1 << LOGN2, LOGE = SCH::LOGE, E = 1 << LOGE, TPF = N2 / E, H = E / 2;
+	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
+	typedef Pow2Sched<SCH::bits[0], SCH::bits[1], SCH::bits[2], 1> SF; // (table layout of the planner: SCH's runs, then w_N^k, k < N / 2)
+	constexpr int LUTC = SF::lutOff(3);
+	static_assert(SCH::bits[3] == 0 && sizeof(T) == 4, "three stages on pairs of fp32 samples");
+	__shared__ __attribute__((aligned(16))) T plane[pow2_lean_plane_elems<SCH, 2>()];
+	const uint32_t tau = threadIdx.x;
+	const uint32_t total = p.tilesPerG0 * p.dim[1].count * p.dim[2].count;
+	const GBuf glut = make_gbuf(p.lut);
+	pk4<T> ra[H], rb[H]; // the two halves of a row while they travel
+	auto rowBase = [&](uint32_t w, bool out) -> int64_t {
+		uint32_t wg = p.reverseTiles ? total - 1u - w : w;
+		const uint32_t f0 = wg % p.tilesPerG0; wg /= p.tilesPerG0;
+		const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
+		return out ? (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride
+		           : (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride;
+	};
+	// half h of row w: pairs i = tau + m TPF, m in [h H, h H + H).  (No zero-padding masks: Pow2Variant::noPadMasks sends a padded pass to the one-row kernel above)
+	auto request = [&](uint32_t w, int h, pk4<T>* raw) {
+		VKFFT_OPAQUE_ZERO(oq);
+		const bool live = w < total;
+		const GBuf gin = make_gbuf((const cx<T>*)p.in + (live ? rowBase(w, false) : 0));
+		const uint32_t lane = live ? tau * 2u * ES + oq : kGbInvalid;
+#pragma unroll
+		for (int m = 0; m < H; m++) raw[m] = gb_load_aos2<T, 0>(gin, lane, (uint32_t)((h * H + m) * TPF) * 2u * ES);
+	};
+	uint32_t w = blockIdx.x;
+	request(w, 0, ra);
+	request(w, 1, rb);
+	for (; w < total; w += gridDim.x) {
+		cxp<T> v[E];
+#pragma unroll
+		for (int m = 0; m < H; m++) v[m] = pk_from_aos<T>(ra[m]);
+#pragma unroll
+		for (int m = 0; m < H; m++) v[H + m] = pk_from_aos<T>(rb[m]);
+		if (p.swapIn) { // inverse = conj . forward . conj
+#pragma unroll
+			for (int m = 0; m < E; m++) v[m].im = -v[m].im;
+		}
+		request(w + gridDim.x, 0, ra); // the first half of the next row travels during the stages and the stores
+		pk_lean_stages<T, SCH, 0, TPF, 2, TwGlobal<T>, TWG>(v, plane, TwGlobal<T>{glut}, tau);
+		VKFFT_SYNC(); // the last exchange's reads are complete in every wave: the next row's first exchange may write the plane
+		const T sc = (T)p.scale, sci = p.swapOut ? -sc : sc;
+		const GBuf gout = make_gbuf((cx<T>*)p.out + rowBase(w, true));
+		VKFFT_OPAQUE_ZERO(oz);
+		const uint32_t lane = tau * ES + oz;
+		constexpr int CH = 8; // twiddles of the last layer in flight at a time
+#pragma unroll
+		for (int m0 = 0; m0 < E; m0 += CH) {
+			pk2<T> tw[CH];
+#pragma unroll
+			for (int i = 0; i < CH; i++) tw[i] = pk_tw<T>(TwGlobal<T>{glut}, tau, (uint32_t)(LUTC + (m0 + i) * TPF));
+			VKFFT_SCHED_FENCE();
+#pragma unroll
+			for (int i = 0; i < CH; i++) {
+				const int m = m0 + i;
+				const T tr = v[m].re.y * tw[i].x - v[m].im.y * tw[i].y, ti = v[m].re.y * tw[i].y + v[m].im.y * tw[i].x; // w^k O[k]
+				const cx<T> lo = {(v[m].re.x + tr) * sc, (v[m].im.x + ti) * sci}, hi = {(v[m].re.x - tr) * sc, (v[m].im.x - ti) * sci};
+				gb_store<T>(gout, lane, (uint32_t)(m * TPF) * ES, lo);
+				gb_store<T>(gout, lane, (uint32_t)(m * TPF + N2) * ES, hi);
+			}
+			VKFFT_SCHED_FENCE();
+		}
+		request(w + gridDim.x, 1, rb); // (behind the stores: it is there when they are)
+	}
+}
+template <typename T, typename SCH, int TWG> void pow2_row_pairs_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
+	const unsigned resident = pow2_num_cus(); // persistent: one 135 KiB workgroup per CU, the rows dealt round-robin
+	hipLaunchKernelGGL((pow2_row_pairs_kernel<T, SCH, TWG>), dim3(grid.x < resident ? grid.x : resident), dim3((1 << SCH::LOGN) >> SCH::LOGE), 0, s, prm);
 }
 
 } // namespace vkfft_mi355x

@@ -65,48 +65,32 @@ constexpr int fused_min(int a, int b) { return a < b ? a : b; }
 
 // first entry of each (log2 N, dp, mode) is the default; VKFFT_MI355X_FUV<log2n>=k selects the k-th shape (tuning)
 static const Pow2FusedVariant kPow2FusedVariants[] = {
-	// fp32.  First entry of a size = what ships; the ones after it are the shapes it was measured against (VKFFT_MI355X_FUV<k> selects them).
-	// Round 4: the software-pipelined form (kernel_pow2_fused_pipe.h) for 2^16 ... 2^20: +4 % (2^18) ... +15 % (2^17) over the round-2/3 shapes that
-	// follow it (two adjacent columns per thread; one column per thread; register-lean plane-split form without the pipelining).
-	// 2^15 = 128 x 256 (only with VKFFT_MI355X_ROW15=0: 2^15 ships as ONE pass of the register-lean row kernel, 4.2 against 3.2-3.5 TB/s)
+	// fp32.  First entry of a size = what ships: the packed-pair software-pipelined form (kernel_pow2_fused_pk.h, round 5); second entry = the round-4 pipelined form it
+	// was measured against (VKFFT_MI355X_FUV<k>=1).  The round-2 / round-3 shapes (two columns per thread without pipelining, the plane-split form at two workgroups per
+	// CU, 8-column 2048-point tiles) lost every comparison since and are no longer instantiated.
+	// 2^15 = 128 x 256 (only with VKFFT_MI355X_ROW15=0: 2^15 ships as ONE pass of the packed row kernel, 4.0-4.3 against 3.5 TB/s)
 	VKFFT_FUK(float, false, 4, 3, 0, 32, 4, 4, 0, 16, 1, 4),
 	VKFFT_FUP(float, false, 4, 3, 0, 32, 4, 4, 0, 16, 1, 4),
-	VKFFT_FU2(float, false, 4, 3, 0, 32, 4, 4, 0, 16),
-	VKFFT_FUL(float, false, 4, 3, 0, 32, 4, 4, 0, 16, 1),
 	// 2^16 = 256 x 256
 	VKFFT_FUK(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 1, 2),
 	VKFFT_FUP(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 1, 2),
-	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 4, 0, 32),
-	VKFFT_FUL(float, false, 4, 4, 0, 32, 4, 4, 0, 32, 1),
 	// 2^17 = 256 x 512
 	VKFFT_FUK(float, false, 4, 4, 0, 32, 4, 3, 2, 16, 1, 2),
 	VKFFT_FUP(float, false, 4, 4, 0, 32, 4, 3, 2, 16, 1, 2),
-	VKFFT_FU2(float, false, 4, 4, 0, 32, 4, 3, 2, 16),
-	VKFFT_FUL(float, false, 4, 4, 0, 32, 4, 3, 2, 16, 1),
 	// 2^18 = 512 x 512
 	VKFFT_FUK(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 2),
 	VKFFT_FUP(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 2),
-	VKFFT_FU2(float, false, 4, 3, 2, 16, 4, 3, 2, 16),
-	VKFFT_FULC(float, false, 4, 3, 2, 16, 4, 3, 2, 16, 1, 2),
-	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: 128 KiB tiles, one workgroup per CU (512 threads x 256 registers = the whole register file: one tile
-	// computing + one tile in flight); 8-column tiles (two workgroups per CU, 64-byte segments on the HBM side) measured 12 % slower, 2^20 as
-	// 512 x 2048 20 % slower, the plane-split form at two workgroups per CU without the pipelining 7-16 % slower (it is VALU/LDS-bound, r04 profile)
+	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: 128 KiB tiles, one workgroup per CU (512 threads x 256 registers: one tile computing + one tile in flight)
 	VKFFT_FUK(float, false, 4, 3, 2, 32, 4, 3, 3, 16, 1, 1),
 	VKFFT_FUP(float, false, 4, 3, 2, 32, 4, 3, 3, 16, 1, 1),
-	VKFFT_FU2(float, false, 4, 3, 2, 32, 4, 3, 3, 16),
-	VKFFT_FUL(float, false, 4, 3, 2, 32, 4, 3, 3, 16, 0),
 	VKFFT_FUK(float, false, 4, 3, 3, 16, 4, 3, 3, 16, 1, 1),
 	VKFFT_FUP(float, false, 4, 3, 3, 16, 4, 3, 3, 16, 1, 1),
-	VKFFT_FU2(float, false, 4, 3, 3, 16, 4, 3, 3, 16),
-	VKFFT_FUL(float, false, 4, 3, 3, 16, 4, 3, 3, 16, 0),
-	// register-lean (round 4): 2048-point tiles 16 columns wide (128-byte segments), 1024 threads, 139 KiB planes: 2^21 +4.5 %, 2^22 +29 % over the 8-column shapes below
-	// round 5: tiles of two halves, software-pipelined at half-tile granularity (2^21 = 2048 x 1024 — the other orientation measured the same —, 2^22 = 2048 x 2048)
-	VKFFT_FUH(1, 0, 1), VKFFT_FUH(1, 1, 1),
+	// 2^21 = 2048 x 1024 (the other orientation measured the same), 2^22 = 2048 x 2048: tiles of two halves, software-pipelined at half-tile granularity (round 5);
+	// second entry = the round-4 shape (register-lean 2048-point tiles 16 columns wide, 1024 threads, no pipelining)
+	VKFFT_FUH(1, 0, 1),
 	VKFFT_FUL(float, false, 4, 3, 3, 32, 4, 4, 3, 16, 0),
+	VKFFT_FUH(1, 1, 1),
 	VKFFT_FUL(float, false, 4, 4, 3, 16, 4, 4, 3, 16, 0),
-	VKFFT_FUT(float, false, 5, 5, 0, 16, 5, 3, 3, 8, 0),
-	VKFFT_FUT(float, false, 5, 3, 3, 8, 5, 5, 0, 16, 0),
-	VKFFT_FUT(float, false, 5, 3, 3, 8, 5, 3, 3, 8, 0),
 	// fp64: 16-byte elements, 8-16 columns = 128-256-byte segments.  2^14 = 128 x 128, 2^15 = 128 x 256, 2^16 = 256 x 256, 2^17 = 256 x 512
 	VKFFT_FU(double, true, 4, 3, 0, 16, 4, 3, 0, 16),
 	VKFFT_FU(double, true, 4, 3, 0, 16, 4, 4, 0, 8),

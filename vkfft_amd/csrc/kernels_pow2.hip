@@ -39,6 +39,10 @@ template <typename T, typename SCH, int TC> void pow2_col_launch(const PassParam
 #define VKFFT_P2KF(T, dp, b0, b1, b2, b3, wpe, twg, fpw) \
 	{ (b0) + (b1) + (b2) + (b3), dp, {b0, b1, b2, b3}, fpw, ((1 << ((b0) + (b1) + (b2) + (b3))) >> Pow2Sched<b0, b1, b2, b3>::LOGE) * (fpw), &pow2_row_lean_pk_launch<T, Pow2Sched<b0, b1, b2, b3>, wpe, twg, fpw>, "pow2_row_lean_pk_kernel" }
 
+// 2^15 as 2^14 pairs of neighbouring samples, persistent and software-pipelined over the rows (bits: the pair transform's three stages + the last layer's run of the table)
+#define VKFFT_P2R(T, dp, b0, b1, b2, twg) \
+	{ (b0) + (b1) + (b2) + 1, dp, {b0, b1, b2, 1}, 1, ((1 << ((b0) + (b1) + (b2))) >> Pow2Sched<b0, b1, b2, 0>::LOGE), &pow2_row_pairs_launch<T, Pow2Sched<b0, b1, b2, 0>, twg>, "pow2_row_pairs_kernel", true }
+
 // first entry of each (log2n, dp) is the default; VKFFT_MI355X_P2V<log2n>=k selects the k-th (tuning)
 static const Pow2Variant kPow2Variants[] = {
 	// fp32
@@ -47,20 +51,24 @@ static const Pow2Variant kPow2Variants[] = {
 	VKFFT_P2(float, false, 4, 0, 0, 0, 64),
 	VKFFT_P2(float, false, 3, 2, 0, 0, 32),
 	VKFFT_P2(float, false, 3, 3, 0, 0, 32),
-	VKFFT_P2(float, false, 4, 3, 0, 0, 16), VKFFT_P2(float, false, 3, 2, 2, 0, 16),
-	VKFFT_P2(float, false, 4, 4, 0, 0, 8), VKFFT_P2(float, false, 4, 4, 0, 0, 16), VKFFT_P2(float, false, 3, 3, 2, 0, 8), VKFFT_P2(float, false, 3, 3, 2, 0, 4),
-	// round 5: 2^9 ... 2^12 on the packed (x, y) rows of kernel_pow2_pk.h, several rows per workgroup (A/B on one box, paired TB/s: 2^9 5.72 -> 6.09, 2^10 5.42 -> 6.07,
-	// 2^11 5.24 -> 5.69, 2^12 5.24 -> 5.67; 16 points per thread where there are three stages: 68-80 VGPRs, six to seven waves per SIMD; 2^8 stays: 6.07 against 5.99)
-	VKFFT_P2KF(float, false, 5, 4, 0, 0, 4, 16, 16), VKFFT_P2(float, false, 5, 4, 0, 0, 8), VKFFT_P2(float, false, 4, 3, 2, 0, 8), VKFFT_P2(float, false, 3, 3, 3, 0, 4), VKFFT_P2(float, false, 4, 3, 2, 0, 4), VKFFT_P2(float, false, 5, 4, 0, 0, 4),
-	VKFFT_P2KF(float, false, 5, 5, 0, 0, 4, 16, 8), VKFFT_P2(float, false, 5, 5, 0, 0, 8), VKFFT_P2(float, false, 4, 3, 3, 0, 4), VKFFT_P2(float, false, 4, 3, 3, 0, 2), VKFFT_P2(float, false, 5, 5, 0, 0, 4), VKFFT_P2(float, false, 5, 5, 0, 0, 2),
-	VKFFT_P2KF(float, false, 4, 4, 3, 0, 5, 16, 4), VKFFT_P2(float, false, 5, 5, 1, 0, 2), VKFFT_P2(float, false, 4, 4, 3, 0, 1), VKFFT_P2(float, false, 4, 4, 3, 0, 2), VKFFT_P2(float, false, 5, 5, 1, 0, 4), VKFFT_P2(float, false, 4, 4, 3, 0, 4),
-	VKFFT_P2KF(float, false, 4, 4, 4, 0, 5, 16, 1), VKFFT_P2(float, false, 4, 4, 4, 0, 1), VKFFT_P2(float, false, 5, 5, 2, 0, 1), VKFFT_P2(float, false, 4, 4, 4, 0, 2), VKFFT_P2(float, false, 5, 5, 2, 0, 2),
-	// 2^13 (P2V13 = 0 .. 5): register-lean rows, four 256-thread workgroups per CU; index 1 is the round-1..3 kernel (two 67 KiB workgroups per CU)
-	VKFFT_P2K(float, false, 5, 4, 4, 0, 4, 16), VKFFT_P2(float, false, 5, 4, 4, 0, 1), VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 16, 0), VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 16, 16), VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 8, 16), VKFFT_P2L(float, false, 5, 5, 3, 0, 4, 16, 16), VKFFT_P2(float, false, 4, 3, 3, 3, 1),
-	// 2^14: register-lean rows, two 512-thread workgroups per CU; index 1 is the round-1..3 kernel (one 135 KiB workgroup per CU)
-	VKFFT_P2K(float, false, 5, 5, 4, 0, 4, 16), VKFFT_P2(float, false, 5, 5, 4, 0, 1), VKFFT_P2L(float, false, 5, 5, 4, 0, 4, 16, 0), VKFFT_P2L(float, false, 5, 5, 4, 0, 4, 16, 16), VKFFT_P2L(float, false, 5, 5, 4, 0, 4, 8, 16), VKFFT_P2L(float, false, 5, 4, 5, 0, 4, 16, 16), VKFFT_P2(float, false, 4, 4, 3, 3, 1),
-	// 2^15 in ONE pass: 1024 threads x 32 points in registers, the 135 KiB plane is all of a CU's LDS budget (VKFFT_MI355X_ROW15=0: the fused two-pass kernel)
-	VKFFT_P2K(float, false, 5, 5, 5, 0, 4, 16), VKFFT_P2L(float, false, 5, 5, 5, 0, 4, 16, 0), VKFFT_P2L(float, false, 5, 5, 5, 0, 4, 16, 16), VKFFT_P2L(float, false, 5, 5, 5, 0, 4, 16, 8), VKFFT_P2L(float, false, 5, 5, 5, 0, 4, 8, 16),
+	VKFFT_P2(float, false, 4, 3, 0, 0, 16),
+	VKFFT_P2(float, false, 4, 4, 0, 0, 8),
+	// round 5: 2^9 / 2^10 on the packed (x, y) rows of kernel_pow2_pk.h, several rows per workgroup (A/B on three boxes, profiles/r05_ab_small_sizes_*: 2^9 5.72 -> 6.09 /
+	// 5.94 -> 5.98, 2^10 5.42 -> 6.07 / 5.58 -> 5.92 TB/s paired).  2^11 / 2^12 keep the round-1 kernel: their packed form (16 points per thread, 68-80 VGPRs, six to seven
+	// waves per SIMD; index 1) won on one box (5.24 -> 5.69 / 5.67) and tied or lost by 1 % on two (5.44 / 5.48 -> 5.41 / 5.43; 5.33 / 5.36 -> 5.27 / 5.31); 2^8 stays: 6.07
+	// against 5.99.  Index 1 of 2^9 / 2^10 = the kernel that shipped before; the other shapes of rounds 1-4 that lost their comparisons are no longer instantiated
+	VKFFT_P2KF(float, false, 5, 4, 0, 0, 4, 16, 16), VKFFT_P2(float, false, 5, 4, 0, 0, 8),
+	VKFFT_P2KF(float, false, 5, 5, 0, 0, 4, 16, 8), VKFFT_P2(float, false, 5, 5, 0, 0, 8),
+	VKFFT_P2(float, false, 5, 5, 1, 0, 2), VKFFT_P2KF(float, false, 4, 4, 3, 0, 5, 16, 4),
+	VKFFT_P2(float, false, 4, 4, 4, 0, 1), VKFFT_P2KF(float, false, 4, 4, 4, 0, 5, 16, 1),
+	// 2^13: packed register-lean rows, four 256-thread workgroups per CU; index 1 the round-1..3 kernel (two 67 KiB workgroups per CU), index 2 the round-4 lean kernel
+	VKFFT_P2K(float, false, 5, 4, 4, 0, 4, 16), VKFFT_P2(float, false, 5, 4, 4, 0, 1), VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 16, 0),
+	// 2^14: two 512-thread workgroups per CU; index 1 the round-1..3 kernel (one 135 KiB workgroup per CU), index 2 the round-4 lean kernel
+	VKFFT_P2K(float, false, 5, 5, 4, 0, 4, 16), VKFFT_P2(float, false, 5, 5, 4, 0, 1), VKFFT_P2L(float, false, 5, 5, 4, 0, 4, 16, 0),
+	// 2^15 in ONE pass (VKFFT_MI355X_ROW15=0: the fused two-pass kernel): as 2^14 pairs of neighbouring samples in persistent 512-thread workgroups, half of the next
+	// row in flight (pow2_row_pairs_kernel, round 5: 4.44-4.48 against 4.33-4.35 TB/s); index 1: one row in 1024 threads x 32 points on packed pairs (also what a
+	// zero-padded row takes: the pairs kernel has no masks), index 2 the round-4 lean kernel
+	VKFFT_P2R(float, false, 5, 5, 4, 8), VKFFT_P2K(float, false, 5, 5, 5, 0, 4, 16), VKFFT_P2L(float, false, 5, 5, 5, 0, 4, 16, 0),
 	// fp64
 	VKFFT_P2(double, true, 2, 0, 0, 0, 64),
 	VKFFT_P2(double, true, 3, 0, 0, 0, 64),
@@ -185,7 +193,7 @@ int launch_pow2(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 }
 
 
-static bool pow2_lookup(const Pow2Variant* tab, int ntab, const char* envPrefix, uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads) {
+static bool pow2_lookup(const Pow2Variant* tab, int ntab, const char* envPrefix, uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads, bool padded = false) {
 	int want = 0;
 	char name[64];
 	snprintf(name, sizeof(name), "%s%u", envPrefix, log2n);
@@ -193,6 +201,7 @@ static bool pow2_lookup(const Pow2Variant* tab, int ntab, const char* envPrefix,
 	int seen = 0, found = -1;
 	for (int i = 0; i < ntab; i++) {
 		if (tab[i].log2n != (int)log2n || tab[i].dp != dp) continue;
+		if (padded && tab[i].noPadMasks) { seen++; continue; }
 		if (found < 0) found = i;
 		if (seen == want) { found = i; break; }
 		seen++;
@@ -203,8 +212,8 @@ static bool pow2_lookup(const Pow2Variant* tab, int ntab, const char* envPrefix,
 	*fpw = tab[found].fpw; *threads = tab[found].threads;
 	return true;
 }
-bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads) {
-	return pow2_lookup(kPow2Variants, kNumPow2Variants, "VKFFT_MI355X_P2V", log2n, dp, variant, bits, fpw, threads);
+bool pow2_row_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* fpw, int* threads, bool padded) {
+	return pow2_lookup(kPow2Variants, kNumPow2Variants, "VKFFT_MI355X_P2V", log2n, dp, variant, bits, fpw, threads, padded);
 }
 bool pow2_col_lookup(uint32_t log2n, bool dp, int* variant, int bits[4], int* tc, int* threads) {
 	return pow2_lookup(kPow2ColVariants, kNumPow2ColVariants, "VKFFT_MI355X_P2C", log2n, dp, variant, bits, tc, threads);

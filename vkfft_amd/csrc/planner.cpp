@@ -1427,7 +1427,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	if (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N >= 4 && j.N <= (dp ? 8192u : (row15 ? 32768u : 16384u))) {
 		int variant, bits[4], fpw, thr;
 		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
-		p2rowOK = (rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && pow2_row_lookup(ilog2(j.N), dp, &variant, bits, &fpw, &thr);
+		p2rowOK = (rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && pow2_row_lookup(ilog2(j.N), dp, &variant, bits, &fpw, &thr, padded);
 	}
 	if (j.N <= singleCap || p2rowOK) {
 		b.L = j.N;
@@ -1442,7 +1442,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		if (unit && !d.disableFastKernels && (j.N & (j.N - 1)) == 0 && j.N >= 4) {
 			int variant, bits[4], fpw, thr;
 			uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
-			if ((rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && pow2_row_lookup(ilog2(j.N), dp, &variant, bits, &fpw, &thr)) {
+			if ((rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && pow2_row_lookup(ilog2(j.N), dp, &variant, bits, &fpw, &thr, padded)) {
 				b.fastKernel = KERNEL_POW2_ROW; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
 				for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
 			}
