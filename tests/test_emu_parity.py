@@ -389,7 +389,7 @@ def test_register_lean_row_strides_padding_and_scale(run, oracle, N):
     assert convpad.zeropad_case(run, (N,), {0: (N // 4 + 1, N // 2 + 3)}, batch=3) < 3e-6  # (an inner range with odd ends)
 
 
-@pytest.mark.parametrize("k,variant,batch", [(15, 0, 5), (15, 1, 5), (16, 1, 3), (17, 1, 3), (18, 1, 3), (19, 1, 2), (20, 1, 2), (21, 0, 1), (21, 1, 1), (22, 0, 1), (22, 1, 1)])
+@pytest.mark.parametrize("k,variant,batch", [(15, 0, 5), (15, 1, 5), (16, 1, 3), (17, 1, 3), (18, 1, 3), (19, 1, 2), (20, 1, 2), (20, 2, 2), (21, 0, 1), (21, 1, 1), (22, 0, 1), (22, 1, 1)])
 def test_fused_fourstep_every_registered_shape(run, oracle, monkeypatch, k, variant, batch):
     """every shape in the fused Four-Step registry besides the defaults the other tests run: index 0 = what ships (2^16 ... 2^20: the packed-pair
     software-pipelined form, kernel_pow2_fused_pk.h; 2^21 / 2^22: packed-pair tiles of two halves, kernel_pow2_fused_pkh.h), then the round-4 pipelined form,

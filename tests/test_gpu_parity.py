@@ -78,7 +78,7 @@ def test_register_lean_rows_every_variant_on_device(run, oracle, monkeypatch, k,
     assert np.array_equal(np.tile(y, reps).view(np.uint8), big.view(np.uint8))
 
 
-@pytest.mark.parametrize("k,variant", [(k, v) for k in range(15, 23) for v in range(2)])
+@pytest.mark.parametrize("k,variant", [(k, v) for k in range(15, 23) for v in range(2)] + [(20, 2)])
 def test_fused_fourstep_every_registered_shape_on_device(run, oracle, monkeypatch, k, variant):
     """every shape of the fused Four-Step registry (index 0 ships: the packed-pair software-pipelined form for 2^16 ... 2^20, kernel_pow2_fused_pk.h, and the
     packed-pair tiles of two halves for 2^21 / 2^22, kernel_pow2_fused_pkh.h; the others are the round-2 ... round-4 shapes they were measured against),

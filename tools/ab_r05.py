@@ -8,7 +8,7 @@ from ab_lean import run, stress
 AB = {
     9: [{}, {"P2V9": 1}], 10: [{}, {"P2V10": 1}], 11: [{}, {"P2V11": 1}], 12: [{}, {"P2V12": 1}],
     13: [{}, {"P2V13": 2}], 14: [{}, {"P2V14": 2}], 15: [{}, {"P2V15": 1}, {"P2V15": 2}],
-    16: [{}, {"FUV16": 1}], 17: [{}, {"FUV17": 1}], 18: [{}, {"FUV18": 1}], 19: [{}, {"FUV19": 1}], 20: [{}, {"FUV20": 1}],
+    16: [{}, {"FUV16": 1}], 17: [{}, {"FUV17": 1}], 18: [{}, {"FUV18": 1}], 19: [{}, {"FUV19": 1}], 20: [{}, {"FUV20": 1}, {"FUV20": 2}],
     21: [{}, {"FUV21": 1}], 22: [{}, {"FUV22": 1}],
 }
 TUNE = {

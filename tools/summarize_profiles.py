@@ -50,13 +50,13 @@ for kname, c in cnt.items():
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c: e["bytes_per_launch"] = e["fetch_bytes_corrected"] + e["write_bytes"]
     summ["kernels"][kname[:150]] = e
 # the instance of every size: log2 N from the template arguments of the kernel's name (row kernels: the bits of their schedule; fused kernels: the bits of
-# both factors; tiles of two halves: 20 + the two split flags) — bench.py reads by_log2N[size the roofline names]
+# both factors; tiles of two halves: twice the half's bits + the two split flags) — bench.py reads by_log2N[size the roofline names]
 import re
 summ["by_log2N"] = {}
 for kname, e in summ["kernels"].items():
     if "bytes_per_launch" not in e or "vkfft_mi355x::pow2_" not in kname: continue
-    m = re.search(r"pow2_fused_pkh_kernel<float, (\d), (\d)", kname)
-    if m: k = 20 + int(m.group(1)) + int(m.group(2))
+    m = re.search(r"pow2_fused_pkh_kernel<float, (?:vkfft_mi355x::)?Pow2Sched<(\d+), (\d+), (\d+), 0>, (\d), (\d)", kname)
+    if m: k = 2 * (int(m.group(1)) + int(m.group(2)) + int(m.group(3))) + int(m.group(4)) + int(m.group(5))
     else:
         sch = re.findall(r"Pow2Sched<(\d+), (\d+), (\d+), (\d+)>", kname)
         if not sch or "col" in kname or "blue" in kname: continue

@@ -25,14 +25,14 @@
 
 namespace vkfft_mi355x {
 
-// SPLITA / SPLITB: the factor of that side has 2048 points (two row-interleaved halves + combine) instead of 1024 (two column groups)
-template <typename T, int SPLITA, int SPLITB, int MODE, int TWL>
-__global__ void __launch_bounds__(512, 2) pow2_fused_pkh_kernel(const FusedParams p) {
-	static_assert(sizeof(T) == 4, "two fp32 columns per thread");
-	typedef Pow2Sched<4, 3, 3, 0> SH; // a half: 1024 points, 16 per thread and column
-	typedef Pow2Sched<4, 3, 3, 1> SF; // (table layout of a 2048-point factor: SH's runs, then w_2048^k, k < 1024)
-	constexpr int L = 1024, E = 16, TPF = 64, TC = 16, NT = 512;
-	constexpr int LA = SPLITA ? 2048 : 1024, LB = SPLITB ? 2048 : 1024;
+// SH: the schedule of a half (L = 1024 points: 512 threads, one workgroup per CU; L = 512: 256 threads, two workgroups per CU — 256 registers per thread either way).
+// SPLITA / SPLITB: the factor of that side has 2 L points (two row-interleaved halves + combine) instead of L (two column groups)
+template <typename T, typename SH, int SPLITA, int SPLITB, int MODE, int TWL>
+__global__ void __launch_bounds__(((1 << SH::LOGN) >> SH::LOGE) * 8, 2) pow2_fused_pkh_kernel(const FusedParams p) {
+	static_assert(sizeof(T) == 4 && SH::bits[3] == 0, "two fp32 columns per thread; three stages per half");
+	typedef Pow2Sched<SH::bits[0], SH::bits[1], SH::bits[2], 1> SF; // (table layout of a 2 L-point factor: SH's runs, then w_2L^k, k < L)
+	constexpr int L = 1 << SH::LOGN, E = 1 << SH::LOGE, TPF = L / E, TC = 16, NT = TPF * TC / 2;
+	constexpr int LA = SPLITA ? 2 * L : L, LB = SPLITB ? 2 * L : L;
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	constexpr int AUX_SC = 16, AUX_ST = 16;       // ring: memory-side loads, write-through stores
 	constexpr int AUX_HBM = (MODE & 2) ? 2 : 0;   // streamed side: non-temporal hint
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(512, 2) pow2_fused_pkh_kernel(const FusedParam
 		const GBuf gs = make_gbuf(sbase + (uint64_t)col0 * LA * ES);
 		if (live) { // (ONE region: register arrays that live across several conditional regions are copied at every merge)
 			// the Four-Step twiddle's table look-ups travel during the stages (pk_fs_request); the second half of a 2048-point factor needs ONE more: w_N^(1024 j)
-			PkFsTw<T, SH::LOGE> fsq, fsq2;
+			PkFsTw<T, SH::LOGE> fsq;
 			pk2<T> fshLo = pk2<T>{(T)1, (T)0}, fshHi = fshLo;
 			cxp<T> vE[E], vO[E];
 #pragma unroll
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(512, 2) pow2_fused_pkh_kernel(const FusedParam
 				const uint32_t e = (uint32_t)L * (col0 + cl), loMask = (1u << p.fsLoBits) - 1u;
 				const cx<T> a = gb_load<T>(gtw, (e & loMask) * ES, 0), b = gb_load<T>(gtw, (e >> p.fsLoBits) * ES, (loMask + 1u) * ES);
 				fshLo = pk2<T>{a.x, a.y}; fshHi = pk2<T>{b.x, b.y};
-			} else pk_fs_request<T, SH::LOGE, TPF>(fsq2, gtw, p.fsLoBits, tau, col0 + 16u + cl);
+			}
 #pragma unroll
 			for (int m = 0; m < E; m++) vO[m] = pk_from_aos<T>(rawO[m]);
 			if (p.swapIn) {
@@ -198,9 +198,8 @@ __global__ void __launch_bounds__(512, 2) pow2_fused_pkh_kernel(const FusedParam
 			if constexpr (SPLITA) { // points k + 1024 of the same columns: every factor times w_N^(1024 j)
 				const pk2<T> hs = pk_cmul_aos<T>(fshLo, fshHi);
 				twiddle(vO, tau + (uint32_t)L, &hs);
-			} else { // the other 16 columns: their own look-ups (requested behind the first half's stages)
-				fsq = fsq2;
-				twiddle(vO, tau, nullptr);
+			} else { // the other 16 columns: their own look-ups, requested now that the first half's are consumed (they travel during the first turn)
+				pk_fs_request<T, SH::LOGE, TPF>(fsq, gtw, p.fsLoBits, tau, col0 + 16u + cl);
 			}
 			VKFFT_SYNC(); // the last exchange's reads are complete
 			VKFFT_PKPROF(9);
@@ -215,6 +214,7 @@ __global__ void __launch_bounds__(512, 2) pow2_fused_pkh_kernel(const FusedParam
 				}
 			}
 			if (hasB && !okB) fused_wait(p.ctr + depB(s), TPC); // rare (the flag was sampled one ticket ago)
+			if constexpr (!SPLITA) twiddle(vO, tau, nullptr);
 			requestB(0, bE); // (behind the first half's ring stores: it travels during the second turn)
 			VKFFT_SYNC(); // the plane is free again
 			{
@@ -313,8 +313,8 @@ __global__ void __launch_bounds__(512, 2) pow2_fused_pkh_kernel(const FusedParam
 	}
 }
 
-template <typename T, int SPLITA, int SPLITB, int MODE, int TWL> void pow2_fused_pkh_launch(const FusedParams& prm, dim3 grid, hipStream_t s) {
-	hipLaunchKernelGGL((pow2_fused_pkh_kernel<T, SPLITA, SPLITB, MODE, TWL>), grid, dim3(512), 0, s, prm);
+template <typename T, typename SH, int SPLITA, int SPLITB, int MODE, int TWL> void pow2_fused_pkh_launch(const FusedParams& prm, dim3 grid, hipStream_t s) {
+	hipLaunchKernelGGL((pow2_fused_pkh_kernel<T, SH, SPLITA, SPLITB, MODE, TWL>), grid, dim3(((1 << SH::LOGN) >> SH::LOGE) * 8), 0, s, prm);
 }
 
 } // namespace vkfft_mi355x

@@ -56,9 +56,12 @@ constexpr int fused_min(int a, int b) { return a < b ? a : b; }
 	  &pow2_fused_pk_launch<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, wgc>, \
 	  (const void*)&pow2_fused_pk_kernel<T, Pow2Sched<a0, a1, a2, 0>, tca, Pow2Sched<b0, b1, b2, 0>, tcb, mode, twl, wgc>, "pow2_fused_pk_kernel" }
 // tiles of two halves on packed pairs (kernel_pow2_fused_pkh.h, round 5): 2^21 / 2^22, a 2048-point factor as two interleaved 1024-point halves + one radix-2 layer
-#define VKFFT_FUHM(splita, splitb, twl, mode) \
-	{ 20 + (splita) + (splitb), false, mode, 10 + (splita), 10 + (splitb), {4, 3, 3, splita}, {4, 3, 3, splitb}, (splita) ? 16 : 32, (splitb) ? 16 : 32, 512, 1, \
-	  &pow2_fused_pkh_launch<float, splita, splitb, mode, twl>, (const void*)&pow2_fused_pkh_kernel<float, splita, splitb, mode, twl>, "pow2_fused_pkh_kernel" }
+#define VKFFT_FUHM(splita, splitb, twl, mode) VKFFT_FUHL(4, 3, 3, splita, splitb, twl, mode)
+// h0 + h1 + h2 = log2 of a half's length (10: 512 threads, one workgroup per CU; 9: 256 threads, two)
+#define VKFFT_FUHL(h0, h1, h2, splita, splitb, twl, mode) \
+	{ 2 * ((h0) + (h1) + (h2)) + (splita) + (splitb), false, mode, (h0) + (h1) + (h2) + (splita), (h0) + (h1) + (h2) + (splitb), {h0, h1, h2, splita}, {h0, h1, h2, splitb}, (splita) ? 16 : 32, (splitb) ? 16 : 32, \
+	  ((1 << ((h0) + (h1) + (h2))) >> Pow2Sched<h0, h1, h2, 0>::LOGE) * 8, (h0) + (h1) + (h2) >= 10 ? 1 : 2, \
+	  &pow2_fused_pkh_launch<float, Pow2Sched<h0, h1, h2, 0>, splita, splitb, mode, twl>, (const void*)&pow2_fused_pkh_kernel<float, Pow2Sched<h0, h1, h2, 0>, splita, splitb, mode, twl>, "pow2_fused_pkh_kernel" }
 #define VKFFT_FUT(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, twl, 1)
 #define VKFFT_FU(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 1)
 #define VKFFT_FU2(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb) VKFFT_FUC(T, dp, a0, a1, a2, tca, b0, b1, b2, tcb, 1, 2) /* two columns per thread */
@@ -83,6 +86,10 @@ static const Pow2FusedVariant kPow2FusedVariants[] = {
 	// 2^19 = 512 x 1024, 2^20 = 1024 x 1024: 128 KiB tiles, one workgroup per CU (512 threads x 256 registers: one tile computing + one tile in flight)
 	VKFFT_FUK(float, false, 4, 3, 2, 32, 4, 3, 3, 16, 1, 1),
 	VKFFT_FUP(float, false, 4, 3, 2, 32, 4, 3, 3, 16, 1, 1),
+	// (2^19 = 512 x 1024 as tiles of two 512-point halves — VKFFT_FUHL(4, 3, 2, 0, 1, 1, 2): 256 threads, two workgroups per CU — measured 2.07-2.16 TB/s against 3.09: not instantiated)
+	// 2^20 = 1024 x 1024 as tiles of two 16-column halves (kernel_pow2_fused_pkh.h): 256-byte segments on both HBM sides, three half-tiles in registers: 3.15 against 3.07 TB/s
+	// for the 16-column packed kernel (index 1), 2.90 for the round-4 pipelined form (index 2)
+	VKFFT_FUH(0, 0, 1),
 	VKFFT_FUK(float, false, 4, 3, 3, 16, 4, 3, 3, 16, 1, 1),
 	VKFFT_FUP(float, false, 4, 3, 3, 16, 4, 3, 3, 16, 1, 1),
 	// 2^21 = 2048 x 1024 (the other orientation measured the same), 2^22 = 2048 x 2048: tiles of two halves, software-pipelined at half-tile granularity (round 5);
