@@ -671,3 +671,23 @@ def test_two_real_rows_per_transform_against_one_row_per_transform(run, monkeypa
         else:
             assert rel_l2(a[1], b[1]) < 1e-6, (N, kw)
         assert rel_l2(fa, fb) < 1e-6, (N, kw)
+
+
+@pytest.mark.parametrize("N", [13, 28, 55, 100, 169, 286, 385])
+@pytest.mark.parametrize("dp", [False, True])
+def test_table_driven_maps_of_the_real_transforms(run, oracle, monkeypatch, N, dp):
+    """kernel_tmaps.h: every family the planner builds tables for (R2C / C2R, DCT / DST I-IV), two rows per transform and an odd row count, against the oracle and
+    against the generic maps of the same plans (VKFFT_MI355X_NO_TMAPS)"""
+    batch = 5
+    parity.check_r2c(run, oracle, (N,), batch, dp)
+    for type, dst in [(1, False), (2, False), (3, False), (4, False), (1, True), (2, True), (3, True), (4, True)]:
+        parity.check_r2r(run, oracle, (N,), batch, dp, type, dst)
+    rng = np.random.default_rng(N)
+    x = rng.uniform(-1, 1, N * batch).astype(np.float64 if dp else np.float32)
+    for kw in (dict(dct=2), dict(dct=3), dict(dct=4), dict(dst=2), dict(dst=3), dict(dst=4), dict(dct=1), dict(dst=1)):
+        monkeypatch.delenv("VKFFT_MI355X_NO_TMAPS", raising=False)
+        a = run.transform(x, (N,), batch, both=True, **kw)
+        monkeypatch.setenv("VKFFT_MI355X_NO_TMAPS", "1")
+        b = run.transform(x, (N,), batch, both=True, **kw)
+        tol = 1e-13 if dp else 2e-6
+        assert rel_l2(a[0], b[0]) < tol and rel_l2(a[1], b[1]) < tol, (kw, rel_l2(a[0], b[0]), rel_l2(a[1], b[1]))

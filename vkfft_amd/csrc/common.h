@@ -116,6 +116,7 @@ struct RaderDesc {
 	FastDiv divSubNb[8], divSubS[8];
 };
 
+constexpr uint32_t kTmOn = 1u, kTmTwo = 2u, kTmSplit = 4u, kTmRowB = 8u, kTmCplx = 16u; // PassParams::tmPreFlags / tmPostFlags (kernel_tmaps.h)
 struct PassParams {
 	const void* in;
 	void* out;
@@ -168,6 +169,10 @@ struct PassParams {
 	                     // filled tiles when dim[0].count is not a multiple of the tile width (prime planes); tilesPerG0 then counts the tiles of both
 	uint32_t raderM;     // mixrad_kernel (kernel_mixrad.h): cofactor M of a row of M * P points, P the Rader prime of the instance (0 / 1: not that kernel)
 	uint32_t pairRows;   // instance kernels between the generic maps (OPS = 1): two real rows per complex transform (kernel_generic.h ops_rows_in / ops_rows_out)
+	// table-driven maps of the real transforms (kernel_tmaps.h): per FFT input position / per spectrum index { byte offsets o1, o2 } and { complex c1, c2 };
+	// flags: kTmOn | kTmTwo (second term of the pre-map is used) | kTmSplit | kTmRowB | kTmCplx (post-map forms).  0: the maps of kernel_generic.h
+	const void* tmPre; const void* tmPost;
+	uint32_t tmPreFlags, tmPostFlags;
 	uint32_t bigSpan;    // pow2_col_kernel: the tile spans 2 GiB or more on one side: 64-bit per-lane addresses instead of a buffer resource per tile
 	// merged convolution along this axis (pow2_col_blue_kernel MODE 6; reference vkFFT_Convolution.h:125): convCf coordinate systems convSysStride elements
 	// apart are transformed, multiplied per frequency by the convM x convM kernel matrix (convM <= 1: every coordinate by its own kernel component) and

@@ -33,6 +33,7 @@ struct PassPlan {
 	std::vector<HostDim> hostLoop; // outer dims iterated on the host (rare: >3 non-collapsible batch dims)
 	// arena offsets (bytes) of the tables, SIZE_MAX = none
 	size_t lutOff = (size_t)-1, auxOff = (size_t)-1, aux2Off = (size_t)-1, aux3Off = (size_t)-1, raderOff = (size_t)-1;
+	size_t tmPreOff = (size_t)-1, tmPostOff = (size_t)-1; // table-driven maps (kernel_tmaps.h)
 	// fused Four-Step launch (KERNEL_POW2_FUSED): parameter block (pointers bound at launch) and its extra arena offsets
 	FusedParams fused = {};
 	size_t fusedLutBOff = (size_t)-1, fusedCtrOff = (size_t)-1, fusedRowTabOff = (size_t)-1;
@@ -131,6 +132,7 @@ int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t st
 const char* pow2_fused_kernel_name(int variant);
 const char* pow2_row_kernel_name(int variant);
 bool mixed_row_lookup(uint64_t n, bool dp, int* variant, int rad[5], int* fpw, int* threads);
+int mixed_row_ops_fpw(int variant); // rows per workgroup of that variant's form between the maps of a real transform
 int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 // one-kernel cyclic convolution (kernel_mixconv.h), unit-stride rows or (col) tiles of neighbouring columns of a strided axis.  rader: the instance of prime p (transform length p - 1); otherwise the Bluestein instance with
 // the smallest padded length >= minLen.  *len = transform length

@@ -18,6 +18,7 @@
 #include "mix_stage.h"
 #include "kernel_generic.h"
 #include "kernel_mixrad.h"
+#include "kernel_tmaps.h"
 
 namespace vkfft_mi355x {
 
@@ -89,9 +90,29 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 		// ---- the row as it lies in memory -> LDS (dense rows: the tile is one contiguous run)
 		if constexpr (OPS != 0) {
 			const int64_t inB = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride;
-			// (the operation hoisted out of the loop: ops_rows_in, kernel_generic.h)
-			FastDiv divN; divN.d = n; divN.rcp = 1.0f / (float)n;
-			dispatch_pre_op(p.preOp, [&](auto opc) { ops_rows_in<T>(p, opc, divN, rows, (uint32_t)SP, (uint32_t)FPW * n, rowsHere, inB, f0 * p.opStride0 + g1 * p.opStride1); });
+			if (p.tmPreFlags & kTmOn) {
+				// table-driven pre-map (kernel_tmaps.h): thread group f fills its own row, every point's loads in flight at once
+				const uint32_t rA = f * rowMult;
+				const uint32_t pitch = (uint32_t)p.dim[0].inStride * p.inElemBytes;
+				const TmSide<T> ts = tm_side<T>(p.tmPre, n, make_gbuf((const char*)p.in + inB * (int64_t)p.inElemBytes), rA < rowsHere ? rA * pitch : kGbInvalid,
+				                                (rowMult == 2u && rA + 1u < rowsHere) ? (rA + 1u) * pitch : kGbInvalid);
+				constexpr int PJ = ((int)n + TPF - 1) / TPF;
+				auto fillRow = [&](auto twoTag) { // (the number of terms outside the loop: a branch per point would put a wait between the points' loads)
+#pragma unroll
+					for (int b = 0; b < PJ; b++) {
+						const uint32_t j = tau + (uint32_t)(b * TPF);
+						if ((b + 1) * TPF <= (int)n || j < n) {
+							const cx<T> v = tm_pre<T, decltype(twoTag)::value>(ts, tau, (uint32_t)(b * TPF));
+							row[j] = swI ? cswap(v) : v;
+						}
+					}
+				};
+				if (p.tmPreFlags & kTmTwo) fillRow(std::true_type{}); else fillRow(std::false_type{});
+			} else {
+				// (the operation hoisted out of the loop: ops_rows_in, kernel_generic.h)
+				FastDiv divN; divN.d = n; divN.rcp = 1.0f / (float)n;
+				dispatch_pre_op(p.preOp, [&](auto opc) { ops_rows_in<T>(p, opc, divN, rows, (uint32_t)SP, (uint32_t)FPW * n, rowsHere, inB, f0 * p.opStride0 + g1 * p.opStride1); });
+			}
 		} else if (denseIn) {
 			for (uint32_t e = tid; e < rowsHere * n; e += (uint32_t)NT) {
 				const uint32_t j = e % n;
@@ -121,6 +142,15 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 		auto fin = [&](cx<T> v) { if (swO) v = cswap(v); if (sc != (T)1) v = cscale(v, sc); return v; };
 		if constexpr (OPS != 0) {
 			const int64_t outB = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride;
+			if (p.tmPostFlags & kTmOn) {
+				const uint32_t rA = f * rowMult, flags = p.tmPostFlags;
+				const uint32_t pitch = (uint32_t)p.dim[0].outStride * p.outElemBytes;
+				const bool split = (flags & kTmSplit) != 0u;
+				const TmSide<T> to = tm_side<T>(p.tmPost, split ? n / 2u + 1u : n, make_gbuf((char*)p.out + outB * (int64_t)p.outElemBytes), rA < rowsHere ? rA * pitch : kGbInvalid,
+				                                (rowMult == 2u && rA + 1u < rowsHere) ? (rA + 1u) * pitch : kGbInvalid);
+				auto rd = [&](uint32_t a) -> cx<T> { const cx<T> v = a == 0u ? sDc[f] : row[a]; return swO ? cswap(v) : v; };
+				if (split) tm_post_split<T, (int)n, TPF>(to, flags, tau, rd); else tm_post_rows<T, (int)n, TPF>(to, flags, tau, rd);
+			} else
 			dispatch_post_op(p.postOp, [&](auto opc) { ops_rows_out<T>(p, opc, rows, sDc, (uint32_t)SP, (uint32_t)FPW, rowsHere, outB, f0 * p.opStride0 + g1 * p.opStride1, n); });
 		} else if (denseOut) {
 			for (uint32_t e = tid; e < rowsHere * n; e += (uint32_t)NT) {

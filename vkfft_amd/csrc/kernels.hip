@@ -92,6 +92,13 @@ bool mixed_row_lookup(uint64_t n, bool dp, int* variant, int rad[5], int* fpw, i
 	}
 	return false;
 }
+// rows per workgroup of the variant's form between the maps (kernel_mixed.h mixed_ops_fpw)
+int mixed_row_ops_fpw(int variant) {
+	int cnt = 0;
+	const MixedVariant* tab = mixed_part((variant >> 16) % kMixedParts, &cnt);
+	const int idx = variant & 0xffff;
+	return (variant < 0 || idx >= cnt) ? 0 : tab[idx].fpwOps;
+}
 int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * prm.dim[1].count * prm.dim[2].count;
 	if (grid64 == 0) return 0;
@@ -235,6 +242,8 @@ static void bind(const DirectionPlan& plan, const PassPlan& pp, const LaunchBuff
 	prm.aux2 = pp.auxIsKernel ? bufs.kernel : pp.aux2Off != (size_t)-1 ? ar + pp.aux2Off : nullptr;
 	prm.aux3 = pp.aux3Off != (size_t)-1 ? ar + pp.aux3Off : nullptr;
 	prm.rader = pp.raderOff != (size_t)-1 ? ar + pp.raderOff : nullptr;
+	prm.tmPre = pp.tmPreOff != (size_t)-1 ? ar + pp.tmPreOff : nullptr;
+	prm.tmPost = pp.tmPostOff != (size_t)-1 ? ar + pp.tmPostOff : nullptr;
 }
 
 int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, const StreamSet& ss, uint32_t* sweep) {

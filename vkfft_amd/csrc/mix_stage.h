@@ -13,6 +13,10 @@ namespace vkfft_mi355x {
 // SF / SL: in() reads / out() writes the exchange buffer itself (the carrier row of the convolution lives there between the phases).
 // one transform of SCH::N points: in(t, c) delivers input t + c, out(t, c, v) receives output t + c (natural order on both sides); t is the lane's
 // butterfly index, c a compile-time multiple of the butterfly count / stride (so that c can ride in the scalar offset of a buffer access)
+// IN = McRegs: the inputs of the first stage are already in registers (x[b][i] = input tau + b * TPF + i * N / R0), loaded by the caller
+template <typename T, int R> struct McRegs { const cx<T> (*x)[R]; };
+template <typename X> struct McIsRegs { static constexpr bool value = false; };
+template <typename T, int R> struct McIsRegs<McRegs<T, R>> { static constexpr bool value = true; };
 template <typename T, typename SCH, int SI, int TPF, int LS, bool PADDED, bool SF, bool SL, typename IN, typename OUT>
 __device__ inline void mc_stage(cx<T>* ldsf, const GBuf glut, const uint32_t tau, const bool waveOnly, const IN& in, const OUT& out) {
 	constexpr int N = SCH::N, R = SCH::rad[SI], NB = N / R, P = (NB + TPF - 1) / TPF, S = SCH::S(SI);
@@ -26,7 +30,10 @@ __device__ inline void mc_stage(cx<T>* ldsf, const GBuf glut, const uint32_t tau
 		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
 #pragma unroll
 			for (int i = 0; i < R; i++) {
-				if constexpr (first) x[b][i] = in(t, (uint32_t)(i * NB));
+				if constexpr (first) {
+					if constexpr (McIsRegs<IN>::value) x[b][i] = in.x[b][i];
+					else x[b][i] = in(t, (uint32_t)(i * NB));
+				}
 				else x[b][i] = ldsf[mix_slot<PADDED ? PAD::shift(SI - 1) : 0>(t + i * NB) * LS];
 			}
 		}

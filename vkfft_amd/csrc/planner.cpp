@@ -194,6 +194,163 @@ static bool pairable_family(uint32_t pre, uint32_t post, uint64_t cplxLen, uint3
 	(void)odd4;
 	return fam(OP_R2C_FULL, OP_R2C_FULL) || fam(OP_C2R_FULL, OP_C2R_FULL) || fam(OP_DCT2_PRE, OP_DCT2_POST) || fam(OP_DCT3_PRE, OP_DCT3_POST) || odd4c;
 }
+// ---- table-driven maps of the real transforms (kernel_tmaps.h) -------------------------------------------------------------------------------------
+// One pair of tables per (family, length): what pre_gather / post_store / post_scatter of kernel_generic.h compute per element, written out per position
+// (reference: the per-family index arithmetic and twiddles of vkFFT_R2C.h:178,450 and vkFFT_R2R.h:193-336, 414-481, 784-1031, 1339-2318).
+// Families: R2C (post) / C2R (pre) in their full-length forms; DCT / DST-I, -II, -III in their full-length forms; DCT / DST-IV of odd length (same-length form)
+// and of even length (half-length complex form).  All but the last carry two rows per transform.
+constexpr uint32_t kTmNoTerm = 0x7FFFFFF8u; // = kGbInvalid (memops.h): a byte offset no buffer access reaches
+enum TmFamily { TM_NONE = 0, TM_R2C, TM_C2R, TM_R2R2, TM_R2R3, TM_DCT1, TM_DST1, TM_R2R4_ODD, TM_R2R4_EVEN };
+static TmFamily tm_family(uint32_t pre, uint32_t post, uint64_t Lc, uint32_t N) {
+	auto fam = [&](uint32_t a, uint32_t c) { return pre == a && post == c; };
+	if (N < 2) return TM_NONE;
+	if (fam(OP_R2C_FULL, OP_R2C_FULL) && Lc == N) return TM_R2C;
+	if (fam(OP_C2R_FULL, OP_C2R_FULL) && Lc == N) return TM_C2R;
+	if ((fam(OP_DCT2_PRE, OP_DCT2_POST) || fam(OP_DST2_PRE, OP_DST2_POST)) && Lc == N) return TM_R2R2;
+	if ((fam(OP_DCT3_PRE, OP_DCT3_POST) || fam(OP_DST3_PRE, OP_DST3_POST)) && Lc == N) return TM_R2R3;
+	if (fam(OP_DCT1_PRE, OP_DCT1_POST) && Lc == 2ull * N - 2) return TM_DCT1;
+	if (fam(OP_DST1_PRE, OP_DST1_POST) && Lc == 2ull * N + 2) return TM_DST1;
+	if (fam(OP_DCT4_PRE, OP_DCT4_POST) || fam(OP_DST4_PRE, OP_DST4_POST)) {
+		if (Lc == N && (N & 1u) && N >= 3) return TM_R2R4_ODD;
+		if (2 * Lc == N) return TM_R2R4_EVEN;
+	}
+	return TM_NONE;
+}
+// threads per row from which the table-driven maps replace the generic ones (measured, profiles/r05_real_rows_table_maps_ab.jsonl: from four threads per row on they
+// win — 91 reals (7 threads) 0.30 -> 0.19 ms, DCT-IV of 65 (5 threads) 0.44 -> 0.22; one thread per row, whose lanes are whole rows apart, loses: 31 reals 0.45 -> 0.77)
+static int tmaps_min_tpf() { return getenv("VKFFT_MI355X_TMAPS_MIN_TPF") ? atoi(getenv("VKFFT_MI355X_TMAPS_MIN_TPF")) : 4; }
+static bool tm_family_pairs(TmFamily f) { return f != TM_NONE && f != TM_R2R4_EVEN; }
+struct TmTable {
+	Arena& ar; size_t off; uint32_t n; bool dp;
+	TmTable(Arena& a, uint32_t entries, bool dp_) : ar(a), n(entries), dp(dp_) {
+		const size_t offsBytes = ((size_t)entries * 8 + 15) & ~(size_t)15;
+		off = ar.alloc(offsBytes + (size_t)entries * (dp ? 32 : 16));
+		for (uint32_t i = 0; i < entries; i++) set(i, kTmNoTerm, kTmNoTerm, cld(0, 0), cld(0, 0));
+	}
+	// two-term pre-map entries: c2 = +-i c1 in every family, and the kernel reads only c1: bit 0 of o2 set = the minus sign (kernel_tmaps.h tm_pre)
+	void set_pre2(uint32_t i, uint32_t o1, uint32_t o2, cld c1, bool minus) { set(i, o1, o2 | (minus ? 1u : 0u), c1, (minus ? cld(0, -1) : cld(0, 1)) * c1); }
+	void set(uint32_t i, uint32_t o1, uint32_t o2, cld c1, cld c2) {
+		uint32_t* o = (uint32_t*)(ar.b.data() + off);
+		o[2 * i] = o1; o[2 * i + 1] = o2;
+		const size_t coef = off + (((size_t)n * 8 + 15) & ~(size_t)15);
+		ar.putc(coef, 2 * (size_t)i, c1, dp); ar.putc(coef, 2 * (size_t)i + 1, c2, dp);
+	}
+};
+// preFlags / postFlags = 0: that side keeps the kernel's own form (R2C reads its reals, C2R writes its reals directly)
+// direct: the kernel moves the plain sides itself (eight or more threads per row, kernel_mixed.h DIRECT)
+static void build_tmaps(TmFamily fam, bool dst, uint64_t Lc, uint32_t N, bool dp, double scaleD, bool direct, Arena& ar, PassPlan& pp) {
+	PassParams& p = pp.prm;
+	const uint32_t L = (uint32_t)Lc, RS = dp ? 8u : 4u, H = L / 2 + 1;
+	const ld sc = (ld)scaleD;
+	const cld I(0, 1);
+	auto ro = [&](uint64_t idx) { return (uint32_t)(idx * RS); };
+	// ---- pre-map: FFT input pos
+	if (fam != TM_R2C || !direct) {
+		TmTable t(ar, L, dp);
+		bool two = false;
+		for (uint32_t pos = 0; pos < L; pos++) {
+			switch (fam) {
+			case TM_R2C: t.set(pos, ro(pos), kTmNoTerm, cld(1, 0), cld(0, 0)); break;
+			case TM_C2R: { // X[pos] for pos <= N/2, conj X[N - pos] beyond; the row = (re, im) pairs
+				const bool lo = pos <= N / 2; const uint64_t e = lo ? pos : N - pos;
+				t.set_pre2(pos, ro(2 * e), ro(2 * e + 1), cld(1, 0), !lo); two = true; break;
+			}
+			case TM_R2R2: { // Makhoul permutation (kernel_generic.h OP_DCT2_PRE / OP_DST2_PRE)
+				const uint64_t src = pos < (N + 1) / 2 ? 2ull * pos : 2ull * (N - 1 - pos) + 1;
+				t.set(pos, ro(src), kTmNoTerm, cld((dst && (src & 1)) ? -1 : 1, 0), cld(0, 0)); break;
+			}
+			case TM_R2R3: { // V_k = e^{+i pi k / 2N} (x_k - i x_{N-k}), x_N = 0; DST-III reads the reversed row
+				const cld w = std::conj(unit_root(pos, 4ull * N));
+				const uint64_t ia = dst ? N - 1 - pos : pos;
+				const uint32_t ob = pos == 0 ? kTmNoTerm : ro(dst ? pos - 1 : N - pos);
+				t.set_pre2(pos, ro(ia), ob, w, true); two = true; break;
+			}
+			case TM_DCT1: { const uint64_t M = 2ull * N - 2; t.set(pos, ro(pos < N ? pos : M - pos), kTmNoTerm, cld(1, 0), cld(0, 0)); break; }
+			case TM_DST1:
+				if (pos == 0 || pos == N + 1) break;
+				if (pos <= N) t.set(pos, ro(pos - 1), kTmNoTerm, cld(1, 0), cld(0, 0));
+				else t.set(pos, ro(2ull * N + 1 - pos), kTmNoTerm, cld(-1, 0), cld(0, 0));
+				break;
+			case TM_R2R4_ODD: { // the row sampled at r = 8 i + N (kernel_generic.h OP_DCT4_PRE, same-length form)
+				const uint64_t m = 4ull * pos + (N >> 1);
+				uint64_t src; bool neg = false;
+				if (m < N) src = m;
+				else if (m < 2ull * N) { src = 2ull * N - 1 - m; neg = true; }
+				else if (m < 3ull * N) { src = m - 2ull * N; neg = true; }
+				else if (m < 4ull * N) src = 4ull * N - 1 - m;
+				else src = m - 4ull * N;
+				t.set(pos, ro(dst ? N - 1 - src : src), kTmNoTerm, cld(neg ? -1 : 1, 0), cld(0, 0)); break;
+			}
+			case TM_R2R4_EVEN: { // z = (x[2 pos] + i x[N - 1 - 2 pos]) e^{-i pi (4 pos + 1) / 4N}
+				uint64_t i0 = 2ull * pos, i1 = N - 1 - 2ull * pos;
+				if (dst) { i0 = N - 1 - i0; i1 = N - 1 - i1; }
+				const cld w = unit_root(4ull * pos + 1, 8ull * N);
+				t.set_pre2(pos, ro(i0), ro(i1), w, false); two = true; break;
+			}
+			default: break;
+			}
+		}
+		pp.tmPreOff = t.off; p.tmPreFlags = kTmOn | (two ? kTmTwo : 0u);
+	}
+	// ---- post-map
+	if (fam == TM_C2R && direct) return; // (the real parts go out directly, scaled: kernel_mixed.h)
+	if (fam == TM_R2R3 || fam == TM_C2R) { // real results: output o of both rows from FFT output m
+		TmTable t(ar, L, dp);
+		for (uint32_t m = 0; m < L; m++) {
+			const uint64_t o = fam == TM_C2R ? m : m < (N + 1) / 2 ? 2ull * m : 2ull * (N - 1 - m) + 1;
+			const ld s = (dst && (o & 1)) ? -sc : sc;
+			t.set(m, ro(o), kTmNoTerm, cld(s, 0), cld(0, -s));
+		}
+		pp.tmPostOff = t.off; p.tmPostFlags = kTmOn | kTmRowB;
+		return;
+	}
+	if (fam == TM_R2R4_EVEN) { // FFT output m feeds outputs 2m and N - 1 - 2m
+		TmTable t(ar, L, dp);
+		for (uint32_t m = 0; m < L; m++) {
+			const cld c = unit_root(m, 2ull * N) * (2 * sc);
+			t.set(m, ro(2ull * m), ro(N - 1 - 2ull * m), c, (dst ? -I : I) * c);
+		}
+		pp.tmPostOff = t.off; p.tmPostFlags = kTmOn;
+		return;
+	}
+	// split forms: index k <= L/2 carries X[k] and (conjugated) X[L - k]; X_a, X_b arrive doubled
+	TmTable t(ar, H, dp);
+	const ld h = sc / 2;
+	for (uint32_t k = 0; k < H; k++) {
+		const uint32_t km = k ? L - k : 0; // the mirror index; outputs that belong to it are written from here unless it is k itself
+		const bool mirror = km != k;
+		switch (fam) {
+		case TM_R2C: t.set(k, ro(2ull * k), kTmNoTerm, cld(h, 0), cld(0, -h)); break; // one complex store (Re X, Im X)
+		case TM_R2R2: { // y[q] = 2 Re(e^{-i pi q / 2N} X[q]); DST-II: output N - 1 - q
+			auto outOf = [&](uint64_t q) { return ro(dst ? N - 1 - q : q); };
+			const cld c1 = unit_root(k, 4ull * N) * (2 * h);
+			if (mirror) t.set(k, outOf(k), outOf(km), c1, std::conj(unit_root(km, 4ull * N)) * (2 * h));
+			else t.set(k, outOf(k), kTmNoTerm, c1, cld(0, 0));
+			break;
+		}
+		case TM_DCT1: t.set(k, ro(k), kTmNoTerm, cld(h, 0), cld(0, 0)); break; // y[k] = Re X[k], k <= N - 1 = L/2
+		case TM_DST1: if (k >= 1 && k <= N) t.set(k, ro(k - 1), kTmNoTerm, I * h, cld(0, 0)); break; // y[k - 1] = -Im X[k]
+		case TM_R2R4_ODD: { // y[j] = 2 Re(e^{-i pi u / 4} X[u mod N]), u = 2 j + 1 (kernel_generic.h OP_DCT4_POST, same-length form)
+			auto outJ = [&](uint64_t q) { return (q & 1) ? (q - 1) >> 1 : (q + N - 1) >> 1; }; // the output whose u = q (mod N)
+			auto coefJ = [&](uint64_t j) {
+				const uint64_t r8 = (2 * j + 1) & 7u;
+				const ld c = (r8 == 1 || r8 == 7) ? 1 : -1, s2 = (r8 == 1 || r8 == 3) ? 1 : -1;
+				ld g = 1.41421356237309504880168872420969807856967L * h;
+				if (dst && (j & 1)) g = -g;
+				return cld(c * g, -s2 * g); // Re((c - i s)(x + i y)) = c x + s y
+			};
+			const uint64_t j1 = outJ(k);
+			if (mirror) { const uint64_t j2 = outJ(km); t.set(k, ro(j1), ro(j2), coefJ(j1), std::conj(coefJ(j2))); }
+			else t.set(k, ro(j1), kTmNoTerm, coefJ(j1), cld(0, 0));
+			break;
+		}
+		default: break;
+		}
+	}
+	pp.tmPostOff = t.off;
+	p.tmPostFlags = kTmOn | kTmSplit | (fam == TM_R2C ? kTmCplx : 0u);
+}
+
 static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	PassBuild b = bIn;
 	size_t mixconvTabOff = (size_t)-1;
@@ -295,6 +452,8 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 			const bool spanOK = (2 * b.L + 128 * (uint64_t)std::max<int64_t>(std::llabs(d0o.inStride), std::llabs(d0o.outStride))) * (b.dp ? 16 : 8) < 0x7FFFFF00ull;
 			if (!spanOK) { /* interpreter */ }
 			else if (mixed_row_lookup(b.L, b.dp, &variant, rad5, &fpw, &thr)) {
+				const int fo = mixed_row_ops_fpw(variant); // (the form between the maps may take fewer rows per workgroup: kernel_mixed.h mixed_ops_fpw)
+				if (fo > 0 && fo != fpw) { thr = thr / fpw * fo; fpw = fo; }
 				b.fastKernel = KERNEL_MIXED_ROW; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
 				for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
 			} else if (!b.dp && b.L >= 74 && b.L <= 4096 && !is_prime_u(b.L) && [&]() {
@@ -491,9 +650,15 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	if (opsCplxLen && b.fastKernel != KERNEL_GENERIC && !getenv("VKFFT_MI355X_NO_ROW_PAIRS")) {
 		// two real rows per complex transform (the reference's mergeSequencesR2C, vkFFT_SharedMemory.h:40): the families whose pre-map is a real sequence
 		// (post-map through the even / odd split) or whose result is real (kernel_generic.h ops_rows_in / ops_rows_out); the tile holds 2 T rows
-		if (pairable_family(b.preOp, b.postOp, opsCplxLen, b.opN)) {
+		// table-driven maps (kernel_tmaps.h): the instance transform of kernel_mixed.h; with them the families whose operation the generic maps only know at run time pair too
+		const TmFamily tmf = ((b.fastKernel == KERNEL_MIXED_ROW || (b.fastKernel == KERNEL_MIXCONV && !b.raderM)) && b.fastThreads / (int)T >= tmaps_min_tpf() && !b.padInN && !b.padOutN && !getenv("VKFFT_MI355X_NO_TMAPS")) ? tm_family(b.preOp, b.postOp, opsCplxLen, b.opN) : TM_NONE;
+		if (pairable_family(b.preOp, b.postOp, opsCplxLen, b.opN) || tm_family_pairs(tmf)) {
 			p.pairRows = 1;
 			p.tilesPerG0 = (uint32_t)((dims[0].count + 2 * (uint64_t)T - 1) / (2 * (uint64_t)T));
+		}
+		if (tmf != TM_NONE) {
+			const bool dstFam = b.preOp == OP_DST2_PRE || b.preOp == OP_DST3_PRE || b.preOp == OP_DST4_PRE || b.preOp == OP_DST1_PRE;
+			build_tmaps(tmf, dstFam, opsCplxLen, b.opN, dp, b.scale, b.fastKernel == KERNEL_MIXED_ROW && b.fastThreads / (int)T >= 8, ar, pp);
 		}
 	}
 	const bool mergeable = (b.fastKernel == KERNEL_MIXCONV && b.colIn) ||
@@ -1600,6 +1765,18 @@ static int plan_real_by_maps(const TransformDesc& d, const RealMapJob& m, Arena&
 // decomposition vkFFT_R2C_even_decomposition.h:40 for long even N, callback form vkFFT_R2C.h:27 otherwise).
 // Here: even N -> one half-length complex FFT per row with the split fused as a post/pre operation of the
 // same kernel; odd N -> full-length complex FFT of the real row.
+// Even real lengths as TWO rows per full-length complex transform instead of one row per half-length transform (the same points per row; kernel_tmaps.h): the
+// maps of the paired form are a signed gather and the even / odd split, those of the half-length forms carry a twiddle per point and go through the generic
+// maps.  Where an instance transform of the full length exists with eight or more threads per row, and (mode 1) the half-length form has no fused-map kernel.
+// VKFFT_MI355X_EVEN_FULL = 0 off, 1 (default), 2 also over a fused-map kernel.
+static bool prefer_full_length_pairs(const TransformDesc& d, uint64_t N, bool unit, uint64_t rows, uint32_t preHalf, uint32_t postHalf, uint64_t halfLen) {
+	const int mode = getenv("VKFFT_MI355X_EVEN_FULL") ? atoi(getenv("VKFFT_MI355X_EVEN_FULL")) : 1;
+	if (!mode || d.disableFastKernels || !unit || rows < 2 || getenv("VKFFT_MI355X_NO_TMAPS") || getenv("VKFFT_MI355X_NO_ROW_PAIRS") || getenv("VKFFT_MI355X_NO_MIXED_OPS")) return false;
+	int v, r5[5], f, t;
+	if (!mixed_row_lookup(N, d.dp, &v, r5, &f, &t) || t / f < 8) return false; // (eight: the plain sides of R2C / C2R then move directly, kernel_mixed.h DIRECT)
+	if (mode == 1 && opfft_lookup(halfLen, d.dp, false, false, preHalf, postHalf, &v, r5, &f, &t)) return false;
+	return true;
+}
 static int plan_r2c_axis0_fused(const TransformDesc& d, bool inverse, const std::vector<HostDim>& othersReal, const std::vector<HostDim>& othersCplx,
                                 int realRole, int cplxRole, double scale, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes, bool usePad);
 static int plan_r2c_axis0(const TransformDesc& d, bool inverse, const std::vector<HostDim>& othersReal, const std::vector<HostDim>& othersCplx,
@@ -1645,6 +1822,10 @@ static int plan_r2c_axis0_fused(const TransformDesc& d, bool inverse, const std:
 	b.dp = dp; b.maxLds = d.maxLds; b.raderDirectMax = dmax; b.allowFast = false; b.allowOp = !d.disableFastKernels;
 	b.opN = (uint32_t)N; b.scale = scale;
 	bool even = (N % 2 == 0);
+	{
+		uint64_t rows = 1; for (auto& o : othersReal) rows *= o.count;
+		if (even && N >= 4 && !padReal && prefer_full_length_pairs(d, N, true, rows, inverse ? OP_C2R_EVEN_PRE : OP_NONE, inverse ? OP_NONE : OP_R2C_EVEN_POST, N / 2)) even = false;
+	}
 	b.L = even ? N / 2 : N;
 	uint64_t blueM = 0; // padded length of the Bluestein-wrapped full-length form (kernel_blue_r2r.h), 0: not used
 	int blueVariant = 0, blueBits[4] = {0, 0, 0, 0}, blueFpw = 0, blueThr = 0;
@@ -1858,7 +2039,11 @@ static int plan_r2r_axis_fused(const TransformDesc& d, int type, bool dst, uint6
 		}
 		else { b.L = 2 * N + 2; b.preOp = OP_DST1_PRE; b.postOp = OP_DST1_POST; }
 		break;
-	case 2: case 3: if (N % 2 == 0 && N >= 4) {
+	case 2: case 3: if (N % 2 == 0 && N >= 4 && ![&]() {
+			uint64_t rows = 1; for (auto& o : others) rows *= o.count;
+			const uint32_t ph = type == 2 ? (dst ? OP_DST2H_PRE : OP_DCT2H_PRE) : (dst ? OP_DST3H_PRE : OP_DCT3H_PRE), qh = type == 2 ? (dst ? OP_DST2H_POST : OP_DCT2H_POST) : (dst ? OP_DST3H_POST : OP_DCT3H_POST);
+			return prefer_full_length_pairs(d, N, unit, rows, ph, qh, N / 2);
+		}()) {
 		// even length: one complex FFT of length N/2 (Makhoul permutation + even R2C/C2R split + quarter-wave twiddle)
 		const uint64_t H = N / 2;
 		b.L = H;
