@@ -691,3 +691,55 @@ def test_table_driven_maps_of_the_real_transforms(run, oracle, monkeypatch, N, d
         b = run.transform(x, (N,), batch, both=True, **kw)
         tol = 1e-13 if dp else 2e-6
         assert rel_l2(a[0], b[0]) < tol and rel_l2(a[1], b[1]) < tol, (kw, rel_l2(a[0], b[0]), rel_l2(a[1], b[1]))
+
+
+@pytest.mark.parametrize("N", [283, 298, 235])
+def test_two_real_rows_per_fused_bluestein_transform(run, oracle, monkeypatch, N):
+    """kernel_blue_r2r.h with PassParams::pairRows: rows whose embedding length needs Bluestein travel two per transform (real sequences through the even / odd
+    split, real results as real and imaginary part); odd row count; against the oracle and against the plans with one row per transform"""
+    batch = 5
+    parity.check_r2c(run, oracle, (N,), batch, False)
+    for type, dst in [(1, False), (2, False), (3, False), (4, False), (1, True), (2, True), (3, True), (4, True)]:
+        parity.check_r2r(run, oracle, (N,), batch, False, type, dst)
+    rng = np.random.default_rng(N)
+    x = rng.uniform(-1, 1, N * batch).astype(np.float32)
+    for kw in (dict(dct=2), dict(dct=3), dict(dct=4)):
+        monkeypatch.delenv("VKFFT_MI355X_NO_BLUE_PAIRS", raising=False)
+        a = run.transform(x, (N,), batch, both=True, **kw)
+        monkeypatch.setenv("VKFFT_MI355X_NO_BLUE_PAIRS", "1")
+        b = run.transform(x, (N,), batch, both=True, **kw)
+        assert rel_l2(a[0], b[0]) < 3e-6 and rel_l2(a[1], b[1]) < 3e-6, (kw, rel_l2(a[0], b[0]), rel_l2(a[1], b[1]))
+
+
+@pytest.mark.parametrize("N", [265, 355, 148, 316])
+def test_table_driven_maps_around_the_rader_stage_kernel(run, oracle, monkeypatch, N):
+    """kernel_mixrad.h between the table-driven maps (kernel_tmaps.h tm_rows_in / tm_rows_out): every family, against the oracle and against the generic maps"""
+    batch = 5
+    parity.check_r2c(run, oracle, (N,), batch, False)
+    for type, dst in [(2, False), (3, False), (4, False), (2, True), (3, True), (4, True)]:
+        parity.check_r2r(run, oracle, (N,), batch, False, type, dst)
+    rng = np.random.default_rng(N)
+    x = rng.uniform(-1, 1, N * batch).astype(np.float32)
+    for kw in (dict(dct=2), dict(dct=3), dict(dct=4)):
+        monkeypatch.delenv("VKFFT_MI355X_NO_MIXRAD_TMAPS", raising=False)
+        a = run.transform(x, (N,), batch, both=True, **kw)
+        monkeypatch.setenv("VKFFT_MI355X_NO_MIXRAD_TMAPS", "1")
+        b = run.transform(x, (N,), batch, both=True, **kw)
+        assert rel_l2(a[0], b[0]) < 3e-6 and rel_l2(a[1], b[1]) < 3e-6, (kw, rel_l2(a[0], b[0]), rel_l2(a[1], b[1]))
+
+
+@pytest.mark.parametrize("N,pitch", [(13, 15), (13, 40), (55, 57), (31, 33)])
+def test_staged_real_rows_leave_the_gap_between_rows_alone(run, N, pitch):
+    """kernel_mixed.h staging tile (fewer than eight threads per row): rows in a pitch longer than the row — the tile is still copied in as one run, but the results go
+    out scalar by scalar with the gaps left out (or, beyond N + 2 scalars of pitch, through the maps directly); DCT-II and its inverse, in place"""
+    import scipy.fft as sf
+    rng = np.random.default_rng(N + pitch)
+    batch = 5
+    buf = rng.uniform(-1, 1, (batch, pitch)).astype(np.float32)
+    h, ptr = run._alloc(buf.reshape(-1))
+    app = api.App([N], batch, buffer_ptr=ptr, lib=run.lib, dct=2, bufferStride=[pitch])
+    app.forward(); y = run._fetch(h, np.float32).reshape(batch, pitch)
+    app.inverse(); z = run._fetch(h, np.float32).reshape(batch, pitch); app.delete()
+    assert rel_l2(y[:, :N], sf.dct(buf[:, :N].astype(np.float64), type=2, axis=1)) < 3e-6
+    assert np.array_equal(y[:, N:], buf[:, N:]) and np.array_equal(z[:, N:], buf[:, N:])
+    assert rel_l2(z[:, :N], buf[:, :N].astype(np.float64) * 2 * N) < 5e-6

@@ -18,6 +18,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 	constexpr int LDSPF = SCH::NS > 1 ? M + (M >> LOGE) : 1;
 	constexpr bool waveOnly = TPF <= 64;
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
+	static_assert(SCH::NS > 1, "the paired form turns the spectrum through the exchange buffer");
 	__shared__ cx<T> lds[FPW * LDSPF];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t f = tid / TPF, tau = tid % TPF;
@@ -35,25 +36,37 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 		const uint32_t tile = wg % p.tilesPerG0;
 		wg /= p.tilesPerG0;
 		const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
-		const uint32_t f0 = tile * FPW, g0 = f0 + f;
-		const bool valid = g0 < p.dim[0].count;
+		// two real rows per transform (PassParams::pairRows; the reference's mergeSequencesR2C, vkFFT_SharedMemory.h:40, vkFFT_R2C.h:178,450): thread group f owns rows
+		// 2f and 2f + 1 of the tile.  Families whose pre-map is a real sequence: z = a + i b, the two spectra come back through the even / odd split, which needs
+		// Y[k] and Y[n - k] together — one more trip through the exchange buffer; families whose result is real (C2R, DCT / DST-III): real and imaginary part.
+		const bool pair = p.pairRows != 0;
+		const uint32_t mult = pair ? 2u : 1u;
+		const uint32_t f0 = tile * FPW * mult, g0 = f0 + f * mult;
+		const bool valid = g0 < p.dim[0].count, validB = pair && g0 + 1u < p.dim[0].count;
 		const int64_t inBase = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride;
 		const int64_t outBase = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride;
 		Io32<T> io;
 		io.gin = make_gbuf((const char*)p.in + inBase * (int64_t)p.inElemBytes);
 		io.gout = make_gbuf((char*)p.out + outBase * (int64_t)p.outElemBytes);
-		io.inOff = valid ? f * (uint32_t)p.dim[0].inStride * p.inElemBytes : kGbInvalid;
-		io.outOff = valid ? f * (uint32_t)p.dim[0].outStride * p.outElemBytes : kGbInvalid;
+		io.inOff = valid ? f * mult * (uint32_t)p.dim[0].inStride * p.inElemBytes : kGbInvalid;
+		io.outOff = valid ? f * mult * (uint32_t)p.dim[0].outStride * p.outElemBytes : kGbInvalid;
 		io.inSj = (uint32_t)p.inStrideJ * p.inElemBytes;
 		io.outSj = (uint32_t)p.outStrideJ * p.outElemBytes;
 		io.set_pad(p);
+		Io32<T> ioB = io;
+		ioB.inOff = validB ? (f * mult + 1u) * (uint32_t)p.dim[0].inStride * p.inElemBytes : kGbInvalid;
+		ioB.outOff = validB ? (f * mult + 1u) * (uint32_t)p.dim[0].outStride * p.outElemBytes : kGbInvalid;
 		const uint32_t nat = g0 * p.opStride0 + g1 * p.opStride1;
+		const bool realResult = op_pair_result_is_real(p.postOp);
 		cx<T> v[E];
 #pragma unroll
 		for (int m = 0; m < EH; m++) { // embedding points >= n are the zero padding (n <= M/2)
 			const uint32_t pos = tau + m * TPF;
 			cx<T> x = {(T)0, (T)0};
-			if (pos < n) x = pre_gather<T>(p, io, pos, nat, op_resolve<PRE>(p.preOp));
+			if (pos < n) {
+				x = pre_gather<T>(p, io, pos, nat, op_resolve<PRE>(p.preOp));
+				if (pair) { const cx<T> xb = pre_gather<T>(p, ioB, pos, nat, op_resolve<PRE>(p.preOp)); x = cx<T>{x.x - xb.y, x.y + xb.x}; }
+			}
 			if (p.swapIn) x = cswap(x);
 			v[m] = cmulc(x, ch[m]);
 		}
@@ -64,12 +77,31 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], bh[m]));
 		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); } // the exchange buffer is reused
 		pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
+		const bool split = pair && !realResult;
+		if (split) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); } // (the spectrum of the pair goes through the exchange buffer once more)
 #pragma unroll
 		for (int m = 0; m < EH; m++) {
 			const uint32_t pos = tau + m * TPF;
 			cx<T> y = cmulc(cswap(v[m]), ch[m]);
 			if (p.swapOut) y = cswap(y);
-			if (pos < n) post_scatter<T>(p, io, pos, y, 0, nat, op_resolve<POST>(p.postOp), p.outLen); // applies the scale
+			v[m] = y;
+			if (pos < n) {
+				if (split) lds[f * LDSPF + pos] = y;
+				else if (pair) { post_scatter<T>(p, io, pos, cx<T>{y.x, (T)0}, 0, nat, op_resolve<POST>(p.postOp), p.outLen); post_scatter<T>(p, ioB, pos, cx<T>{y.y, (T)0}, 0, nat, op_resolve<POST>(p.postOp), p.outLen); }
+				else post_scatter<T>(p, io, pos, y, 0, nat, op_resolve<POST>(p.postOp), p.outLen); // applies the scale
+			}
+		}
+		if (split) {
+			if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
+#pragma unroll
+			for (int m = 0; m < EH; m++) {
+				const uint32_t pos = tau + m * TPF;
+				if (pos < n) {
+					const cx<T> y = v[m], ym = lds[f * LDSPF + (pos ? n - pos : 0u)];
+					post_scatter<T>(p, io, pos, cx<T>{(T)0.5 * (y.x + ym.x), (T)0.5 * (y.y - ym.y)}, 0, nat, op_resolve<POST>(p.postOp), p.outLen);
+					post_scatter<T>(p, ioB, pos, cx<T>{(T)0.5 * (y.y + ym.y), (T)0.5 * (ym.x - y.x)}, 0, nat, op_resolve<POST>(p.postOp), p.outLen);
+				}
+			}
 		}
 		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); }
 	}

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 					for (int b = 0; b < PJ; b++) {
 						const uint32_t j = tau + (uint32_t)(b * TPF);
 						if ((b + 1) * TPF <= (int)n || j < n) {
-							const cx<T> v = tm_pre<T, decltype(twoTag)::value>(ts, tau, (uint32_t)(b * TPF));
+							const cx<T> v = tm_pre<T, decltype(twoTag)::value>(ts, TmGlobal<T>{ts.data}, tau, (uint32_t)(b * TPF));
 							row[j] = swI ? cswap(v) : v;
 						}
 					}
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(TPF * FPW) mixconv_kernel(const PassParams p) 
 				const TmSide<T> to = tm_side<T>(p.tmPost, split ? n / 2u + 1u : n, make_gbuf((char*)p.out + outB * (int64_t)p.outElemBytes), rA < rowsHere ? rA * pitch : kGbInvalid,
 				                                (rowMult == 2u && rA + 1u < rowsHere) ? (rA + 1u) * pitch : kGbInvalid);
 				auto rd = [&](uint32_t a) -> cx<T> { const cx<T> v = a == 0u ? sDc[f] : row[a]; return swO ? cswap(v) : v; };
-				if (split) tm_post_split<T, (int)n, TPF>(to, flags, tau, rd); else tm_post_rows<T, (int)n, TPF>(to, flags, tau, rd);
+				if (split) tm_post_split<T, (int)n, TPF>(to, TmGlobal<T>{to.data}, flags, tau, rd); else tm_post_rows<T, (int)n, TPF>(to, TmGlobal<T>{to.data}, flags, tau, rd);
 			} else
 			dispatch_post_op(p.postOp, [&](auto opc) { ops_rows_out<T>(p, opc, rows, sDc, (uint32_t)SP, (uint32_t)FPW, rowsHere, outB, f0 * p.opStride0 + g1 * p.opStride1, n); });
 		} else if (denseOut) {

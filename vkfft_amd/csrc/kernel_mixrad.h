@@ -20,6 +20,7 @@
 #include "mix_stage.h"
 #include "mixrad_plan.h"
 #include "kernel_generic.h"
+#include "kernel_tmaps.h"
 
 namespace vkfft_mi355x {
 
@@ -145,7 +146,13 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	const int64_t rowOut0 = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride;
 	const uint32_t nat0 = f0 * p.opStride0 + g1 * p.opStride1;
 	// ---- 1. rows -> LDS, sub-sequence-major
-	if (ops) {
+	if (ops && (p.tmPreFlags & kTmOn)) { // table-driven pre-map (kernel_tmaps.h)
+		const GBuf gdi = make_gbuf((const char*)p.in + rowIn0 * (int64_t)p.inElemBytes);
+		const uint32_t pitch = (uint32_t)p.dim[0].inStride * p.inElemBytes;
+		auto put = [&](uint32_t r, uint32_t pos, cx<T> z) { uint32_t a, b; divM.divmod(pos, a, b); rowbuf[r * N + b * (uint32_t)P + a] = z; };
+		if (p.tmPreFlags & kTmTwo) tm_rows_in<T, true>(p.tmPre, gdi, N, divN, rowsHere, realRowsHere, rowMult, pitch, p.swapIn != 0, tid, (uint32_t)NT, put);
+		else tm_rows_in<T, false>(p.tmPre, gdi, N, divN, rowsHere, realRowsHere, rowMult, pitch, p.swapIn != 0, tid, (uint32_t)NT, put);
+	} else if (ops) {
 		dispatch_pre_op(p.preOp, [&](auto opc) { ops_rows_in<T>(p, opc, divN, rowbuf, N, rowsHere * N, realRowsHere, rowIn0, nat0, M, (uint32_t)P); });
 	} else {
 		const uint32_t inRowBytes = (uint32_t)p.dim[0].inStride * ES;
@@ -201,6 +208,11 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 #undef VKFFT_MIXRAD_CASE
 	if (ops) {
 		VKFFT_SYNC();
+		if (p.tmPostFlags & kTmOn) {
+			const bool swOut = p.swapOut != 0;
+			tm_rows_out<T>(p.tmPost, make_gbuf((char*)p.out + rowOut0 * (int64_t)p.outElemBytes), N, rowsHere, realRowsHere, rowMult, (uint32_t)p.dim[0].outStride * p.outElemBytes, p.tmPostFlags,
+			               tid, (uint32_t)NT, [&](uint32_t r, uint32_t a) -> cx<T> { const cx<T> v = natural[r * N + a]; return swOut ? cswap(v) : v; });
+		} else
 		dispatch_post_op(p.postOp, [&](auto opc) { ops_rows_out<T>(p, opc, natural, (const cx<T>*)nullptr, N, RW, realRowsHere, rowOut0, nat0, N); });
 	}
 }

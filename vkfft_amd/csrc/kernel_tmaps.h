@@ -30,6 +30,20 @@ __device__ inline void tm_load_u2(GBuf b, uint32_t voff, uint32_t soff, uint32_t
 }
 #endif
 
+// Where the maps read the rows from / put their values: global memory (buffer accesses: an out-of-range offset reads 0 / drops the store) or a staging tile
+// in LDS that holds the tile's rows as they lie in memory (kernel_mixed.h, fewer than eight threads per row: the tile moves as one contiguous run)
+template <typename T> struct TmGlobal {
+	GBuf g;
+	__device__ inline T real(uint32_t off) const { return gb_load_real<T>(g, off, 0); }
+	__device__ inline void put(uint32_t off, T v) const { gb_store_real<T>(g, off, 0, v); }
+	__device__ inline void put2(uint32_t off, cx<T> v) const { gb_store<T>(g, off, 0, v); }
+};
+template <typename T> struct TmLds {
+	T* base;
+	__device__ inline T real(uint32_t off) const { const T v = base[(off < kGbRange ? off : 0u) / (uint32_t)sizeof(T)]; return off < kGbRange ? v : (T)0; }
+	__device__ inline void put(uint32_t off, T v) const { if (off < kGbRange) base[off / (uint32_t)sizeof(T)] = v; }
+	__device__ inline void put2(uint32_t off, cx<T> v) const { if (off < kGbRange) { base[off / (uint32_t)sizeof(T)] = v.x; base[off / (uint32_t)sizeof(T) + 1u] = v.y; } }
+};
 // the tables of one side: offs = uint32 pairs, coef = pairs of cx<T>, one entry per position; data = the tile's rows
 template <typename T> struct TmSide {
 	GBuf data, offs, coef;
@@ -49,11 +63,11 @@ template <typename T> __device__ inline void tm_entry(const TmSide<T>& s, uint32
 
 // pre-map: FFT input t + c of the transform that carries rows a and b.  One term (TWO = false): a signed gather — every family of that form has a REAL c1
 // (R2C, DCT / DST-I, -II, odd -IV), so only o1 and Re c1 are read: four registers per point in flight instead of ten
-template <typename T, bool TWO> __device__ inline cx<T> tm_pre(const TmSide<T>& s, uint32_t t, uint32_t c) {
+template <typename T, bool TWO, typename SRC> __device__ inline cx<T> tm_pre(const TmSide<T>& s, const SRC& src, uint32_t t, uint32_t c) {
 	if constexpr (!TWO) {
 		const uint32_t o1 = tm_load_u1(s.offs, t * 8u, c * 8u);
 		const T sg = gb_load_real<T>(s.coef, t * (uint32_t)(4 * sizeof(T)), c * (uint32_t)(4 * sizeof(T)));
-		const T a1 = gb_load_real<T>(s.data, s.rowA + o1, 0), b1 = gb_load_real<T>(s.data, s.rowB + o1, 0);
+		const T a1 = src.real(s.rowA + o1), b1 = src.real(s.rowB + o1);
 		return cx<T>{sg * a1, sg * b1};
 	} else {
 		// two terms: c2 = +-i c1 in every family (C2R: the imaginary part of a bin; DCT / DST-III: -i x[N - k]; even DCT / DST-IV: +i x[N - 1 - 2n]); the sign
@@ -63,8 +77,8 @@ template <typename T, bool TWO> __device__ inline cx<T> tm_pre(const TmSide<T>& 
 		const cx<T> c1 = gb_load<T>(s.coef, t * (uint32_t)(4 * sizeof(T)), c * (uint32_t)(4 * sizeof(T)));
 		const bool minus = (o2 & 1u) != 0u;
 		o2 &= ~1u;
-		const T a1 = gb_load_real<T>(s.data, s.rowA + o1, 0), b1 = gb_load_real<T>(s.data, s.rowB + o1, 0);
-		T a2 = gb_load_real<T>(s.data, s.rowA + o2, 0), b2 = gb_load_real<T>(s.data, s.rowB + o2, 0);
+		const T a1 = src.real(s.rowA + o1), b1 = src.real(s.rowB + o1);
+		T a2 = src.real(s.rowA + o2), b2 = src.real(s.rowB + o2);
 		if (minus) { a2 = -a2; b2 = -b2; }
 		const cx<T> w = {a1 - b2, a2 + b1};
 		return cx<T>{c1.x * w.x - c1.y * w.y, c1.x * w.y + c1.y * w.x};
@@ -77,7 +91,7 @@ template <typename T, bool TWO> __device__ inline cx<T> tm_pre(const TmSide<T>& 
 // point — measured on 169-point rows: 19 us per tile, every family alike.  Lanes beyond the last point read nothing and get an out-of-range store offset
 // (no branch around the loads: at a join the compiler waits for everything that is in flight).
 // split form: index k <= L/2 (kernel_tmaps.h header)
-template <typename T, int L, int TPF, typename RD> __device__ inline void tm_post_split(const TmSide<T>& s, uint32_t flags, uint32_t tau, const RD& rd) {
+template <typename T, int L, int TPF, typename RD, typename SINK> __device__ inline void tm_post_split(const TmSide<T>& s, const SINK& sink, uint32_t flags, uint32_t tau, const RD& rd) {
 	constexpr int H = L / 2 + 1, PB = (H + TPF - 1) / TPF;
 	uint32_t o1[PB], o2[PB]; T ya1[PB], ya2[PB], yb1[PB], yb2[PB];
 #pragma unroll
@@ -98,17 +112,17 @@ template <typename T, int L, int TPF, typename RD> __device__ inline void tm_pos
 	}
 	if (flags & kTmCplx) {
 #pragma unroll
-		for (int b = 0; b < PB; b++) { gb_store<T>(s.data, s.rowA + o1[b], 0, cx<T>{ya1[b], ya2[b]}); gb_store<T>(s.data, s.rowB + o1[b], 0, cx<T>{yb1[b], yb2[b]}); }
+		for (int b = 0; b < PB; b++) { sink.put2(s.rowA + o1[b], cx<T>{ya1[b], ya2[b]}); sink.put2(s.rowB + o1[b], cx<T>{yb1[b], yb2[b]}); }
 	} else {
 #pragma unroll
 		for (int b = 0; b < PB; b++) {
-			gb_store_real<T>(s.data, s.rowA + o1[b], 0, ya1[b]); gb_store_real<T>(s.data, s.rowA + o2[b], 0, ya2[b]);
-			gb_store_real<T>(s.data, s.rowB + o1[b], 0, yb1[b]); gb_store_real<T>(s.data, s.rowB + o2[b], 0, yb2[b]);
+			sink.put(s.rowA + o1[b], ya1[b]); sink.put(s.rowA + o2[b], ya2[b]);
+			sink.put(s.rowB + o1[b], yb1[b]); sink.put(s.rowB + o2[b], yb2[b]);
 		}
 	}
 }
 // direct forms: FFT output m -> y[o1] = Re(c1 Z), y[o2] = Re(c2 Z); kTmRowB: real results of a pair, y_a[o1] = s Re Z, y_b[o1] = s Im Z with s = Re c1
-template <typename T, int L, int TPF, typename RD> __device__ inline void tm_post_rows(const TmSide<T>& s, uint32_t flags, uint32_t tau, const RD& rd) {
+template <typename T, int L, int TPF, typename RD, typename SINK> __device__ inline void tm_post_rows(const TmSide<T>& s, const SINK& sink, uint32_t flags, uint32_t tau, const RD& rd) {
 	constexpr int P = (L + TPF - 1) / TPF;
 	if (flags & kTmRowB) {
 		uint32_t o1[P]; T ya[P], yb[P];
@@ -122,7 +136,7 @@ template <typename T, int L, int TPF, typename RD> __device__ inline void tm_pos
 			o1[b] = live ? a1 : kGbInvalid; ya[b] = sg * z.x; yb[b] = sg * z.y;
 		}
 #pragma unroll
-		for (int b = 0; b < P; b++) { gb_store_real<T>(s.data, s.rowA + o1[b], 0, ya[b]); gb_store_real<T>(s.data, s.rowB + o1[b], 0, yb[b]); }
+		for (int b = 0; b < P; b++) { sink.put(s.rowA + o1[b], ya[b]); sink.put(s.rowB + o1[b], yb[b]); }
 	} else {
 		constexpr int CH = 8; // (eight points per round: the entries of sixteen would not fit beside the rest)
 #pragma unroll
@@ -143,7 +157,81 @@ template <typename T, int L, int TPF, typename RD> __device__ inline void tm_pos
 				}
 			}
 #pragma unroll
-			for (int j = 0; j < CH; j++) if (b0 + j < P) { gb_store_real<T>(s.data, s.rowA + o1[j], 0, y1[j]); gb_store_real<T>(s.data, s.rowA + o2[j], 0, y2[j]); }
+			for (int j = 0; j < CH; j++) if (b0 + j < P) { sink.put(s.rowA + o1[j], y1[j]); sink.put(s.rowA + o2[j], y2[j]); }
+		}
+	}
+}
+
+// ---- the same maps over a tile of rows of RUN-TIME length held in LDS (kernel_mixrad.h: rows of M * P points, M a run-time cofactor): all NT threads of the
+// workgroup sweep the tile's points, four per trip — the four points' table entries and values are requested together, the LDS writes / the stores follow
+// (a rolled loop with one point per trip pays a memory round trip per point; and see the note on the post-maps above about loads behind stores).
+// rows: transforms in the tile; realRows: real rows in the tile (mult per transform); pitchBytes: row pitch in memory
+template <typename T, bool TWO, typename DST>
+__device__ inline void tm_rows_in(const void* table, GBuf data, uint32_t N, const FastDiv divN, uint32_t rows, uint32_t realRows, uint32_t mult, uint32_t pitchBytes, bool swI,
+                                  uint32_t tid, uint32_t NT, const DST& dst) {
+	TmSide<T> s = tm_side<T>(table, N, data, 0u, 0u);
+	const uint32_t total = rows * N;
+	constexpr int U = 4;
+	for (uint32_t e0 = tid; e0 < total; e0 += (uint32_t)U * NT) {
+		cx<T> z[U]; uint32_t rr[U], pp[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const uint32_t e = e0 + (uint32_t)u * NT;
+			const bool live = e < total;
+			divN.divmod(live ? e : 0u, rr[u], pp[u]);
+			const uint32_t rA = rr[u] * mult;
+			s.rowA = (live && rA < realRows) ? rA * pitchBytes : kGbInvalid;
+			s.rowB = (live && mult == 2u && rA + 1u < realRows) ? (rA + 1u) * pitchBytes : kGbInvalid;
+			z[u] = tm_pre<T, TWO>(s, TmGlobal<T>{data}, pp[u], 0u);
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++) if (e0 + (uint32_t)u * NT < total) dst(rr[u], pp[u], swI ? cswap(z[u]) : z[u]);
+	}
+}
+// rd(r, a) = FFT output a of transform r (un-swapped by the caller)
+template <typename T, typename RD>
+__device__ inline void tm_rows_out(const void* table, GBuf data, uint32_t L, uint32_t rows, uint32_t realRows, uint32_t mult, uint32_t pitchBytes, uint32_t flags,
+                                   uint32_t tid, uint32_t NT, const RD& rd) {
+	const bool split = (flags & kTmSplit) != 0u, cplx = (flags & kTmCplx) != 0u, rowB = (flags & kTmRowB) != 0u;
+	const uint32_t H = split ? L / 2u + 1u : L;
+	FastDiv divH; divH.d = H; divH.rcp = 1.0f / (float)H;
+	const TmSide<T> s = tm_side<T>(table, H, data, 0u, 0u);
+	const uint32_t total = rows * H;
+	constexpr int U = 4;
+	for (uint32_t e0 = tid; e0 < total; e0 += (uint32_t)U * NT) {
+		uint32_t a1[U], a2[U], b1[U], b2[U]; T ya1[U], ya2[U], yb1[U], yb2[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const uint32_t e = e0 + (uint32_t)u * NT;
+			const bool live = e < total;
+			uint32_t r, k;
+			divH.divmod(live ? e : 0u, r, k);
+			const uint32_t rA = r * mult;
+			const uint32_t offA = (live && rA < realRows) ? rA * pitchBytes : kGbInvalid, offB = (live && mult == 2u && rA + 1u < realRows) ? (rA + 1u) * pitchBytes : kGbInvalid;
+			uint32_t o1, o2; cx<T> c1, c2;
+			tm_entry<T>(s, k, 0u, o1, o2, c1, c2);
+			const cx<T> zk = rd(r, k);
+			if (split) {
+				const cx<T> zm = rd(r, k ? L - k : 0u);
+				const cx<T> xa = {zk.x + zm.x, zk.y - zm.y}, xb = {zk.y + zm.y, zm.x - zk.x};
+				ya1[u] = c1.x * xa.x - c1.y * xa.y; ya2[u] = c2.x * xa.x - c2.y * xa.y;
+				yb1[u] = c1.x * xb.x - c1.y * xb.y; yb2[u] = c2.x * xb.x - c2.y * xb.y;
+				a1[u] = offA + o1; a2[u] = offA + o2; b1[u] = offB + o1; b2[u] = offB + o2;
+			} else { // direct forms: y1 to row a at o1; y2 to row b at o1 (real results of a pair) or to row a at o2
+				ya1[u] = c1.x * zk.x - c1.y * zk.y; ya2[u] = c2.x * zk.x - c2.y * zk.y;
+				a1[u] = offA + o1; a2[u] = rowB ? offB + o1 : offA + o2;
+				yb1[u] = yb2[u] = (T)0; b1[u] = b2[u] = kGbInvalid;
+			}
+		}
+		if (cplx) {
+#pragma unroll
+			for (int u = 0; u < U; u++) { gb_store<T>(data, a1[u], 0, cx<T>{ya1[u], ya2[u]}); gb_store<T>(data, b1[u], 0, cx<T>{yb1[u], yb2[u]}); }
+		} else {
+#pragma unroll
+			for (int u = 0; u < U; u++) {
+				gb_store_real<T>(data, a1[u], 0, ya1[u]); gb_store_real<T>(data, a2[u], 0, ya2[u]);
+				if (split) { gb_store_real<T>(data, b1[u], 0, yb1[u]); gb_store_real<T>(data, b2[u], 0, yb2[u]); }
+			}
 		}
 	}
 }

@@ -218,7 +218,7 @@ static TmFamily tm_family(uint32_t pre, uint32_t post, uint64_t Lc, uint32_t N) 
 }
 // threads per row from which the table-driven maps replace the generic ones (measured, profiles/r05_real_rows_table_maps_ab.jsonl: from four threads per row on they
 // win — 91 reals (7 threads) 0.30 -> 0.19 ms, DCT-IV of 65 (5 threads) 0.44 -> 0.22; one thread per row, whose lanes are whole rows apart, loses: 31 reals 0.45 -> 0.77)
-static int tmaps_min_tpf() { return getenv("VKFFT_MI355X_TMAPS_MIN_TPF") ? atoi(getenv("VKFFT_MI355X_TMAPS_MIN_TPF")) : 4; }
+static int tmaps_min_tpf() { return getenv("VKFFT_MI355X_TMAPS_MIN_TPF") ? atoi(getenv("VKFFT_MI355X_TMAPS_MIN_TPF")) : 1; }
 static bool tm_family_pairs(TmFamily f) { return f != TM_NONE && f != TM_R2R4_EVEN; }
 struct TmTable {
 	Arena& ar; size_t off; uint32_t n; bool dp;
@@ -651,14 +651,27 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		// two real rows per complex transform (the reference's mergeSequencesR2C, vkFFT_SharedMemory.h:40): the families whose pre-map is a real sequence
 		// (post-map through the even / odd split) or whose result is real (kernel_generic.h ops_rows_in / ops_rows_out); the tile holds 2 T rows
 		// table-driven maps (kernel_tmaps.h): the instance transform of kernel_mixed.h; with them the families whose operation the generic maps only know at run time pair too
-		const TmFamily tmf = ((b.fastKernel == KERNEL_MIXED_ROW || (b.fastKernel == KERNEL_MIXCONV && !b.raderM)) && b.fastThreads / (int)T >= tmaps_min_tpf() && !b.padInN && !b.padOutN && !getenv("VKFFT_MI355X_NO_TMAPS")) ? tm_family(b.preOp, b.postOp, opsCplxLen, b.opN) : TM_NONE;
+		const TmFamily tmf = ((((b.fastKernel == KERNEL_MIXED_ROW || (b.fastKernel == KERNEL_MIXCONV && !b.raderM)) && b.fastThreads / (int)T >= tmaps_min_tpf()) || (b.fastKernel == KERNEL_MIXCONV && b.raderM && !getenv("VKFFT_MI355X_NO_MIXRAD_TMAPS"))) && !b.padInN && !b.padOutN && !getenv("VKFFT_MI355X_NO_TMAPS")) ? tm_family(b.preOp, b.postOp, opsCplxLen, b.opN) : TM_NONE;
 		if (pairable_family(b.preOp, b.postOp, opsCplxLen, b.opN) || tm_family_pairs(tmf)) {
 			p.pairRows = 1;
 			p.tilesPerG0 = (uint32_t)((dims[0].count + 2 * (uint64_t)T - 1) / (2 * (uint64_t)T));
 		}
-		if (tmf != TM_NONE) {
+		// (the one family that does not pair — even DCT / DST-IV on its half-length complex form — with fewer than four threads per row: the staged tile of ONE row per
+		// thread measured 1.8x slower than the generic loops: DCT-IV of 20 and 30 reals, profiles/r05_dct4_rows_reference_every_length_step3_*)
+		if (tmf == TM_R2R4_EVEN && b.fastThreads / (int)T < 4) { /* generic maps */ }
+		else if (tmf != TM_NONE) {
 			const bool dstFam = b.preOp == OP_DST2_PRE || b.preOp == OP_DST3_PRE || b.preOp == OP_DST4_PRE || b.preOp == OP_DST1_PRE;
 			build_tmaps(tmf, dstFam, opsCplxLen, b.opN, dp, b.scale, b.fastKernel == KERNEL_MIXED_ROW && b.fastThreads / (int)T >= 8, ar, pp);
+		}
+	}
+	if (b.fastKernel == KERNEL_POW2_BLUE_R2R && !b.padInN && !b.padOutN && !getenv("VKFFT_MI355X_NO_ROW_PAIRS") && !getenv("VKFFT_MI355X_NO_BLUE_PAIRS")) {
+		// two real rows per fused Bluestein transform (kernel_blue_r2r.h): the families whose embedding sequence is real, or whose result is
+		auto fam = [&](uint32_t a, uint32_t c) { return b.preOp == a && b.postOp == c; };
+		const bool same4 = (fam(OP_DCT4_PRE, OP_DCT4_POST) || fam(OP_DST4_PRE, OP_DST4_POST)) && b.blueN == b.opN;
+		if (fam(OP_R2C_FULL, OP_R2C_FULL) || fam(OP_C2R_FULL, OP_C2R_FULL) || fam(OP_DCT2_PRE, OP_DCT2_POST) || fam(OP_DST2_PRE, OP_DST2_POST) || fam(OP_DCT3_PRE, OP_DCT3_POST) ||
+		    fam(OP_DST3_PRE, OP_DST3_POST) || fam(OP_DCT1_PRE, OP_DCT1_POST) || fam(OP_DST1_PRE, OP_DST1_POST) || same4) {
+			p.pairRows = 1;
+			p.tilesPerG0 = (uint32_t)((dims[0].count + 2 * (uint64_t)T - 1) / (2 * (uint64_t)T));
 		}
 	}
 	const bool mergeable = (b.fastKernel == KERNEL_MIXCONV && b.colIn) ||
