@@ -52,9 +52,37 @@ Dominant kernels (rocprofv3 `--kernel-trace --stats`, `r05_bench_kernel_stats.cs
 | `r05_fused_phase_profile_packed_kernels.txt` | per-phase cycle sums per ticket of the packed fused kernels, three builds (DESIGN §4.10b: the stall at the issue of stores, the second half requested behind stores, scratch reloads, the twiddle look-ups) | `make dev; VKFFT_MI355X_LIB=… python tools/prof_fused.py <k> <k>` |
 | `r05_fused_lag_ring_pairs.jsonl`, `r05_fused_margin_chunk_queue_knobs.jsonl` | lag / ring pairs and the other planner knobs at 2^19 … 2^22 (2^22: lag 4 / ring 8 = 256 MiB 3.04 TB/s against 2.73 for lag 3 / ring 6: the ring budget of 32 MiB transforms) | `python tools/ab_r05.py lags`, `… tune` |
 | `r05_fused_stress_unbalanced_queues.jsonl` | 480 launch pairs under unbalanced queues (3, 5, 6, 7 queues, lag 1, ring 4) on the packed kernels, 2^16 … 2^22: 0 wrong | `python tools/ab_r05.py stress` |
-| `r05_real_rows_selected_baseline.jsonl` | real rows off the fused-map lists with the reference in the same process (unchanged this round: R2C 169 0.35 ×, DCT-II 169 0.24 ×, R2C 385 0.56 ×, R2C 100 0.94 ×) | `python tools/perf_real_rows.py …` |
+| `r05_real_rows_selected_baseline.jsonl` | real rows off the fused-map lists with the reference in the same process BEFORE the table-driven maps ( R2C 169 0.35 ×, DCT-II 169 0.24 ×, R2C 385 0.56 ×, R2C 100 0.94 ×) | `python tools/perf_real_rows.py …` |
 | `r05_kernel_resources.json` | registers, scratch and occupancy of every kernel instance of the final sources | `make CXXFLAGS='… -Rpass-analysis=kernel-resource-usage' 2> log; python tools/kernel_resources.py profiles/r05_kernel_resources.json log` |
 | `r05_gpu_suite.log` | `pytest -m gpu` on the device, final sources | see the file |
 '''
+# ---- real rows: the three sweeps of the final build, reference in the same process on every length
+import collections
+def geo(v): return math.exp(sum(math.log(x) for x in v) / len(v))
+rr = ""
+for fam, label, old in (("r2c", "R2C 4 … 400 (step 3)", 0.63), ("dct2", "DCT-II 4 … 400 (step 3)", 0.53), ("dct4", "DCT-IV 5 … 400 (step 5)", 0.64)):
+    fn = f"{P}/r05_{fam}_rows_reference_every_length_final.jsonl"
+    if not os.path.exists(fn): continue
+    rows_ = [json.loads(l) for l in open(fn) if l.startswith("{")]
+    rs = [(r["ref_ms"] / r["ms"], r["N"], r["kernel"]) for r in rows_ if r.get("ref_ms")]
+    by = collections.defaultdict(list)
+    for x, n, k in rs: by[k].append(x)
+    worst = min(rs)
+    rr += (f"| {label} | {len(rs)} | {old:.2f} | **{geo([x[0] for x in rs]):.2f}** | {sum(1 for x in rs if x[0] < 0.5)} | {worst[1]} ({worst[0]:.2f}) | "
+           + ", ".join(f"`{k}` {len(v)}: {geo(v):.2f}" for k, v in sorted(by.items())) + " |\n")
+if rr:
+    s += f"""
+Real rows, geometric mean of (reference pair time ÷ our pair time), the reference timed in the same process on EVERY length (`tools/perf_real_sweep_r05.py`; 2^25 reals per launch):
+
+| sweep | lengths | round 4 (r04b) | **round 5** | lengths below 0.5 × | worst length | by kernel (count: geometric mean) |
+|---|---|---|---|---|---|---|
+{rr}
+| file | what |
+|---|---|
+| `r05_{{r2c,dct2,dct4}}_rows_reference_every_length_final.jsonl` | the three sweeps on the final sources (same gpurun call as the bench line) |
+| `r05_*_rows_reference_every_length_step1…4_*.jsonl` | the same sweeps after each step of DESIGN §4.12c: tables in the instance kernels; + two rows per Bluestein transform and the Rader-stage tables; + the staging tile as static LDS (a regression: the even lengths); + as dynamic LDS |
+| `r05_real_rows_table_maps_ab.jsonl` | A/B on one box: table-driven against generic maps of the same plans, even lengths on half- against full-length forms, thresholds of threads per row |
+| `r05_real_rows_169_counters.txt` | rocprofv3 kernel trace and SQ counters of the 169-point rows: what bounds them (DESIGN §4.12c) |
+"""
 open(f"{P}/README.md", "w").write(s + "\n")
 print("profiles/README.md: round 5 section written;", f"{d['value']/1000:.2f} TFLOP/s", "ratios", [round(ps[str(k)]['alg_GBps'] / ref[k]['alg_GBps'], 2) for k in range(8, 23)])

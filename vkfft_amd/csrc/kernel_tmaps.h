@@ -46,18 +46,19 @@ template <typename T> struct TmLds {
 };
 // the tables of one side: offs = uint32 pairs, coef = pairs of cx<T>, one entry per position; data = the tile's rows
 template <typename T> struct TmSide {
-	GBuf data, offs, coef;
-	uint32_t rowA, rowB; // byte offsets of the two rows of this transform (kGbInvalid: no such row)
+	GBuf data, tab;      // the rows; the table: uint32 pairs, then (16-byte aligned) the coefficient pairs — ONE resource, the coefficients at a scalar offset (a second
+	                     // resource per side cost the small instances their last scalar registers: 27 spilled, a private segment for them)
+	uint32_t coefOff, rowA, rowB; // rowA / rowB: byte offsets of the two rows of this transform (kGbInvalid: no such row)
 };
 template <typename T> __device__ inline TmSide<T> tm_side(const void* table, uint32_t entries, GBuf data, uint32_t rowA, uint32_t rowB) {
 	TmSide<T> s;
-	s.data = data; s.offs = make_gbuf(table); s.coef = make_gbuf((const char*)table + (((size_t)entries * 8u + 15u) & ~(size_t)15u));
+	s.data = data; s.tab = make_gbuf(table); s.coefOff = (entries * 8u + 15u) & ~15u;
 	s.rowA = rowA; s.rowB = rowB;
 	return s;
 }
 template <typename T> __device__ inline void tm_entry(const TmSide<T>& s, uint32_t t, uint32_t c, uint32_t& o1, uint32_t& o2, cx<T>& c1, cx<T>& c2) {
-	tm_load_u2(s.offs, t * 8u, c * 8u, o1, o2);
-	const Real4<T> q = gb_load_real4<T>(s.coef, t * (uint32_t)(4 * sizeof(T)), c * (uint32_t)(4 * sizeof(T)));
+	tm_load_u2(s.tab, t * 8u + c * 8u, 0u, o1, o2);
+	const Real4<T> q = gb_load_real4<T>(s.tab, t * (uint32_t)(4 * sizeof(T)) + s.coefOff + c * (uint32_t)(4 * sizeof(T)), 0u);
 	c1 = cx<T>{q.x, q.y}; c2 = cx<T>{q.z, q.w};
 }
 
@@ -65,16 +66,16 @@ template <typename T> __device__ inline void tm_entry(const TmSide<T>& s, uint32
 // (R2C, DCT / DST-I, -II, odd -IV), so only o1 and Re c1 are read: four registers per point in flight instead of ten
 template <typename T, bool TWO, typename SRC> __device__ inline cx<T> tm_pre(const TmSide<T>& s, const SRC& src, uint32_t t, uint32_t c) {
 	if constexpr (!TWO) {
-		const uint32_t o1 = tm_load_u1(s.offs, t * 8u, c * 8u);
-		const T sg = gb_load_real<T>(s.coef, t * (uint32_t)(4 * sizeof(T)), c * (uint32_t)(4 * sizeof(T)));
+		const uint32_t o1 = tm_load_u1(s.tab, t * 8u + c * 8u, 0u);
+		const T sg = gb_load_real<T>(s.tab, t * (uint32_t)(4 * sizeof(T)) + s.coefOff + c * (uint32_t)(4 * sizeof(T)), 0u);
 		const T a1 = src.real(s.rowA + o1), b1 = src.real(s.rowB + o1);
 		return cx<T>{sg * a1, sg * b1};
 	} else {
 		// two terms: c2 = +-i c1 in every family (C2R: the imaginary part of a bin; DCT / DST-III: -i x[N - k]; even DCT / DST-IV: +i x[N - 1 - 2n]); the sign
 		// rides in bit 0 of o2 and only c1 is read — eight registers per point in flight instead of ten.  z = V_a + i V_b = c1 ((a1 - s b2) + i (s a2 + b1))
 		uint32_t o1, o2;
-		tm_load_u2(s.offs, t * 8u, c * 8u, o1, o2);
-		const cx<T> c1 = gb_load<T>(s.coef, t * (uint32_t)(4 * sizeof(T)), c * (uint32_t)(4 * sizeof(T)));
+		tm_load_u2(s.tab, t * 8u + c * 8u, 0u, o1, o2);
+		const cx<T> c1 = gb_load<T>(s.tab, t * (uint32_t)(4 * sizeof(T)) + s.coefOff + c * (uint32_t)(4 * sizeof(T)), 0u);
 		const bool minus = (o2 & 1u) != 0u;
 		o2 &= ~1u;
 		const T a1 = src.real(s.rowA + o1), b1 = src.real(s.rowB + o1);
@@ -102,8 +103,8 @@ template <typename T, int L, int TPF, typename RD, typename SINK> __device__ inl
 		const cx<T> zk = rd(kk), zm = rd(kk ? (uint32_t)L - kk : 0u);
 		cx<T> c1, c2;
 		uint32_t a1, a2;
-		tm_load_u2(s.offs, live ? tau * 8u : kGbInvalid, (uint32_t)(b * TPF) * 8u, a1, a2);
-		const Real4<T> q = gb_load_real4<T>(s.coef, live ? tau * (uint32_t)(4 * sizeof(T)) : kGbInvalid, (uint32_t)(b * TPF) * (uint32_t)(4 * sizeof(T)));
+		tm_load_u2(s.tab, live ? tau * 8u + (uint32_t)(b * TPF) * 8u : kGbInvalid, 0u, a1, a2);
+		const Real4<T> q = gb_load_real4<T>(s.tab, live ? tau * (uint32_t)(4 * sizeof(T)) + s.coefOff + (uint32_t)(b * TPF) * (uint32_t)(4 * sizeof(T)) : kGbInvalid, 0u);
 		c1 = cx<T>{q.x, q.y}; c2 = cx<T>{q.z, q.w};
 		o1[b] = live ? a1 : kGbInvalid; o2[b] = live ? a2 : kGbInvalid;
 		const cx<T> xa = {zk.x + zm.x, zk.y - zm.y}, xb = {zk.y + zm.y, zm.x - zk.x};
@@ -131,8 +132,8 @@ template <typename T, int L, int TPF, typename RD, typename SINK> __device__ inl
 			const uint32_t m = tau + (uint32_t)(b * TPF);
 			const bool live = (b + 1) * TPF <= L || m < (uint32_t)L;
 			const cx<T> z = rd(live ? m : 0u);
-			const uint32_t a1 = tm_load_u1(s.offs, live ? tau * 8u : kGbInvalid, (uint32_t)(b * TPF) * 8u);
-			const T sg = gb_load_real<T>(s.coef, live ? tau * (uint32_t)(4 * sizeof(T)) : kGbInvalid, (uint32_t)(b * TPF) * (uint32_t)(4 * sizeof(T)));
+			const uint32_t a1 = tm_load_u1(s.tab, live ? tau * 8u + (uint32_t)(b * TPF) * 8u : kGbInvalid, 0u);
+			const T sg = gb_load_real<T>(s.tab, live ? tau * (uint32_t)(4 * sizeof(T)) + s.coefOff + (uint32_t)(b * TPF) * (uint32_t)(4 * sizeof(T)) : kGbInvalid, 0u);
 			o1[b] = live ? a1 : kGbInvalid; ya[b] = sg * z.x; yb[b] = sg * z.y;
 		}
 #pragma unroll
@@ -150,8 +151,8 @@ template <typename T, int L, int TPF, typename RD, typename SINK> __device__ inl
 					const bool live = (b + 1) * TPF <= L || m < (uint32_t)L;
 					const cx<T> z = rd(live ? m : 0u);
 					uint32_t a1, a2;
-					tm_load_u2(s.offs, live ? tau * 8u : kGbInvalid, (uint32_t)(b * TPF) * 8u, a1, a2);
-					const Real4<T> q = gb_load_real4<T>(s.coef, live ? tau * (uint32_t)(4 * sizeof(T)) : kGbInvalid, (uint32_t)(b * TPF) * (uint32_t)(4 * sizeof(T)));
+					tm_load_u2(s.tab, live ? tau * 8u + (uint32_t)(b * TPF) * 8u : kGbInvalid, 0u, a1, a2);
+					const Real4<T> q = gb_load_real4<T>(s.tab, live ? tau * (uint32_t)(4 * sizeof(T)) + s.coefOff + (uint32_t)(b * TPF) * (uint32_t)(4 * sizeof(T)) : kGbInvalid, 0u);
 					o1[j] = live ? a1 : kGbInvalid; o2[j] = live ? a2 : kGbInvalid;
 					y1[j] = q.x * z.x - q.y * z.y; y2[j] = q.z * z.x - q.w * z.y;
 				}
