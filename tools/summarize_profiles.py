@@ -61,6 +61,7 @@ for kname, e in summ["kernels"].items():
         sch = re.findall(r"Pow2Sched<(\d+), (\d+), (\d+), (\d+)>", kname)
         if not sch or "col" in kname or "blue" in kname: continue
         k = sum(int(b) for t in sch for b in t)
+        if "pow2_row_pairs_kernel" in kname: k += 1  # (rows as pairs of samples: the schedule is the half length's)
     summ["by_log2N"][str(k)] = dict(kernel=kname, bytes_per_launch=e["bytes_per_launch"], fetch_bytes_corrected=e["fetch_bytes_corrected"], write_bytes=e["write_bytes"],
                                     algorithmic_bytes_per_transform=2.0 * (1 << 30))
 for fam in ("pow2_fused_kernel", "pow2_row_kernel", "pow2_col_kernel"):
