@@ -54,13 +54,15 @@ static const Pow2Variant kPow2Variants[] = {
 	VKFFT_P2(float, false, 4, 3, 0, 0, 16),
 	VKFFT_P2(float, false, 4, 4, 0, 0, 8),
 	// round 5: 2^9 / 2^10 on the packed (x, y) rows of kernel_pow2_pk.h, several rows per workgroup (A/B on three boxes, profiles/r05_ab_small_sizes_*: 2^9 5.72 -> 6.09 /
-	// 5.94 -> 5.98, 2^10 5.42 -> 6.07 / 5.58 -> 5.92 TB/s paired).  2^11 / 2^12 keep the round-1 kernel: their packed form (16 points per thread, 68-80 VGPRs, six to seven
-	// waves per SIMD; index 1) won on one box (5.24 -> 5.69 / 5.67) and tied or lost by 1 % on two (5.44 / 5.48 -> 5.41 / 5.43; 5.33 / 5.36 -> 5.27 / 5.31); 2^8 stays: 6.07
+	// 5.94 -> 5.98, 2^10 5.42 -> 6.07 / 5.58 -> 5.92 TB/s paired).  2^11 / 2^12: their packed form (16 points per thread, 68-80 VGPRs, six to seven
+	// waves per SIMD) won on one box (5.24 -> 5.69 / 5.67) and tied or lost by 1 % on two (5.44 / 5.48 -> 5.41 / 5.43; 5.33 / 5.36 -> 5.27 / 5.31); 2^8 stays: 6.07
 	// against 5.99.  Index 1 of 2^9 / 2^10 = the kernel that shipped before; the other shapes of rounds 1-4 that lost their comparisons are no longer instantiated
 	VKFFT_P2KF(float, false, 5, 4, 0, 0, 4, 16, 16), VKFFT_P2(float, false, 5, 4, 0, 0, 8),
 	VKFFT_P2KF(float, false, 5, 5, 0, 0, 4, 16, 8), VKFFT_P2(float, false, 5, 5, 0, 0, 8),
-	VKFFT_P2(float, false, 5, 5, 1, 0, 2), VKFFT_P2KF(float, false, 4, 4, 3, 0, 5, 16, 4),
-	VKFFT_P2(float, false, 4, 4, 4, 0, 1), VKFFT_P2KF(float, false, 4, 4, 4, 0, 5, 16, 1),
+	// (last measurement of the round, a fourth box, the reference in the same lease — profiles/r05_ab_2p11_2p12_packed_rows_fourth_box.jsonl: 2^11 5.20-5.23 -> 5.62-5.70, 2^12
+	// 5.16-5.23 -> 5.56-5.60, the reference 5.66 / 5.44: never more than 1 % behind, 8 % ahead on two boxes of four — the packed form is the default now, the round-1 kernel index 1)
+	VKFFT_P2KF(float, false, 4, 4, 3, 0, 5, 16, 4), VKFFT_P2(float, false, 5, 5, 1, 0, 2),
+	VKFFT_P2KF(float, false, 4, 4, 4, 0, 5, 16, 1), VKFFT_P2(float, false, 4, 4, 4, 0, 1),
 	// 2^13: packed register-lean rows, four 256-thread workgroups per CU; index 1 the round-1..3 kernel (two 67 KiB workgroups per CU), index 2 the round-4 lean kernel
 	VKFFT_P2K(float, false, 5, 4, 4, 0, 4, 16), VKFFT_P2(float, false, 5, 4, 4, 0, 1), VKFFT_P2L(float, false, 5, 4, 4, 0, 4, 16, 0),
 	// 2^14: two 512-thread workgroups per CU; index 1 the round-1..3 kernel (one 135 KiB workgroup per CU), index 2 the round-4 lean kernel

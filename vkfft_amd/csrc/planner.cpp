@@ -652,14 +652,16 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		// (post-map through the even / odd split) or whose result is real (kernel_generic.h ops_rows_in / ops_rows_out); the tile holds 2 T rows
 		// table-driven maps (kernel_tmaps.h): the instance transform of kernel_mixed.h; with them the families whose operation the generic maps only know at run time pair too
 		const TmFamily tmf = ((((b.fastKernel == KERNEL_MIXED_ROW || (b.fastKernel == KERNEL_MIXCONV && !b.raderM)) && b.fastThreads / (int)T >= tmaps_min_tpf()) || (b.fastKernel == KERNEL_MIXCONV && b.raderM && !getenv("VKFFT_MI355X_NO_MIXRAD_TMAPS"))) && !b.padInN && !b.padOutN && !getenv("VKFFT_MI355X_NO_TMAPS")) ? tm_family(b.preOp, b.postOp, opsCplxLen, b.opN) : TM_NONE;
-		if (pairable_family(b.preOp, b.postOp, opsCplxLen, b.opN) || tm_family_pairs(tmf)) {
+		// (the one family that does not pair — even DCT / DST-IV on its half-length complex form — with fewer than four threads per row: the staged tile of ONE row per
+		// thread measured 1.8x slower than the generic loops: DCT-IV of 20 and 30 reals, profiles/r05_dct4_rows_reference_every_length_step3_*; and the maps address
+		// the 2 T real rows of a tile with 32-bit byte offsets from the tile's base)
+		const uint64_t tmReach = (2 * (uint64_t)T + 2) * (uint64_t)std::max<int64_t>(std::llabs(dims[0].inStride), std::llabs(dims[0].outStride)) * (dp ? 16 : 8);
+		const bool tmOn = tmf != TM_NONE && !(tmf == TM_R2R4_EVEN && b.fastThreads / (int)T < 4) && tmReach < 0x7FFFFF00ull;
+		if (pairable_family(b.preOp, b.postOp, opsCplxLen, b.opN) || (tmOn && tm_family_pairs(tmf))) {
 			p.pairRows = 1;
 			p.tilesPerG0 = (uint32_t)((dims[0].count + 2 * (uint64_t)T - 1) / (2 * (uint64_t)T));
 		}
-		// (the one family that does not pair — even DCT / DST-IV on its half-length complex form — with fewer than four threads per row: the staged tile of ONE row per
-		// thread measured 1.8x slower than the generic loops: DCT-IV of 20 and 30 reals, profiles/r05_dct4_rows_reference_every_length_step3_*)
-		if (tmf == TM_R2R4_EVEN && b.fastThreads / (int)T < 4) { /* generic maps */ }
-		else if (tmf != TM_NONE) {
+		if (tmOn) {
 			const bool dstFam = b.preOp == OP_DST2_PRE || b.preOp == OP_DST3_PRE || b.preOp == OP_DST4_PRE || b.preOp == OP_DST1_PRE;
 			build_tmaps(tmf, dstFam, opsCplxLen, b.opN, dp, b.scale, b.fastKernel == KERNEL_MIXED_ROW && b.fastThreads / (int)T >= 8, ar, pp);
 		}
