@@ -54,7 +54,7 @@ Dominant kernels (rocprofv3 `--kernel-trace --stats`, `r05_bench_kernel_stats.cs
 | `r05_fused_stress_unbalanced_queues.jsonl` | 480 launch pairs under unbalanced queues (3, 5, 6, 7 queues, lag 1, ring 4) on the packed kernels, 2^16 … 2^22: 0 wrong | `python tools/ab_r05.py stress` |
 | `r05_real_rows_selected_baseline.jsonl` | real rows off the fused-map lists with the reference in the same process BEFORE the table-driven maps ( R2C 169 0.35 ×, DCT-II 169 0.24 ×, R2C 385 0.56 ×, R2C 100 0.94 ×) | `python tools/perf_real_rows.py …` |
 | `r05_kernel_resources.json` | registers, scratch and occupancy of every kernel instance of the final sources | `make CXXFLAGS='… -Rpass-analysis=kernel-resource-usage' 2> log; python tools/kernel_resources.py profiles/r05_kernel_resources.json log` |
-| `r05_gpu_suite.log` | `pytest -m gpu` on the device, final sources | see the file |
+| `r05_gpu_suite.log`, `r05_gpu_subset_after_last_change.log` | `pytest -m gpu` on the device: the whole suite on sources `88eb3dd2fd1e7cad` (648 passed, 1 skipped), and the power-of-two-row, golden and real-transform tests again after the last change (354 passed) | see the files |
 '''
 # ---- real rows: the three sweeps of the final build, reference in the same process on every length
 import collections
@@ -79,7 +79,7 @@ Real rows, geometric mean of (reference pair time ÷ our pair time), the referen
 {rr}
 | file | what |
 |---|---|
-| `r05_{{r2c,dct2,dct4}}_rows_reference_every_length_final.jsonl` | the three sweeps on the final sources (same gpurun call as the bench line) |
+| `r05_{{r2c,dct2,dct4}}_rows_reference_every_length_final.jsonl` | the three sweeps, sources `88eb3dd2fd1e7cad` — one commit before the bench line's: the same kernels; after it only the registry order of 2^11 / 2^12 and a planner guard changed |
 | `r05_*_rows_reference_every_length_step1…4_*.jsonl` | the same sweeps after each step of DESIGN §4.12c: tables in the instance kernels; + two rows per Bluestein transform and the Rader-stage tables; + the staging tile as static LDS (a regression: the even lengths); + as dynamic LDS |
 | `r05_real_rows_table_maps_ab.jsonl` | A/B on one box: table-driven against generic maps of the same plans, even lengths on half- against full-length forms, thresholds of threads per row |
 | `r05_real_rows_169_counters.txt` | rocprofv3 kernel trace and SQ counters of the 169-point rows: what bounds them (DESIGN §4.12c) |
