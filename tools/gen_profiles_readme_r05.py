@@ -54,7 +54,7 @@ Dominant kernels (rocprofv3 `--kernel-trace --stats`, `r05_bench_kernel_stats.cs
 | `r05_fused_stress_unbalanced_queues.jsonl` | 480 launch pairs under unbalanced queues (3, 5, 6, 7 queues, lag 1, ring 4) on the packed kernels, 2^16 … 2^22: 0 wrong | `python tools/ab_r05.py stress` |
 | `r05_real_rows_selected_baseline.jsonl` | real rows off the fused-map lists with the reference in the same process BEFORE the table-driven maps ( R2C 169 0.35 ×, DCT-II 169 0.24 ×, R2C 385 0.56 ×, R2C 100 0.94 ×) | `python tools/perf_real_rows.py …` |
 | `r05_kernel_resources.json` | registers, scratch and occupancy of every kernel instance of the final sources | `make CXXFLAGS='… -Rpass-analysis=kernel-resource-usage' 2> log; python tools/kernel_resources.py profiles/r05_kernel_resources.json log` |
-| `r05_gpu_suite.log`, `r05_gpu_subset_after_last_change.log` | `pytest -m gpu` on the device: the whole suite on sources `88eb3dd2fd1e7cad` (648 passed, 1 skipped), and the power-of-two-row, golden and real-transform tests again after the last change (354 passed) | see the files |
+| `r05_gpu_suite.log` | `pytest -m gpu` on the device, final sources (the hash is the first line of the file): 648 passed, 1 skipped | see the file |
 '''
 # ---- real rows: the three sweeps of the final build, reference in the same process on every length
 import collections
