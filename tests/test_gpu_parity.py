@@ -1183,3 +1183,24 @@ def test_paired_rows_and_odd_dct4_against_the_reference_live(run, kind, N, B):
     kw = dict(r2c=True) if kind == 1 else dict(dct=kind - 10)
     y, _ = run.transform(x, (N,), B, **kw)
     assert rel_l2(y.astype(np.float64), r.astype(np.float64)) < 3e-6, (kind, N)
+
+
+@pytest.mark.parametrize("N", [28, 130, 364, 283, 298, 265, 55, 169])
+def test_table_driven_maps_on_the_device(run, oracle, monkeypatch, N):
+    """kernel_tmaps.h on the device: even lengths as two rows per full-length transform (130, 364), rows through the staging tile (28: half-length forms beside it; 55),
+    two rows per fused Bluestein transform (283, 298), the Rader-stage kernel between the tables (265), the instance transform with eight or more threads per row (169);
+    every family, an odd row count, against the oracle and against the generic maps / one row per transform of the same plans"""
+    batch = 5
+    parity.check_r2c(run, oracle, (N,), batch, False)
+    for type, dst in [(1, False), (2, False), (3, False), (4, False), (1, True), (2, True), (3, True), (4, True)]:
+        parity.check_r2r(run, oracle, (N,), batch, False, type, dst)
+    rng = np.random.default_rng(N)
+    x = rng.uniform(-1, 1, N * 4099).astype(np.float32)  # (enough rows for every CU, an odd count)
+    for kw in (dict(dct=2), dict(dct=3), dict(dct=4)):
+        for k in ("VKFFT_MI355X_NO_TMAPS", "VKFFT_MI355X_NO_BLUE_PAIRS", "VKFFT_MI355X_NO_MIXRAD_TMAPS", "VKFFT_MI355X_EVEN_FULL"):
+            monkeypatch.delenv(k, raising=False)
+        a = run.transform(x, (N,), 4099, both=True, **kw)
+        monkeypatch.setenv("VKFFT_MI355X_NO_TMAPS", "1"); monkeypatch.setenv("VKFFT_MI355X_NO_BLUE_PAIRS", "1")
+        monkeypatch.setenv("VKFFT_MI355X_NO_MIXRAD_TMAPS", "1"); monkeypatch.setenv("VKFFT_MI355X_EVEN_FULL", "0")
+        b = run.transform(x, (N,), 4099, both=True, **kw)
+        assert rel_l2(a[0], b[0]) < 3e-6 and rel_l2(a[1], b[1]) < 3e-6, (N, kw, rel_l2(a[0], b[0]), rel_l2(a[1], b[1]))
