@@ -407,11 +407,13 @@ def test_fused_fourstep_every_registered_shape(run, oracle, monkeypatch, k, vari
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
 
 
-@pytest.mark.parametrize("N", [2 * 37, 3 * 41, 8 * 37, 7 * 127, 30 * 89, 32 * 101, 5 * 53, 4 * 61, 16 * 257, 9 * 113, 25 * 73, 21 * 43, 2 * 1297, 12 * 337, 64 * 37, 6 * 521])
+@pytest.mark.parametrize("N", [2 * 37, 3 * 41, 8 * 37, 7 * 127, 30 * 89, 32 * 101, 5 * 53, 4 * 61, 16 * 257, 9 * 113, 25 * 73, 21 * 43, 2 * 1297, 12 * 337, 64 * 37, 6 * 521,
+                               29 * 97, 44 * 71, 104 * 37, 23 * 151, 19 * 97, 34 * 37, 62 * 61, 87 * 37, 110 * 37, 75 * 41, 98 * 37, 105 * 37, 37 * 37, 61 * 61, 53 * 53, 96 * 41, 94 * 37, 59 * 61])
 def test_rader_stage_of_a_composite_length(run, oracle, monkeypatch, N):
     """kernel_mixrad.h: rows of M * P points, the Rader convolution of the prime P as a stage (cofactors below, equal to and above the thread groups of
-    the prime's instance; 64 * 37 has no such plan — cofactor above 32 — and must still be right through Bluestein); against the truth, against the
-    Bluestein plan of the same length, a batch that leaves the last workgroup partly filled, and the inverse"""
+    the prime's instance; one and two column steps in registers; odd radices as direct sums — 11, 13, the primes 17 ... 31, 15, 25, 49; P * P through the prime's
+    convolution along the columns; 59 * 61 has no such plan — the cofactor is a prime above 55 — and must still be right through Bluestein); against the truth,
+    against the Bluestein plan of the same length, a batch that leaves the last workgroup partly filled, and the inverse"""
     monkeypatch.setenv("VKFFT_MI355X_MIXRAD", "2")  # (every served length, also where the cost model prefers Bluestein)
     batch = 7
     x = parity.seeded_complex(N * batch, False, N)

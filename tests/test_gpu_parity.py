@@ -41,9 +41,11 @@ def test_pow2_multi_pass(run, oracle, k, passes):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("N", [2 * 37, 3 * 41, 8 * 37, 7 * 127, 30 * 89, 32 * 101, 5 * 53, 4 * 61, 16 * 257, 9 * 113, 25 * 73, 21 * 43, 2 * 1297, 12 * 337, 6 * 521, 10 * 401, 28 * 97, 18 * 181])
+@pytest.mark.parametrize("N", [2 * 37, 3 * 41, 8 * 37, 7 * 127, 30 * 89, 32 * 101, 5 * 53, 4 * 61, 16 * 257, 9 * 113, 25 * 73, 21 * 43, 2 * 1297, 12 * 337, 6 * 521, 10 * 401, 28 * 97, 18 * 181,
+                               29 * 97, 44 * 71, 104 * 37, 23 * 151, 19 * 97, 64 * 37, 62 * 61, 110 * 37, 75 * 41, 98 * 37, 37 * 37, 61 * 61, 43 * 43, 94 * 37])
 def test_rader_stage_of_a_composite_length_on_device(run, oracle, monkeypatch, N):
-    """kernel_mixrad.h on the device: rows of M * P points with the prime's Rader convolution as a stage — the truth, the Bluestein plan of the same
+    """kernel_mixrad.h on the device: rows of M * P points with the prime's Rader convolution as a stage (round 6: any cofactor with prime factors up to 31 as one or two
+    column steps, odd radices as direct sums, P * P through the prime's convolution along the columns) — the truth, the Bluestein plan of the same
     length, a chip-filling batch against the small one bit for bit"""
     monkeypatch.setenv("VKFFT_MI355X_MIXRAD", "2")  # (every served length, also where the cost model prefers Bluestein)
     batch = 7
@@ -1158,12 +1160,12 @@ def test_two_real_rows_per_transform_preferred_over_a_fused_map_instance(run, or
         parity.check_r2r(run, oracle, (N,), 7, False, type, dst)
 
 
-@pytest.mark.parametrize("kind,N,B", [(14, 45, 6), (14, 1125, 3), (14, 239, 5), (14, 37, 9), (1, 169, 7), (1, 385, 5), (1, 37, 9), (1, 265, 3), (12, 169, 7), (12, 111, 5), (13, 169, 7), (13, 61, 5)])
+@pytest.mark.parametrize("kind,N,B", [(14, 1451, 2), (14, 45, 6), (14, 1125, 3), (14, 239, 5), (14, 37, 9), (1, 169, 7), (1, 385, 5), (1, 37, 9), (1, 265, 3), (12, 169, 7), (12, 111, 5), (13, 169, 7), (13, 61, 5)])
 def test_paired_rows_and_odd_dct4_against_the_reference_live(run, kind, N, B):
     """round 4: DCT-IV of odd length in the same-length form and the real rows that travel two per transform, against the reference's own HIP backend on fresh
-    random data (oracle/_ref travelled with the snapshot; skipped where it did not).  (DCT-IV of 1451 reals x 2 is left out: a pytest worker died in that case on
-    the device once; each library alone runs it — ours to 1.9e-7 of the double truth, the reference with rc 0 — and so does tools/perf_real_rows.py 14:1451 with both in one
-    process; a crash would take the whole suite down.)"""
+    random data (oracle/_ref travelled with the snapshot; skipped where it did not).  DCT-IV of 1451 reals x 2 is back (round 6): the worker death once seen in this case
+    did not reproduce in 500 fresh plans with both libraries in one process, 300 with this library alone and 100 chip-filling batches
+    (tools/repro_dct4_1451.py, profiles/r06_dct4_1451_reproduction_*.jsonl)"""
     import os
     sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     import sys

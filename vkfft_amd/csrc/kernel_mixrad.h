@@ -1,17 +1,22 @@
-// Rader as a stage of a composite length, in ONE kernel: unit-stride rows of N = M * P points, P a prime with 13-smooth P - 1, M a small cofactor.
+// Rader as a stage of a composite length, in ONE kernel: unit-stride rows of N = M * P points, P a prime with a smooth P - 1, M = A * B any cofactor whose prime
+// factors are at most 31 (complex rows, and the real transforms whose complex length is such a composite between the table-driven maps of kernel_tmaps.h).
 //
 // The reference builds a Rader tree per prime factor and runs it as one stage among the radix stages of its generated kernel
-// (vkFFT_Scheduler.h:1733-1873, 2304-2404; vkFFT_RaderKernels.h:30, 1278).  Until round 4 this library had Rader for PRIME lengths only
-// (kernel_mixconv.h) and sent 2670 = 30 * 89, 3232 = 32 * 101, 889 = 7 * 127 ... whole through Bluestein on two to four times the points (0.4-0.6x the
-// reference).  Here, Cooley-Tukey with n = M a + b, k = k2 + P k1:
+// (vkFFT_Scheduler.h:1733-1873, 2304-2404; vkFFT_RaderKernels.h:30, 1278).  Here, Cooley-Tukey with n = M a + b, k = k2 + P k1:
 //     X[k2 + P k1] = sum_b  W_M^(b k1) * W_N^(b k2) * Y_b[k2],     Y_b[k2] = sum_a x[M a + b] W_P^(a k2)
-//   1. the row arrives in LDS sub-sequence-major (x[M a + b] at b*P + a): the M sub-sequences are contiguous runs of P points;
-//   2. every sub-sequence is transformed IN PLACE by the Rader convolution of kernel_mixconv.h (gather through g^a, FFT of P - 1 points, times the kernel
-//      spectrum, inverse FFT, scatter through g^-q) — the FPW thread groups of the workgroup each take one sub-sequence (of one of FPW / M rows when M is
-//      small, in rounds when M exceeds FPW); the compile-time radix schedule and the padded exchange buffer are those of the prime's own instance;
-//   3. a thread takes output column k2: M values (consecutive lanes read consecutive addresses), the twiddles W_N^(b k2) from a table, one M-point
-//      butterfly in registers, M stores that are each coalesced along k2.
-// One instance per prime (the Rader row instances of the mixconv tables), the cofactor is a run-time parameter: no instance per (M, P) pair.
+//   1. the rows of a tile arrive in LDS sub-sequence-major: sub-sequence b of row r is buffer r * M + b (pitch SP: the padded exchange buffer of the prime's
+//      convolution, exactly a row of the prime's own Rader kernel, kernel_mixconv.h); with them arrive the TABLES of the convolution — stage twiddles, kernel
+//      spectrum, the two generator permutations — and of the column steps, so that between the load of the rows and the store of the results no phase waits for
+//      memory (round 5 kept them in global memory: five or six dependent trips to L2 per tile on one or two workgroups per CU were the whole run time);
+//   2. every buffer is transformed IN PLACE by the Rader convolution (gather through g^a, FFT of P - 1 points, times the kernel spectrum, inverse FFT, scatter
+//      through g^-q): the FPW thread groups of the prime's instance take the R * M buffers in rounds;
+//   3. the M-point transforms along b, P of them per row, in place as one or two column steps M = A * B (decimation in frequency: b = a' B + b',
+//      k1 = k1a + A k1b): step one — radix A over a', times W_M^(b' k1a) — and step two — radix B over b' — each one butterfly per thread in registers with the
+//      lanes along k2 (consecutive LDS addresses).  The twiddle W_N^(b k2) rides on the first step's loads as a product of two table entries (b k2 < N:
+//      high and low six bits).  Step two stores to memory (B runs of P points per butterfly) or, for the real transforms, back in place, from where the
+//      table-driven post-map takes natural index n at buffer (k1 mod A) * B + k1 / A, offset k2.
+// One instance per prime (the Rader row instances of the mixconv tables): the cofactor and its split are run-time parameters.
+// P * P (1369 = 37 * 37, 3721 = 61 * 61): the column transform is the same prime — the same convolution, its thread groups along the columns (element pitch SP).
 #pragma once
 #include "engine.h"
 #include "butterflies.h"
@@ -19,287 +24,349 @@
 #include "mix_sched.h"
 #include "mix_stage.h"
 #include "mixrad_plan.h"
-#include "kernel_generic.h"
 #include "kernel_tmaps.h"
 
 namespace vkfft_mi355x {
 
-// M-point butterfly for the cofactors that have no dft<M> of their own: one Cooley-Tukey step A x B in registers, roots folded at compile time
-template <int A, int B, typename T> __host__ __device__ inline void mixrad_dft_ab(cx<T>* v) {
-	constexpr int R = A * B;
-	cx<T> y[R];
+template <typename SCH> __host__ __device__ constexpr int mixrad_lut_elems() { // entries of the prime's stage-twiddle table (planner.cpp finish_pass: stages 1 ... NS - 1)
+	int n = 0;
+	for (int j = 1; j < SCH::NS; j++) n += (SCH::rad[j] - 1) * SCH::S(j);
+	return n;
+}
+template <typename T, typename SCH, int TPF> struct MixradGeom {
+	static constexpr int L = SCH::N, P = L + 1;
+	static constexpr int EXPF = SCH::NS > 1 ? MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems() : 1;
+	static constexpr int SP = (EXPF > P ? EXPF : P) | 1; // buffer pitch: odd (consecutive buffers start on different banks)
+	static constexpr int LUTN = mixrad_lut_elems<SCH>();
+};
+
+// one transform of the prime's convolution: mc_stage (mix_stage.h) with the stage twiddles in LDS
+// LS / PADDED: a row buffer is dense with the per-exchange padding of MixPad; a column of the tile (P * P rows) has element pitch LS = SP and no padding.
+// live = false: a thread group without a job in this round — it runs along (the barriers are the workgroup's) and writes nothing
+template <typename T, typename SCH, int SI, int TPF, int LS, bool PADDED, typename IN, typename OUT>
+__device__ inline void mixrad_stage(cx<T>* ldsf, const cx<T>* lut, const uint32_t tau, const bool waveOnly, const bool live, const IN& in, const OUT& out) {
+	constexpr int N = SCH::N, R = SCH::rad[SI], NB = N / R, PB = (NB + TPF - 1) / TPF, S = SCH::S(SI);
+	constexpr bool first = SI == 0, last = SI == SCH::NS - 1;
+	using PAD = MixPad<SCH, TPF, (int)sizeof(cx<T>)>;
+	cx<T> x[PB][R];
 #pragma unroll
-	for (int n2 = 0; n2 < B; n2++) {
-		cx<T> tmp[A];
+	for (int b = 0; b < PB; b++) {
+		const uint32_t t = tau + b * TPF;
+		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
 #pragma unroll
-		for (int n1 = 0; n1 < A; n1++) tmp[n1] = v[B * n1 + n2];
-		dft<A, T>(tmp);
-#pragma unroll
-		for (int k1 = 0; k1 < A; k1++) {
-			const int m = (n2 * k1) % R;
-			if (m == 0) y[n2 * A + k1] = tmp[k1];
-			else y[n2 * A + k1] = cmul(tmp[k1], cx<T>{(T)__builtin_cos(6.283185307179586476925286766559 * m / R), (T)(-__builtin_sin(6.283185307179586476925286766559 * m / R))});
+			for (int i = 0; i < R; i++) {
+				if constexpr (first) x[b][i] = in(t, (uint32_t)(i * NB));
+				else x[b][i] = ldsf[mix_slot<PADDED ? PAD::shift(SI - 1) : 0>(t + i * NB) * LS];
+			}
 		}
 	}
+	// every input is in registers before the buffer is overwritten (in() reads the buffer, out() writes it)
+	if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
 #pragma unroll
-	for (int k1 = 0; k1 < A; k1++) {
-		cx<T> tmp[B];
+	for (int b = 0; b < PB; b++) {
+		const uint32_t t = tau + b * TPF;
+		if ((b + 1) * TPF <= NB || t < (uint32_t)NB) {
+			const uint32_t s = t % (uint32_t)S;
+			if constexpr (!first) {
+				constexpr int LO = SCH::lutOff(SI);
 #pragma unroll
-		for (int n2 = 0; n2 < B; n2++) tmp[n2] = y[n2 * A + k1];
-		dft<B, T>(tmp);
+				for (int i = 1; i < R; i++) x[b][i] = cmul(x[b][i], lut[s + (uint32_t)(LO + (i - 1) * S)]);
+			}
+			dft<R, T>(x[b]);
+			if constexpr (last) {
 #pragma unroll
-		for (int k2 = 0; k2 < B; k2++) v[k1 + A * k2] = tmp[k2];
+				for (int k = 0; k < R; k++) out(t, (uint32_t)(k * S), x[b][k]); // last stage: s = t
+			} else {
+				const uint32_t ob = (t - s) * (uint32_t)R + s;
+#pragma unroll
+				for (int k = 0; k < R; k++) if (live) ldsf[mix_slot<PADDED ? PAD::shift(SI) : 0>(ob + k * S) * LS] = x[b][k];
+			}
+		}
 	}
-}
-template <int M, typename T> __host__ __device__ inline void mixrad_dft(cx<T>* v) {
-	if constexpr (M == 18) mixrad_dft_ab<2, 9, T>(v);
-	else if constexpr (M == 20) mixrad_dft_ab<4, 5, T>(v);
-	else if constexpr (M == 21) mixrad_dft_ab<3, 7, T>(v);
-	else if constexpr (M == 24) mixrad_dft_ab<8, 3, T>(v);
-	else if constexpr (M == 27) mixrad_dft_ab<3, 9, T>(v);
-	else if constexpr (M == 28) mixrad_dft_ab<4, 7, T>(v);
-	else if constexpr (M == 30) mixrad_dft_ab<2, 15, T>(v);
-	else dft<M, T>(v); // 2 ... 10, 12, 14, 15, 16, 25, 32
-}
-// step 3 for a compile-time cofactor
-// Source: sub-sequence b of row r at rowbuf + r * rowPitch + b * SUBS (SUBS = P: the tile of whole rows; SUBS = the buffer pitch of a thread group: every group
-// holds one sub-sequence, whose bin 0 lives in dc[r * M + b] as in the prime's own Rader kernel).
-// toLds != nullptr (real transforms between the generic maps): the columns go to a second row region in natural order instead of global memory
-template <typename T, int M, int P, int NT, int SUBS>
-__device__ inline void mixrad_columns(const cx<T>* rowbuf, const uint32_t rowPitch, const cx<T>* dc, const uint32_t N, const uint32_t rowsHere, const GBuf gout, const GBuf gtw,
-                                      const uint32_t outRowBytes, const bool swO, const T sc, const uint32_t tid, cx<T>* toLds) {
-	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
-	const uint32_t total = rowsHere * (uint32_t)P;
-	for (uint32_t j = tid; j < total; j += (uint32_t)NT) {
-		const uint32_t r = j / (uint32_t)P, k2 = j % (uint32_t)P;
-		const cx<T>* const src = rowbuf + r * rowPitch + k2;
-		cx<T> y[M];
-#pragma unroll
-		for (int b = 0; b < M; b++) y[b] = src[b * SUBS];
-		if (dc && k2 == 0u) {
-#pragma unroll
-			for (int b = 0; b < M; b++) y[b] = dc[r * (uint32_t)M + b];
-		}
-		constexpr int TWG = 8; // twiddles in flight at a time (the butterfly of a large cofactor needs the registers)
-#pragma unroll
-		for (int b0 = 1; b0 < M; b0 += TWG) {
-			cx<T> w[TWG];
-#pragma unroll
-			for (int b = b0; b < b0 + TWG && b < M; b++) w[b - b0] = gb_load<T>(gtw, k2 * ES, (uint32_t)((b - 1) * P) * ES);
-			if constexpr (M > 10) VKFFT_SCHED_FENCE();
-#pragma unroll
-			for (int b = b0; b < b0 + TWG && b < M; b++) { y[b] = cmul(y[b], w[b - b0]); if constexpr (M > 10) { VKFFT_PIN(y[b].x); VKFFT_PIN(y[b].y); } }
-			if constexpr (M > 10) VKFFT_SCHED_FENCE();
-		}
-		mixrad_dft<M, T>(y);
-		if (toLds) {
-#pragma unroll
-			for (int k1 = 0; k1 < M; k1++) toLds[r * N + k2 + (uint32_t)(k1 * P)] = y[k1];
-			continue;
-		}
-		const uint32_t o = r * outRowBytes + k2 * ES;
-#pragma unroll
-		for (int k1 = 0; k1 < M; k1++) {
-			cx<T> v = swO ? cswap(y[k1]) : y[k1];
-			if (sc != (T)1) v = cscale(v, sc);
-			gb_store<T>(gout, o, (uint32_t)(k1 * P) * ES, v);
-		}
+	if constexpr (!last) {
+		if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC();
+		mixrad_stage<T, SCH, SI + 1 < SCH::NS ? SI + 1 : SI, TPF, LS, PADDED>(ldsf, lut, tau, waveOnly, live, in, out);
 	}
 }
 
-// lut = stage twiddles of SCH (length P - 1); rader = uint32 g^a mod P (a < L) followed by g^-k mod P; aux2 = FFT of the Rader kernel / L (L entries)
-// followed by the column twiddles W_N^(b k2), (b - 1) * P + k2, b = 1 ... M - 1; raderM = M.
-// Tiles: forceT = rows per workgroup = mixrad_rows(2, ...): as many rows as the tile's LDS holds (the thread groups take their sub-sequences in rounds).
-template <typename T, typename SCH, int TPF, int FPW>
-__global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
-	constexpr int L = SCH::N, P = L + 1, NT = TPF * FPW;
-	constexpr int EXPF = SCH::NS > 1 ? MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems() : 1;
-	constexpr int EX = (EXPF > L ? EXPF : L) | 1;                     // per thread group: exchange buffer of the stages = carrier of the spectrum between the two transforms
-	constexpr int ROWN = (int)mixrad_row_elems(P, FPW); // rows of the tile, sub-sequence-major
-	constexpr bool waveOnly = (TPF <= 64) && (64 % TPF == 0);
-	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
-	static_assert((size_t)(FPW * EX + ROWN) * sizeof(cx<T>) <= 160 * 1024, "LDS");
-	__shared__ cx<T> exb[FPW * EX];
-	__shared__ cx<T> rowbuf[ROWN];
-	const uint32_t tid = threadIdx.x;
-	const uint32_t f = tid / TPF, tau = tid % TPF;
-	const uint32_t M = p.raderM, N = M * (uint32_t)P;
-	// real transforms (R2C / C2R / DCT / DST whose complex length is M * P): the row enters through the generic pre-map and leaves through the generic
-	// post-map (kernel_generic.h: ops_rows_in / ops_rows_out, the operation hoisted out of their loops); the kernel spectrum then comes from aux3
-	FastDiv divN, divM; // (by the row length and by the cofactor: run-time values of this kernel, not the pass's own dividers, which the generic maps use)
-	divN.d = N; divN.rcp = 1.0f / (float)N; divM.d = M; divM.rcp = 1.0f / (float)M;
-	const bool ops = p.preOp != OP_NONE || p.postOp != OP_NONE;
-	const uint32_t RW = mixrad_rows(2, P, FPW, M, ops);
-	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
-	const uint32_t tile = wg % p.tilesPerG0;
-	wg /= p.tilesPerG0;
-	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
-	const uint32_t rowMult = (ops && p.pairRows) ? 2u : 1u; // two real rows per complex row of the tile (kernel_generic.h)
-	const uint32_t f0 = tile * RW * rowMult;
-	const uint32_t realRowsHere = p.dim[0].count - f0 < RW * rowMult ? p.dim[0].count - f0 : RW * rowMult;
-	const uint32_t rowsHere = (realRowsHere + rowMult - 1u) / rowMult; // complex rows of the tile
-	const GBuf gin = make_gbuf((const cx<T>*)p.in + ((int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride));
-	const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride));
-	const GBuf glut = make_gbuf(p.lut), gbh = make_gbuf(ops ? p.aux3 : p.aux2), gtw = make_gbuf((const cx<T>*)(ops ? p.aux3 : p.aux2) + L);
-	const bool swI = p.bluesteinSwapIn != 0, swO = p.bluesteinSwapOut != 0;
-	const int64_t rowIn0 = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride;
-	const int64_t rowOut0 = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride;
-	const uint32_t nat0 = f0 * p.opStride0 + g1 * p.opStride1;
-	// ---- 1. rows -> LDS, sub-sequence-major
-	if (ops && (p.tmPreFlags & kTmOn)) { // table-driven pre-map (kernel_tmaps.h)
-		const GBuf gdi = make_gbuf((const char*)p.in + rowIn0 * (int64_t)p.inElemBytes);
-		const uint32_t pitch = (uint32_t)p.dim[0].inStride * p.inElemBytes;
-		auto put = [&](uint32_t r, uint32_t pos, cx<T> z) { uint32_t a, b; divM.divmod(pos, a, b); rowbuf[r * N + b * (uint32_t)P + a] = z; };
-		if (p.tmPreFlags & kTmTwo) tm_rows_in<T, true>(p.tmPre, gdi, N, divN, rowsHere, realRowsHere, rowMult, pitch, p.swapIn != 0, tid, (uint32_t)NT, put);
-		else tm_rows_in<T, false>(p.tmPre, gdi, N, divN, rowsHere, realRowsHere, rowMult, pitch, p.swapIn != 0, tid, (uint32_t)NT, put);
-	} else if (ops) {
-		dispatch_pre_op(p.preOp, [&](auto opc) { ops_rows_in<T>(p, opc, divN, rowbuf, N, rowsHere * N, realRowsHere, rowIn0, nat0, M, (uint32_t)P); });
-	} else {
-		const uint32_t inRowBytes = (uint32_t)p.dim[0].inStride * ES;
-		for (uint32_t e = tid; e < rowsHere * N; e += (uint32_t)NT) {
-			uint32_t r, n, a, b;
-			divN.divmod(e, r, n);
-			divM.divmod(n, a, b);
-			const cx<T> v = gb_load<T>(gin, r * inRowBytes + n * ES, 0);
-			rowbuf[r * N + b * (uint32_t)P + a] = swI ? cswap(v) : v;
+// W_N^e as the product of two table entries (e = 64 hi + lo)
+template <typename T> __device__ inline cx<T> mixrad_tw(const cx<T>* lo, const cx<T>* hi, uint32_t e) { return cmul(hi[e >> 6], lo[e & 63u]); }
+
+// one column step of radix RAD over the buffers of a tile.  Items (r, o, k2): row, the index the step does not touch (o < M / RAD), column.  Input i of the butterfly
+// sits in buffer r * M + o * so + i * si.  FIRST: the twiddle W_N^(b k2) on the loads, b = buffer index inside the row.  POSTTW: output k times W_M^(o k) (step one
+// of two).  emit(r, o, k2, k, v) receives output k.
+template <typename T, int RAD, int P, int SP, int NT, bool FIRST, bool POSTTW, typename EMIT>
+__device__ inline void mixrad_col_step(const cx<T>* bufs, const uint32_t M, const uint32_t so, const uint32_t si, const uint32_t rowsHere, const cx<T>* twLo, const cx<T>* twHi,
+                                       const cx<T>* wM, const uint32_t tid, const EMIT& emit) {
+	const uint32_t others = M / (uint32_t)RAD, total = rowsHere * others * (uint32_t)P;
+	FastDiv divO; divO.d = others; divO.rcp = 1.0f / (float)others;
+	for (uint32_t j = tid; j < total; j += (uint32_t)NT) {
+		const uint32_t q = j / (uint32_t)P, k2 = j - q * (uint32_t)P;
+		uint32_t r, o;
+		divO.divmod(q, r, o);
+		const uint32_t b0 = o * so;
+		const cx<T>* const src = bufs + (r * M + b0) * (uint32_t)SP + k2;
+		cx<T> y[RAD];
+#pragma unroll
+		for (int i = 0; i < RAD; i++) y[i] = src[(uint32_t)i * si * (uint32_t)SP];
+		if constexpr (FIRST) {
+#pragma unroll
+			for (int i = 0; i < RAD; i++) {
+				const uint32_t e = (b0 + (uint32_t)i * si) * k2;
+				if (i > 0 || b0 != 0u) y[i] = cmul(y[i], mixrad_tw<T>(twLo, twHi, e));
+			}
 		}
-	}
-	VKFFT_SYNC();
-	// ---- 2. Rader convolution of every sub-sequence, in place
-	{
-		const uint32_t* const gp = (const uint32_t*)p.rader;
-		cx<T>* const ex = exb + f * EX;
-		const uint32_t jobs = rowsHere * M;
-		auto fsync = [&]() { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); };
-		for (uint32_t job = f; job < ((jobs + (uint32_t)FPW - 1u) / (uint32_t)FPW) * (uint32_t)FPW; job += (uint32_t)FPW) { // (every group runs every round: the barriers are the workgroup's)
-			const bool live = job < jobs;
-			uint32_t r = 0, b = 0;
-			if (live) divM.divmod(job, r, b);
-			cx<T>* const seq = rowbuf + r * N + b * (uint32_t)P;
-			const cx<T> x0 = seq[0];
-			// forward transform of x[g^a]; spectrum * FFT(w^(g^-q)) / L, + x0 on the zero frequency (= x0 added to every output); X[0] = x0 + sum of the others
-			mc_stage<T, SCH, 0, TPF, 1, true, false, true>(ex, glut, tau, waveOnly, [&](uint32_t t, uint32_t c) -> cx<T> { return seq[gp[t + c]]; },
-			                                                [&](uint32_t t, uint32_t c, cx<T> v) {
-				                                                const uint32_t k = t + c;
-				                                                cx<T> w = cmul(v, gb_load<T>(gbh, t * ES, c * ES));
-				                                                if (k == 0u) { if (live) seq[0] = cadd(x0, v); w = cadd(w, x0); }
-				                                                ex[k] = cswap(w);
-			                                                });
-			fsync();
-			// inverse transform; result q belongs to output index g^-q
-			mc_stage<T, SCH, 0, TPF, 1, true, true, false>(ex, glut, tau, waveOnly, [&](uint32_t t, uint32_t c) -> cx<T> { return ex[t + c]; },
-			                                                [&](uint32_t t, uint32_t c, cx<T> v) { if (live) seq[gp[(uint32_t)L + t + c]] = cswap(v); });
-			fsync(); // the exchange buffer is free for the next round
+		dft<RAD, T>(y);
+#pragma unroll
+		for (int k = 0; k < RAD; k++) {
+			if constexpr (POSTTW) { if (k > 0) y[k] = cmul(y[k], wM[o * (uint32_t)k]); }
+			emit(r, o, k2, (uint32_t)k, y[k]);
 		}
-	}
-	VKFFT_SYNC();
-	// ---- 3. column twiddle, M-point butterfly, coalesced stores
-	const uint32_t outRowBytes = (uint32_t)p.dim[0].outStride * ES;
-	const T sc = (T)p.scale;
-	cx<T>* const natural = ops ? rowbuf + ROWN / 2 : nullptr; // (the rows of an OPS tile fill at most half the region: mixrad_rows)
-#define VKFFT_MIXRAD_CASE(m) case m: mixrad_columns<T, m, P, NT, P>(rowbuf, N, (const cx<T>*)nullptr, N, rowsHere, gout, gtw, outRowBytes, swO, sc, tid, natural); break;
-	switch (M) {
-	VKFFT_MIXRAD_CASE(2) VKFFT_MIXRAD_CASE(3) VKFFT_MIXRAD_CASE(4) VKFFT_MIXRAD_CASE(5) VKFFT_MIXRAD_CASE(6) VKFFT_MIXRAD_CASE(7) VKFFT_MIXRAD_CASE(8)
-	VKFFT_MIXRAD_CASE(9) VKFFT_MIXRAD_CASE(10) VKFFT_MIXRAD_CASE(12) VKFFT_MIXRAD_CASE(14) VKFFT_MIXRAD_CASE(15) VKFFT_MIXRAD_CASE(16) VKFFT_MIXRAD_CASE(18)
-	VKFFT_MIXRAD_CASE(20) VKFFT_MIXRAD_CASE(21) VKFFT_MIXRAD_CASE(24) VKFFT_MIXRAD_CASE(25) VKFFT_MIXRAD_CASE(27) VKFFT_MIXRAD_CASE(28) VKFFT_MIXRAD_CASE(30)
-	VKFFT_MIXRAD_CASE(32)
-	default: break;
-	}
-#undef VKFFT_MIXRAD_CASE
-	if (ops) {
-		VKFFT_SYNC();
-		if (p.tmPostFlags & kTmOn) {
-			const bool swOut = p.swapOut != 0;
-			tm_rows_out<T>(p.tmPost, make_gbuf((char*)p.out + rowOut0 * (int64_t)p.outElemBytes), N, rowsHere, realRowsHere, rowMult, (uint32_t)p.dim[0].outStride * p.outElemBytes, p.tmPostFlags,
-			               tid, (uint32_t)NT, [&](uint32_t r, uint32_t a) -> cx<T> { const cx<T> v = natural[r * N + a]; return swOut ? cswap(v) : v; });
-		} else
-		dispatch_post_op(p.postOp, [&](auto opc) { ops_rows_out<T>(p, opc, natural, (const cx<T>*)nullptr, N, RW, realRowsHere, rowOut0, nat0, N); });
 	}
 }
-// ---- cofactors up to 10 that fit the thread groups of the prime's instance, complex rows: every thread group owns ONE sub-sequence in ONE buffer — exchange
-// buffer of the stages, carrier of the spectrum and the sub-sequence itself, exactly as a row of the prime's own Rader kernel (kernel_mixconv.h) — so the LDS
-// and the occupancy are those of that kernel (a separate tile of rows halves them: 74 = 2 * 37 ran at 2.8 TB/s against 4.3 for the prime itself).
-// forceT = rows per workgroup = FPW / M.
-template <typename T, typename SCH, int TPF, int FPW>
-__global__ void __launch_bounds__(TPF * FPW) mixrad_small_kernel(const PassParams p) {
-	constexpr int L = SCH::N, P = L + 1, NT = TPF * FPW;
-	constexpr int EXPF = SCH::NS > 1 ? MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems() : 1;
-	constexpr int SP = (EXPF > P ? EXPF : P) | 1;
+// the same step for ANY odd radix (a run-time value: 11, 13, the direct primes 17 ... 31, 15, 25 ...): the direct sum in its mirrored form,
+//     X[k], X[RAD - k] = x0 + sum_j cos(2 pi j k / RAD) (x_j + x_(RAD-j))  -+  i sum_j sin(2 pi j k / RAD) (x_j - x_(RAD-j)),     j, k = 1 ... (RAD - 1) / 2,
+// with the inputs READ AGAIN FROM LDS for every pair of outputs and the roots from the cofactor's table (W_RAD^m = wM[m * M / RAD]: one broadcast read per term).
+// Rolled loops, a dozen live registers, one body for every such radix — the butterflies of butterflies.h hold 2 RAD ... 4 RAD registers (DftPrime<31>: the kernel at 193
+// VGPRs, two wavefronts per SIMD, for every cofactor it serves).  O(RAD^2) LDS reads per butterfly; at 31 points that is still a fifth of the LDS time of the
+// prime's convolution.  The outputs must not land on the inputs (they are re-read): only the last step of a complex row (results leave to memory) takes this form.
+template <typename T, int P, int SP, int NT, bool FIRST, typename EMIT>
+__device__ inline void mixrad_col_direct(cx<T>* bufs, const uint32_t M, const uint32_t RAD, const uint32_t so, const uint32_t si, const uint32_t rowsHere, const cx<T>* twLo,
+                                         const cx<T>* twHi, const cx<T>* wM, const uint32_t tid, const EMIT& emit) {
+	const uint32_t others = M / RAD, total = rowsHere * others * (uint32_t)P, wStep = M / RAD, H = (RAD - 1u) / 2u;
+	FastDiv divO; divO.d = others; divO.rcp = 1.0f / (float)others;
+	for (uint32_t j0 = tid; j0 < total; j0 += (uint32_t)NT) {
+		const uint32_t q = j0 / (uint32_t)P, k2 = j0 - q * (uint32_t)P;
+		uint32_t r, o;
+		divO.divmod(q, r, o);
+		const uint32_t b0 = o * so, stride = si * (uint32_t)SP;
+		cx<T>* const col = bufs + (r * M + b0) * (uint32_t)SP + k2;
+		if constexpr (FIRST) { // the twiddle W_N^(b k2) once, in place (the column is this thread's)
+			for (uint32_t i = (b0 ? 0u : 1u); i < RAD; i++) col[i * stride] = cmul(col[i * stride], mixrad_tw<T>(twLo, twHi, (b0 + i * si) * k2));
+		}
+		const cx<T> x0 = col[0];
+		cx<T> sum = x0;
+		for (uint32_t i = 1; i < RAD; i++) sum = cadd(sum, col[i * stride]);
+		emit(r, o, k2, 0u, sum);
+		for (uint32_t k = 1; k <= H; k++) {
+			cx<T> a = x0, b = {(T)0, (T)0};
+			uint32_t m = 0;
+#pragma unroll 2
+			for (uint32_t jj = 1; jj <= H; jj++) {
+				m += k; if (m >= RAD) m -= RAD;
+				const cx<T> vj = col[jj * stride], vm = col[(RAD - jj) * stride], w = wM[m * wStep]; // w = cos - i sin
+				a.x += w.x * (vj.x + vm.x); a.y += w.x * (vj.y + vm.y);
+				b.x -= w.y * (vj.x - vm.x); b.y -= w.y * (vj.y - vm.y);
+			}
+			emit(r, o, k2, k, cx<T>{a.x + b.y, a.y - b.x});       // X_k = a - i b
+			emit(r, o, k2, RAD - k, cx<T>{a.x - b.y, a.y + b.x}); // X_(RAD-k) = a + i b
+		}
+	}
+}
+#ifndef VKFFT_MIXRAD_RADICES
+#define VKFFT_MIXRAD_RADICES(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(12) // butterflies in registers (mixrad_plan.h mixrad_radix_reg)
+#endif
+
+// lut = stage twiddles of SCH (length P - 1); rader = uint32 g^a mod P (a < L) followed by g^-k mod P; aux2 (aux3 for the real transforms) = FFT of the Rader
+// kernel / L (L entries), W_N^lo (64), W_N^(64 hi) (ceil(N / 64)), W_M^e (M);  raderM = M, raderA = A, T = rows (transforms) per workgroup.
+// SQ: the instance for M = P (rows of P * P points; only the primes up to 61 have one) — its column convolution costs registers that the other cofactors of the same
+// prime should not pay for (37-point instance: 84 -> 100 VGPRs)
+template <typename T, typename SCH, int TPF, int FPW, bool SQ>
+__global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
+	using G = MixradGeom<T, SCH, TPF>;
+	constexpr int L = G::L, P = G::P, NT = TPF * FPW, SP = G::SP, LUTN = G::LUTN;
 	constexpr bool waveOnly = (TPF <= 64) && (64 % TPF == 0);
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
-	__shared__ cx<T> lds[FPW * SP];
-	__shared__ cx<T> sDc[FPW];
+	VKFFT_DYN_SMEM(smem)
 	const uint32_t tid = threadIdx.x;
 	const uint32_t f = tid / TPF, tau = tid % TPF;
-	const uint32_t M = p.raderM, N = M * (uint32_t)P;
-	FastDiv divN, divM;
-	divN.d = N; divN.rcp = 1.0f / (float)N; divM.d = M; divM.rcp = 1.0f / (float)M;
-	const uint32_t RW = (uint32_t)FPW / M;
+	const uint32_t M = p.raderM, A = p.raderA, B = A ? M / A : 1u, N = M * (uint32_t)P, R = p.T;
+	const uint32_t nbuf = R * M, NH = (N + 63u) / 64u;
+	cx<T>* const bufs = (cx<T>*)smem;
+	const bool ops = p.preOp != OP_NONE || p.postOp != OP_NONE;
+	// a real transform whose last column step is a direct sum: that step may not write over its inputs and the post-map reads LDS — a second set of buffers takes its results
+	const bool twoSets = ops && mixrad_two_sets(M, A);
+	cx<T>* const bufs2 = twoSets ? bufs + nbuf * (uint32_t)SP : bufs;
+	cx<T>* const sLut = bufs2 + nbuf * (uint32_t)SP;
+	cx<T>* const sBh = sLut + LUTN;
+	cx<T>* const sTwLo = sBh + L;
+	cx<T>* const sTwHi = sTwLo + 64;
+	cx<T>* const sWM = sTwHi + NH;
+	uint16_t* const sGp = (uint16_t*)(sWM + M);
 	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
 	const uint32_t g1 = wg % p.dim[1].count, g2 = wg / p.dim[1].count;
-	const uint32_t f0 = tile * RW;
-	const uint32_t rowsHere = p.dim[0].count - f0 < RW ? p.dim[0].count - f0 : RW;
-	const GBuf gin = make_gbuf((const cx<T>*)p.in + ((int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride));
-	const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride));
-	const GBuf glut = make_gbuf(p.lut), gbh = make_gbuf(p.aux2), gtw = make_gbuf((const cx<T>*)p.aux2 + L);
-	const bool swI = p.bluesteinSwapIn != 0, swO = p.bluesteinSwapOut != 0;
-	// ---- 1. rows -> the groups' buffers: element M a + b of row r is element a of group r * M + b
-	{
+	const uint32_t rowMult = (ops && p.pairRows) ? 2u : 1u; // two real rows per complex row of the tile (kernel_tmaps.h)
+	const uint32_t f0 = tile * R * rowMult;
+	const uint32_t realRowsHere = p.dim[0].count - f0 < R * rowMult ? p.dim[0].count - f0 : R * rowMult;
+	const uint32_t rowsHere = (realRowsHere + rowMult - 1u) / rowMult; // complex rows of the tile
+	const int64_t rowIn0 = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride;
+	const int64_t rowOut0 = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride;
+	FastDiv divN, divM;
+	divN.d = N; divN.rcp = 1.0f / (float)N; divM.d = M; divM.rcp = 1.0f / (float)M;
+	// ---- 1. rows -> buffers (element M a + b of row r = element a of buffer r * M + b), tables -> LDS: one trip to memory for both
+	if (ops) {
+		const GBuf gdi = make_gbuf((const char*)p.in + rowIn0 * (int64_t)p.inElemBytes);
+		const uint32_t pitch = (uint32_t)p.dim[0].inStride * p.inElemBytes;
+		auto put = [&](uint32_t r, uint32_t pos, cx<T> z) { uint32_t a, b; divM.divmod(pos, a, b); bufs[(r * M + b) * (uint32_t)SP + a] = z; };
+		if (p.tmPreFlags & kTmTwo) tm_rows_in<T, true>(p.tmPre, gdi, N, divN, rowsHere, realRowsHere, rowMult, pitch, p.swapIn != 0, tid, (uint32_t)NT, put);
+		else tm_rows_in<T, false>(p.tmPre, gdi, N, divN, rowsHere, realRowsHere, rowMult, pitch, p.swapIn != 0, tid, (uint32_t)NT, put);
+	} else {
+		const GBuf gin = make_gbuf((const cx<T>*)p.in + rowIn0);
+		const bool swI = p.bluesteinSwapIn != 0;
 		const uint32_t inRowBytes = (uint32_t)p.dim[0].inStride * ES;
-		for (uint32_t e = tid; e < rowsHere * N; e += (uint32_t)NT) {
-			uint32_t r, n, a, b;
-			divN.divmod(e, r, n);
-			divM.divmod(n, a, b);
-			const cx<T> v = gb_load<T>(gin, r * inRowBytes + n * ES, 0);
-			lds[(r * M + b) * (uint32_t)SP + a] = swI ? cswap(v) : v;
+		constexpr int U = 4; // elements requested together
+		const uint32_t total = rowsHere * N;
+		for (uint32_t e0 = tid; e0 < total; e0 += (uint32_t)(U * NT)) {
+			cx<T> v[U]; uint32_t dst[U];
+#pragma unroll
+			for (int u = 0; u < U; u++) {
+				const uint32_t e = e0 + (uint32_t)(u * NT);
+				uint32_t r, n, a, b;
+				divN.divmod(e < total ? e : 0u, r, n);
+				divM.divmod(n, a, b);
+				v[u] = gb_load<T>(gin, e < total ? r * inRowBytes + n * ES : kGbInvalid, 0);
+				dst[u] = (r * M + b) * (uint32_t)SP + a;
+			}
+#pragma unroll
+			for (int u = 0; u < U; u++) if (e0 + (uint32_t)(u * NT) < total) bufs[dst[u]] = swI ? cswap(v[u]) : v[u];
+		}
+	}
+	{
+		const cx<T>* const glut = (const cx<T>*)p.lut;
+		for (uint32_t i = tid; i < (uint32_t)LUTN; i += (uint32_t)NT) sLut[i] = glut[i];
+		const cx<T>* const gtab = (const cx<T>*)(ops ? p.aux3 : p.aux2);
+		const uint32_t ntab = (uint32_t)L + 64u + NH + M; // (sBh, sTwLo, sTwHi, sWM are one run)
+		for (uint32_t i = tid; i < ntab; i += (uint32_t)NT) sBh[i] = gtab[i];
+		const uint32_t* const gp = (const uint32_t*)p.rader;
+		for (uint32_t i = tid; i < 2u * (uint32_t)L; i += (uint32_t)NT) sGp[i] = (uint16_t)gp[i];
+	}
+	VKFFT_SYNC();
+	// ---- 2. Rader convolution of every buffer, in place (the flow of mixconv_kernel<RADER = 1>)
+	auto fsync = [&]() { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); };
+	{
+		const uint32_t rounds = (nbuf + (uint32_t)FPW - 1u) / (uint32_t)FPW;
+		for (uint32_t rd = 0; rd < rounds; rd++) {
+			const uint32_t job = rd * (uint32_t)FPW + f;
+			const bool live = job < nbuf;
+			cx<T>* const row = bufs + (live ? job : 0u) * (uint32_t)SP;
+			const cx<T> x0 = row[0];
+			cx<T> dc = {(T)0, (T)0};
+			// forward transform of x[g^a]; spectrum * FFT(w^(g^-q)) / L, + x0 on the zero frequency (= x0 added to every output); X[0] = x0 + sum of the others
+			mixrad_stage<T, SCH, 0, TPF, 1, true>(row, (const cx<T>*)sLut, tau, waveOnly, live, [&](uint32_t t, uint32_t c) -> cx<T> { return row[sGp[t + c]]; },
+			                                      [&](uint32_t t, uint32_t c, cx<T> v) {
+				                                      const uint32_t k = t + c;
+				                                      cx<T> w = cmul(v, sBh[k]);
+				                                      if (k == 0u) { dc = cadd(x0, v); w = cadd(w, x0); }
+				                                      if (live) row[k] = cswap(w);
+			                                      });
+			fsync();
+			// inverse transform; result q belongs to output index g^-q
+			mixrad_stage<T, SCH, 0, TPF, 1, true>(row, (const cx<T>*)sLut, tau, waveOnly, live, [&](uint32_t t, uint32_t c) -> cx<T> { return row[t + c]; },
+			                                      [&](uint32_t t, uint32_t c, cx<T> v) { if (live) row[sGp[(uint32_t)L + t + c]] = cswap(v); });
+			if (tau == 0u && live) row[0] = dc; // (slot 0 carried the zero frequency of the spectrum; the scatter writes 1 ... P - 1)
 		}
 	}
 	VKFFT_SYNC();
-	// ---- 2. the Rader convolution of the group's sub-sequence, in its buffer (the flow of mixconv_kernel<RADER = 1>)
-	{
-		const uint32_t* const gp = (const uint32_t*)p.rader;
-		cx<T>* const row = lds + f * SP;
-		const bool live = f < rowsHere * M;
-		const cx<T> x0 = row[0];
-		auto fsync = [&]() { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); };
-		mc_stage<T, SCH, 0, TPF, 1, true, true, true>(row, glut, tau, waveOnly, [&](uint32_t t, uint32_t c) -> cx<T> { return live ? row[gp[t + c]] : cx<T>{(T)0, (T)0}; },
-		                                               [&](uint32_t t, uint32_t c, cx<T> v) {
-			                                               const uint32_t k = t + c;
-			                                               cx<T> w = cmul(v, gb_load<T>(gbh, t * ES, c * ES));
-			                                               if (k == 0u) { sDc[f] = cadd(x0, v); w = cadd(w, x0); } // X[0] = x0 + sum of the others
-			                                               row[k] = cswap(w);
-		                                               });
-		fsync();
-		mc_stage<T, SCH, 0, TPF, 1, true, true, true>(row, glut, tau, waveOnly, [&](uint32_t t, uint32_t c) -> cx<T> { return row[t + c]; },
-		                                               [&](uint32_t t, uint32_t c, cx<T> v) { row[gp[(uint32_t)L + t + c]] = cswap(v); });
+	// ---- 2b. M = P (rows of P * P points): the transform along b is the same prime — the same convolution on the COLUMNS of the tile (element b of column k2 of row r
+	// at buffer r * M + b, offset k2: element pitch SP), the twiddle W_N^(b k2) on the gather.  Result k1 lands in buffer k1: natural index n at buffer n / P, offset n mod P
+	if constexpr (SQ) {
+		const uint32_t ncol = R * (uint32_t)P, rounds = (ncol + (uint32_t)FPW - 1u) / (uint32_t)FPW;
+		for (uint32_t rd = 0; rd < rounds; rd++) {
+			const uint32_t job = rd * (uint32_t)FPW + f;
+			const bool live = job < ncol;
+			const uint32_t jc = live ? job : 0u, r = jc / (uint32_t)P, k2 = jc - r * (uint32_t)P;
+			cx<T>* const col = bufs + r * M * (uint32_t)SP + k2;
+			const cx<T> x0 = col[0];
+			cx<T> dc = {(T)0, (T)0};
+			mixrad_stage<T, SCH, 0, TPF, SP, false>(col, (const cx<T>*)sLut, tau, waveOnly, live,
+			                                        [&](uint32_t t, uint32_t c) -> cx<T> { const uint32_t b = sGp[t + c]; return cmul(col[b * (uint32_t)SP], mixrad_tw<T>(sTwLo, sTwHi, b * k2)); },
+			                                        [&](uint32_t t, uint32_t c, cx<T> v) {
+				                                        const uint32_t k = t + c;
+				                                        cx<T> w = cmul(v, sBh[k]);
+				                                        if (k == 0u) { dc = cadd(x0, v); w = cadd(w, x0); }
+				                                        if (live) col[k * (uint32_t)SP] = cswap(w);
+			                                        });
+			fsync();
+			mixrad_stage<T, SCH, 0, TPF, SP, false>(col, (const cx<T>*)sLut, tau, waveOnly, live, [&](uint32_t t, uint32_t c) -> cx<T> { return col[(t + c) * (uint32_t)SP]; },
+			                                        [&](uint32_t t, uint32_t c, cx<T> v) { if (live) col[(uint32_t)sGp[(uint32_t)L + t + c] * (uint32_t)SP] = cswap(v); });
+			if (tau == 0u && live) col[0] = dc;
+		}
+		VKFFT_SYNC();
 	}
-	VKFFT_SYNC();
-	// ---- 3. column twiddle, M-point butterfly, coalesced stores
+	// ---- 3. column steps
+	const bool swO = ops ? false : p.bluesteinSwapOut != 0;
+	const T sc = ops ? (T)1 : (T)p.scale;
+	const GBuf gout = make_gbuf((cx<T>*)p.out + rowOut0);
 	const uint32_t outRowBytes = (uint32_t)p.dim[0].outStride * ES;
-	const T sc = (T)p.scale;
-#define VKFFT_MIXRAD_CASE(m) case m: mixrad_columns<T, m, P, NT, SP>(lds, M * (uint32_t)SP, sDc, N, rowsHere, gout, gtw, outRowBytes, swO, sc, tid, (cx<T>*)nullptr); break;
-	switch (M) {
-	VKFFT_MIXRAD_CASE(2) VKFFT_MIXRAD_CASE(3) VKFFT_MIXRAD_CASE(4) VKFFT_MIXRAD_CASE(5) VKFFT_MIXRAD_CASE(6) VKFFT_MIXRAD_CASE(7) VKFFT_MIXRAD_CASE(8)
-	VKFFT_MIXRAD_CASE(9) VKFFT_MIXRAD_CASE(10)
-	default: break;
+	const uint32_t Ae = A ? A : 1u; // (M = P: one "step" of M, already done)
+	if (SQ && !ops) { // the rows leave in natural order: one contiguous run per row
+		const uint32_t total = rowsHere * N;
+		for (uint32_t e = tid; e < total; e += (uint32_t)NT) {
+			uint32_t r, n;
+			divN.divmod(e, r, n);
+			const uint32_t k1 = n / (uint32_t)P, k2 = n - k1 * (uint32_t)P;
+			cx<T> v = bufs[(r * M + k1) * (uint32_t)SP + k2];
+			if (swO) v = cswap(v);
+			if (sc != (T)1) v = cscale(v, sc);
+			gb_store<T>(gout, r * outRowBytes + n * ES, 0, v);
+		}
 	}
+	if (!SQ && A > 1u) {
+		auto inPlace = [&](uint32_t r, uint32_t o, uint32_t k2, uint32_t k, cx<T> v) { bufs[(r * M + o + k * B) * (uint32_t)SP + k2] = v; };
+#define VKFFT_MIXRAD_CASE(m) case m: if constexpr (2 * m * P <= (int)kMixradLongest) mixrad_col_step<T, m, P, SP, NT, true, true>(bufs, M, 1u, B, rowsHere, sTwLo, sTwHi, sWM, tid, inPlace); break;
+		switch (A) { VKFFT_MIXRAD_RADICES(VKFFT_MIXRAD_CASE) default: break; }
 #undef VKFFT_MIXRAD_CASE
+		VKFFT_SYNC();
+	}
+	if constexpr (!SQ) {
+		auto store = [&](uint32_t r, uint32_t o, uint32_t k2, uint32_t k, cx<T> v) {
+			if (ops) { bufs2[(r * M + o * B + k) * (uint32_t)SP + k2] = v; return; }
+			if (swO) v = cswap(v);
+			if (sc != (T)1) v = cscale(v, sc);
+			gb_store<T>(gout, r * outRowBytes + (k2 + (uint32_t)P * (o + A * k)) * ES, 0, v);
+		};
+		// (A == 1: this is the first step and carries the twiddle; else the buffers hold step one's results)
+#define VKFFT_MIXRAD_CASE(m) case m: if constexpr (m * P <= (int)kMixradLongest) { \
+			if (A == 1u) mixrad_col_step<T, m, P, SP, NT, true, false>(bufs, M, B, 1u, rowsHere, sTwLo, sTwHi, sWM, tid, store); \
+			else if constexpr (2 * m * P <= (int)kMixradLongest) mixrad_col_step<T, m, P, SP, NT, false, false>(bufs, M, B, 1u, rowsHere, sTwLo, sTwHi, sWM, tid, store); } break;
+		switch (B) {
+		VKFFT_MIXRAD_RADICES(VKFFT_MIXRAD_CASE)
+		default: // an odd radix without a register butterfly here (complex rows only: mixrad_plan.h)
+			if (A == 1u) mixrad_col_direct<T, P, SP, NT, true>(bufs, M, B, B, 1u, rowsHere, sTwLo, sTwHi, sWM, tid, store);
+			else mixrad_col_direct<T, P, SP, NT, false>(bufs, M, B, B, 1u, rowsHere, sTwLo, sTwHi, sWM, tid, store);
+			break;
+		}
+#undef VKFFT_MIXRAD_CASE
+	}
+	if (ops) {
+		VKFFT_SYNC();
+		const bool swOut = p.swapOut != 0;
+		tm_rows_out<T>(p.tmPost, make_gbuf((char*)p.out + rowOut0 * (int64_t)p.outElemBytes), N, rowsHere, realRowsHere, rowMult, (uint32_t)p.dim[0].outStride * p.outElemBytes, p.tmPostFlags,
+		               tid, (uint32_t)NT, [&](uint32_t r, uint32_t n) -> cx<T> {
+			               const uint32_t k1 = n / (uint32_t)P, k2 = n - k1 * (uint32_t)P, k1b = k1 / Ae, k1a = k1 - k1b * Ae;
+			               const cx<T> v = bufs2[(r * M + k1a * (M / Ae) + k1b) * (uint32_t)SP + k2];
+			               return swOut ? cswap(v) : v;
+		               });
+	}
 }
 
 template <typename T, typename SCH, int TPF, int FPW> void mixrad_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
-	constexpr int P = SCH::N + 1;
+	using G = MixradGeom<T, SCH, TPF>;
 	const bool ops = prm.preOp != OP_NONE || prm.postOp != OP_NONE;
-	const int mode = mixrad_mode((uint32_t)P, (uint32_t)FPW, prm.raderM, ops);
-	if (mode == 1) hipLaunchKernelGGL((mixrad_small_kernel<T, SCH, TPF, FPW>), grid, dim3(TPF * FPW), 0, s, prm);
-	else if constexpr (12 * P <= (int)kMixradLongest) { if (mode == 2) hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW>), grid, dim3(TPF * FPW), 0, s, prm); }
+	const size_t lds = (size_t)mixrad_lds_bytes((uint32_t)G::P, (uint32_t)G::SP, (uint32_t)G::LUTN, prm.raderM, prm.T, (uint32_t)sizeof(cx<T>), ops && mixrad_two_sets(prm.raderM, prm.raderA));
+	if (prm.raderA == 0u) {
+		if constexpr (G::P * G::P <= (int)kMixradLongest) hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, true>), grid, dim3(TPF * FPW), lds, s, prm);
+	} else hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, false>), grid, dim3(TPF * FPW), lds, s, prm);
 }
-// the composite forms exist for the fp32 Rader ROW instances whose prime leaves room for a cofactor (2 P <= the longest row)
+// the composite form exists for the Rader ROW instances whose prime leaves room for a cofactor (2 P <= the longest row)
 template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> constexpr auto mixrad_ptr() -> void (*)(const PassParams&, dim3, hipStream_t) {
 	constexpr int P = SCH::N + 1;
 	if constexpr (RADER != 0 && COL == 0 && sizeof(T) == 4 && 2 * P <= (int)kMixradLongest) return &mixrad_launch<T, SCH, TPF, FPW>;
 	else return nullptr;
 }
+template <typename T, typename SCH, int TPF, int RADER, int COL> constexpr int mixrad_sp() { if constexpr (RADER != 0 && COL == 0) return MixradGeom<T, SCH, TPF>::SP; else return 0; }
+template <typename T, typename SCH, int TPF, int RADER, int COL> constexpr int mixrad_lutn() { if constexpr (RADER != 0 && COL == 0) return MixradGeom<T, SCH, TPF>::LUTN; else return 0; }
 
 } // namespace vkfft_mi355x

@@ -150,6 +150,13 @@ bool mixrad_available(int variant) {
 	const int idx = variant & 0xffff;
 	return variant >= 0 && idx < cnt && tab[idx].launchRad != nullptr;
 }
+bool mixrad_geom(int variant, int* sp, int* lutn) {
+	if (!mixrad_available(variant)) return false;
+	int cnt = 0;
+	const MixConvVariant* tab = mixconv_part((variant >> 16) % kMixConvParts, &cnt);
+	*sp = tab[variant & 0xffff].radSP; *lutn = tab[variant & 0xffff].radLutN;
+	return true;
+}
 int launch_mixconv(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 	const uint64_t grid64 = (uint64_t)prm.tilesPerG0 * (prm.colMerge ? 1u : prm.dim[1].count) * prm.dim[2].count;
 	if (grid64 == 0) return 0;

@@ -120,7 +120,7 @@ struct PassBuild {
 	uint32_t raderDirectMax = 0;
 	std::string label;
 	uint32_t forceT = 0;
-	uint32_t raderM = 0; // mixrad_kernel: cofactor of the composite length (kernel_mixrad.h)
+	uint32_t raderM = 0, raderA = 0; // mixrad_kernel: cofactor of the composite length and its split (kernel_mixrad.h)
 	std::vector<uint32_t> radices; // explicit stage radices (fast kernels fix their own schedule)
 	int fastKernel = KERNEL_GENERIC, fastVariant = -1, fastThreads = 0;
 	bool allowFast = true;
@@ -166,9 +166,10 @@ static void make_mixconv_rader_tables(uint64_t P, bool dp, Arena& ar, size_t& ta
 	for (uint64_t m = 0; m < L; m++) ar.putc(bhatOff, m, bk[m] / (ld)L, dp);
 }
 
-// ... followed by the column twiddles of the composite form (kernel_mixrad.h): W_N^(b k2) at L + (b - 1) * P + k2, b = 1 ... M - 1, N = M * P
+// ... followed by the tables of the column steps of the composite form (kernel_mixrad.h), N = M * P: W_N^lo (lo < 64), W_N^(64 hi) (hi < ceil(N / 64)) — the
+// twiddle W_N^(b k2) is the product of two entries — and W_M^e (e < M)
 static void make_mixrad_tables(uint64_t P, uint64_t M, bool dp, Arena& ar, size_t& tabOff, size_t& bhatOff) {
-	const uint64_t L = P - 1, g = primitive_root(P), gi = powmod(g, P - 2, P), N = M * P;
+	const uint64_t L = P - 1, g = primitive_root(P), gi = powmod(g, P - 2, P), N = M * P, NH = (N + 63) / 64;
 	tabOff = ar.alloc(2 * (size_t)L * sizeof(uint32_t));
 	std::vector<cld> bk(L);
 	{
@@ -177,9 +178,40 @@ static void make_mixrad_tables(uint64_t P, uint64_t M, bool dp, Arena& ar, size_
 		for (uint64_t q = 0; q < L; q++) { tab[q] = (uint32_t)gp; tab[L + q] = (uint32_t)gm; bk[q] = unit_root(gm, P); gp = gp * g % P; gm = gm * gi % P; }
 	}
 	host_fft(bk);
-	bhatOff = ar.alloc((L + (M - 1) * P) * (dp ? 16 : 8));
+	bhatOff = ar.alloc((L + 64 + NH + M) * (dp ? 16 : 8));
 	for (uint64_t m = 0; m < L; m++) ar.putc(bhatOff, m, bk[m] / (ld)L, dp);
-	for (uint64_t b = 1; b < M; b++) for (uint64_t k = 0; k < P; k++) ar.putc(bhatOff, L + (b - 1) * P + k, unit_root((b * k) % N, N), dp);
+	for (uint64_t e = 0; e < 64; e++) ar.putc(bhatOff, L + e, unit_root(e % N, N), dp);
+	for (uint64_t h = 0; h < NH; h++) ar.putc(bhatOff, L + 64 + h, unit_root((64 * h) % N, N), dp);
+	for (uint64_t e = 0; e < M; e++) ar.putc(bhatOff, L + 64 + NH + e, unit_root(e, M), dp);
+}
+// A row of L = M * P complex points on the Rader-stage kernel (kernel_mixrad.h): P the largest prime factor (37 or more, with a Rader row instance), M a cofactor
+// that splits into the kernel's column radices (mixrad_plan.h).  VKFFT_MI355X_MIXRAD=0: off; VKFFT_MI355X_MIXRAD_LDS_KIB: the LDS budget of a tile (tuning)
+struct MixradChoice { uint64_t P = 0, M = 0, len = 0; uint32_t A = 0, rows = 0; int variant = -1, rad[5] = {1, 1, 1, 1, 1}, fpw = 0, threads = 0; double cost = 2.0; };
+static bool mixrad_choose(uint64_t L, bool dp, bool ops, MixradChoice& c) { // ops: a real transform between the table-driven maps
+	if (dp || L < 74 || L > kMixradLongest) return false;
+	if (getenv("VKFFT_MI355X_MIXRAD") && atoi(getenv("VKFFT_MI355X_MIXRAD")) == 0) return false;
+	uint64_t P = 0, rest = L;
+	for (uint64_t q = 2; q * q <= rest; q++) while (rest % q == 0) { P = q; rest /= q; }
+	if (rest > 1) P = rest; // largest prime factor
+	if (P < 37 || P == L) return false;
+	const uint64_t M = L / P;
+	uint32_t A = 0, B = 0;
+	if (M == P) A = 0; // P * P: the column transform is the prime's own convolution (kernel_mixrad.h, 2b)
+	else if (!mixrad_split((uint32_t)M, A, B)) return false;
+	uint64_t len; int sp = 0, lutn = 0;
+	if (!mixconv_lookup(true, false, P, dp, &c.variant, &len, c.rad, &c.fpw, &c.threads) || !mixrad_geom(c.variant, &sp, &lutn)) return false;
+	const uint64_t budget = (getenv("VKFFT_MI355X_MIXRAD_LDS_KIB") ? (uint64_t)atoll(getenv("VKFFT_MI355X_MIXRAD_LDS_KIB")) : 40ull) << 10;
+	const bool twoSets = ops && mixrad_two_sets((uint32_t)M, A);
+	c.P = P; c.M = M; c.A = A; c.len = len;
+	c.rows = mixrad_rows((uint32_t)P, (uint32_t)sp, (uint32_t)lutn, (uint32_t)c.fpw, (uint32_t)M, dp ? 16u : 8u, budget, twoSets);
+	if (mixrad_lds_bytes((uint32_t)P, (uint32_t)sp, (uint32_t)lutn, (uint32_t)M, c.rows, dp ? 16u : 8u, twoSets) > 160ull * 1024) return false;
+	// points of the fused power-of-two Bluestein transform that one point of the row costs (profiles/r06_rader_stage_forced_vs_bluestein.jsonl: every served class
+	// forced either way): 1.2-2.2 with register column steps; a direct last step of radix B adds (B / 33)^2.2 (23: 2.4, 29: 2.5, 37: 3.4, 49: 4.3); primes whose
+	// own convolution has a radix-13 stage (131, 157, 313: 2.2-3.2) one more, 521 and up (three stages, 138 registers: 3.9) two
+	c.cost = 1.9;
+	if (A != 0 && !mixrad_radix_reg(B)) c.cost += std::pow((double)B / 33.0, 2.2);
+	if ((P - 1) % 13 == 0) c.cost += P >= 500 ? 2.0 : 1.0;
+	return true;
 }
 
 // Real-transform families that can carry TWO rows per complex transform (kernel_generic.h ops_rows_in / ops_rows_out): the pre-map of a row is a real
@@ -456,27 +488,22 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 				if (fo > 0 && fo != fpw) { thr = thr / fpw * fo; fpw = fo; }
 				b.fastKernel = KERNEL_MIXED_ROW; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
 				for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
-			} else if (!b.dp && b.L >= 74 && b.L <= 4096 && !is_prime_u(b.L) && [&]() {
-				// the complex length is M * P with a Rader prime and a served cofactor: mixrad_kernel behind the maps (kernel_mixrad.h)
-				if (getenv("VKFFT_MI355X_MIXRAD") && atoi(getenv("VKFFT_MI355X_MIXRAD")) == 0) return false;
-				uint64_t P = 0, rest = b.L;
-				for (uint64_t q = 2; q * q <= rest; q++) while (rest % q == 0) { P = q; rest /= q; }
-				if (rest > 1) P = rest;
-				const uint64_t M = P ? b.L / P : 0;
-				if (P < 37 || !mixrad_cofactor_ok((uint32_t)M) || !mixconv_lookup(true, false, P, b.dp, &variant, &len, rad5, &fpw, &thr) || !mixrad_available(variant)) return false;
-				const int mode = mixrad_mode((uint32_t)P, (uint32_t)fpw, (uint32_t)M, true);
-				if (!mixrad_fits(mode, (uint32_t)P, (uint32_t)fpw, (uint32_t)M, true)) return false;
+			} else if (!padMask && tm_family(b.preOp, b.postOp, b.L, b.opN) != TM_NONE && !getenv("VKFFT_MI355X_NO_TMAPS") && [&]() {
+				// the complex length is M * P with a Rader prime and a served cofactor: mixrad_kernel between the table-driven maps (kernel_mixrad.h, kernel_tmaps.h)
+				MixradChoice mr;
+				if (!mixrad_choose(b.L, b.dp, true, mr)) return false;
+				if ((2 * (uint64_t)mr.rows + 2) * (uint64_t)std::max<int64_t>(std::llabs(d0o.inStride), std::llabs(d0o.outStride)) * (b.dp ? 16 : 8) >= 0x7FFFFF00ull) return false;
 				const uint64_t N = b.L;
 				if (!b.inLen) b.inLen = (uint32_t)N;
 				if (!b.outLen) b.outLen = (uint32_t)N;
 				if (!b.blueN) b.blueN = (uint32_t)N;
 				size_t bhatOff;
-				make_mixrad_tables(P, M, b.dp, ar, mixconvTabOff, bhatOff);
+				make_mixrad_tables(mr.P, mr.M, b.dp, ar, mixconvTabOff, bhatOff);
 				b.auxOff2ForPre = bhatOff;
-				b.L = len; b.raderM = (uint32_t)M;
-				b.fastKernel = KERNEL_MIXCONV; b.fastVariant = variant; b.fastThreads = thr;
-				b.forceT = mixrad_rows(mode, (uint32_t)P, (uint32_t)fpw, (uint32_t)M, true);
-				for (int k = 0; k < 5; k++) if (rad5[k] > 1) b.radices.push_back((uint32_t)rad5[k]);
+				b.L = mr.len; b.raderM = (uint32_t)mr.M; b.raderA = mr.A;
+				b.fastKernel = KERNEL_MIXCONV; b.fastVariant = mr.variant; b.fastThreads = mr.threads;
+				b.forceT = mr.rows;
+				for (int k = 0; k < 5; k++) if (mr.rad[k] > 1) b.radices.push_back((uint32_t)mr.rad[k]);
 				return true;
 			}()) {
 			} else if (b.L >= 37 && is_prime_u(b.L) && mixconv_lookup(true, false, b.L, b.dp, &variant, &len, rad5, &fpw, &thr)) {
@@ -643,21 +670,23 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.bigSpan = b.bigSpan ? 1u : 0u;
 	p.divL = make_fastdiv((uint32_t)b.L);
 	p.divOutLen = make_fastdiv(p.outLen);
-	p.raderM = b.raderM; // mixrad_kernel: rows of raderM * (L + 1) points
+	p.raderM = b.raderM; p.raderA = b.raderA; // mixrad_kernel: rows of raderM * (L + 1) points
 	const uint64_t padded = p.padShift >= 31 ? b.L : b.L + (b.L >> p.padShift);
 	p.ldsElems = (uint32_t)((padded + 1) * p.Tp);
 	p.tilesPerG0 = (uint32_t)((dims[0].count + T - 1) / T);
-	if (opsCplxLen && b.fastKernel != KERNEL_GENERIC && !getenv("VKFFT_MI355X_NO_ROW_PAIRS")) {
+	const bool noPairs = getenv("VKFFT_MI355X_NO_ROW_PAIRS") != nullptr;
+	if (opsCplxLen && b.fastKernel != KERNEL_GENERIC && (!noPairs || b.raderM)) { // (the Rader-stage kernel has no other maps than the tables: kernel_mixrad.h)
 		// two real rows per complex transform (the reference's mergeSequencesR2C, vkFFT_SharedMemory.h:40): the families whose pre-map is a real sequence
 		// (post-map through the even / odd split) or whose result is real (kernel_generic.h ops_rows_in / ops_rows_out); the tile holds 2 T rows
 		// table-driven maps (kernel_tmaps.h): the instance transform of kernel_mixed.h; with them the families whose operation the generic maps only know at run time pair too
-		const TmFamily tmf = ((((b.fastKernel == KERNEL_MIXED_ROW || (b.fastKernel == KERNEL_MIXCONV && !b.raderM)) && b.fastThreads / (int)T >= tmaps_min_tpf()) || (b.fastKernel == KERNEL_MIXCONV && b.raderM && !getenv("VKFFT_MI355X_NO_MIXRAD_TMAPS"))) && !b.padInN && !b.padOutN && !getenv("VKFFT_MI355X_NO_TMAPS")) ? tm_family(b.preOp, b.postOp, opsCplxLen, b.opN) : TM_NONE;
+		const TmFamily tmf = ((((b.fastKernel == KERNEL_MIXED_ROW || (b.fastKernel == KERNEL_MIXCONV && !b.raderM)) && b.fastThreads / (int)T >= tmaps_min_tpf()) || (b.fastKernel == KERNEL_MIXCONV && b.raderM)) && !b.padInN && !b.padOutN && !getenv("VKFFT_MI355X_NO_TMAPS")) ? tm_family(b.preOp, b.postOp, opsCplxLen, b.opN) : TM_NONE;
 		// (the one family that does not pair — even DCT / DST-IV on its half-length complex form — with fewer than four threads per row: the staged tile of ONE row per
 		// thread measured 1.8x slower than the generic loops: DCT-IV of 20 and 30 reals, profiles/r05_dct4_rows_reference_every_length_step3_*; and the maps address
 		// the 2 T real rows of a tile with 32-bit byte offsets from the tile's base)
 		const uint64_t tmReach = (2 * (uint64_t)T + 2) * (uint64_t)std::max<int64_t>(std::llabs(dims[0].inStride), std::llabs(dims[0].outStride)) * (dp ? 16 : 8);
-		const bool tmOn = tmf != TM_NONE && !(tmf == TM_R2R4_EVEN && b.fastThreads / (int)T < 4) && tmReach < 0x7FFFFF00ull;
-		if (pairable_family(b.preOp, b.postOp, opsCplxLen, b.opN) || (tmOn && tm_family_pairs(tmf))) {
+		const bool tmOn = tmf != TM_NONE && !(tmf == TM_R2R4_EVEN && !b.raderM && b.fastThreads / (int)T < 4) && tmReach < 0x7FFFFF00ull;
+		if (b.raderM && !tmOn) return 3002;
+		if (!noPairs && (pairable_family(b.preOp, b.postOp, opsCplxLen, b.opN) || (tmOn && tm_family_pairs(tmf)))) {
 			p.pairRows = 1;
 			p.tilesPerG0 = (uint32_t)((dims[0].count + 2 * (uint64_t)T - 1) / (2 * (uint64_t)T));
 		}
@@ -1261,39 +1290,29 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	// look-ups through L2); VKFFT_MI355X_MIXCONV=0 turns the family off, =2 always prefers it (tests, tuning)
 	// ... or, for a composite length M * P with ONE prime factor above 31 whose P - 1 is 13-smooth and a cofactor of at most 32: the Rader convolution as a
 	// stage of the row (kernel_mixrad.h; the reference's Rader stage inside its radix kernels, vkFFT_Scheduler.h:1733-1873).  VKFFT_MI355X_MIXRAD=0: off
-	if (unit && !padded && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N) && !dp && j.N <= 4096u &&
-	    !(getenv("VKFFT_MI355X_MIXRAD") && atoi(getenv("VKFFT_MI355X_MIXRAD")) == 0)) {
-		uint64_t P = 0, rest = j.N;
-		for (uint64_t q = 2; q * q <= rest; q++) while (rest % q == 0) { P = q; rest /= q; }
-		if (rest > 1) P = rest; // largest prime factor
-		const uint64_t M = P ? j.N / P : 0;
-		int v, r5[5], f, t; uint64_t len;
+	if (unit && !padded && !nativeInstance && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein && !smooth13(j.N)) {
+		MixradChoice mr;
 		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
-		// taken where it was measured faster than the fused Bluestein kernel on the next power of two M2 >= 2N - 1 (profiles/r04_rader_stage_*.jsonl: every served
-		// length forced either way).  A point of the row costs c points of the padded power-of-two transform: the one-buffer kernel for cofactors up to 10
-		// c = 2 (74 ... 2570: 1.1-2.3x Bluestein wherever the padding is 2x or more; 0.9x at 122, 123, 254 right below a power of two), 3 where the prime's
-		// own convolution has a radix-13 stage (131, 157, 313, 521, 677: 939 = 3 * 313 and 1563 = 3 * 521 0.75x); the tiled kernel for the larger
-		// cofactors 3.4 and 5.7 (2670 1.7x, 3232 1.1x; 2020, 2032, 3144 0.6-0.7x).  Bluestein's 8192-point rows leave one workgroup per CU: 1.5 per point.
+		// taken where it is faster than the fused Bluestein kernel on the next power of two M2 >= 2N - 1 (every served length forced either way on the device).  A point of
+		// the row costs c points of the padded power-of-two transform; Bluestein's 8192-point rows leave one workgroup per CU: 1.5 per point
 		uint64_t M2 = 64; while (M2 < 2 * j.N - 1) M2 *= 2;
 		const bool radForced = getenv("VKFFT_MI355X_MIXRAD") && atoi(getenv("VKFFT_MI355X_MIXRAD")) == 2; // (tests: always)
-		bool radTake = P >= 37 && mixrad_cofactor_ok((uint32_t)M) && (rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && mixconv_lookup(true, false, P, dp, &v, &len, r5, &f, &t) && mixrad_available(v);
+		bool radTake = mixrad_choose(j.N, dp, false, mr) && (rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull;
 		if (radTake) {
-			const int mode = mixrad_mode((uint32_t)P, (uint32_t)f, (uint32_t)M, false);
-			const bool slowRadix = (P - 1) % 13 == 0;
-			const double c = mode == 1 ? (slowRadix ? 3.0 : 2.0) : (slowRadix ? 5.7 : 3.4);
-			radTake = mixrad_fits(mode, (uint32_t)P, (uint32_t)f, (uint32_t)M, false) && (radForced || c * (double)j.N < (double)M2 * (M2 >= 8192 ? 1.5 : 1.0));
+			const double c = getenv("VKFFT_MI355X_MIXRAD_COST") ? atof(getenv("VKFFT_MI355X_MIXRAD_COST")) : mr.cost;
+			radTake = radForced || c * (double)j.N < (double)M2 * (M2 >= 8192 ? 1.5 : 1.0);
 		}
 		if (radTake) {
-			b.L = len; b.inLen = b.outLen = (uint32_t)j.N; b.opN = (uint32_t)j.N;
-			for (int k = 0; k < 5; k++) if (r5[k] > 1) b.radices.push_back((uint32_t)r5[k]);
-			b.fastKernel = KERNEL_MIXCONV; b.fastVariant = v; b.fastThreads = t;
-			b.forceT = mixrad_rows(mixrad_mode((uint32_t)P, (uint32_t)f, (uint32_t)M, false), (uint32_t)P, (uint32_t)f, (uint32_t)M, false); // rows per workgroup
-			b.raderM = (uint32_t)M;
+			b.L = mr.len; b.inLen = b.outLen = (uint32_t)j.N; b.opN = (uint32_t)j.N;
+			for (int k = 0; k < 5; k++) if (mr.rad[k] > 1) b.radices.push_back((uint32_t)mr.rad[k]);
+			b.fastKernel = KERNEL_MIXCONV; b.fastVariant = mr.variant; b.fastThreads = mr.threads;
+			b.forceT = mr.rows; // rows per workgroup
+			b.raderM = (uint32_t)mr.M; b.raderA = mr.A;
 			b.bsSwapIn = b.bsSwapOut = j.inverse; b.scale = j.scale;
 			b.inStrideJ = j.inStrideJ; b.outStrideJ = j.outStrideJ; b.dims = j.others;
 			b.colIn = b.colOut = false;
 			size_t tabOff, bhatOff;
-			make_mixrad_tables(P, M, dp, ar, tabOff, bhatOff);
+			make_mixrad_tables(mr.P, mr.M, dp, ar, tabOff, bhatOff);
 			b.aux2Off = bhatOff;
 			b.label = "rader-stage";
 			PassPlan pp; int r = finish_pass(b, ar, pp); if (r) return r;
@@ -1716,11 +1735,8 @@ static bool real_row_prefers_bluestein(uint64_t L, bool dp) {
 	int v, r5[5], f, t; uint64_t len;
 	if (mixed_row_lookup(L, dp, &v, r5, &f, &t)) return false;
 	if (P == L) return !mixconv_lookup(true, false, P, dp, &v, &len, r5, &f, &t);
-	if (getenv("VKFFT_MI355X_MIXRAD") && atoi(getenv("VKFFT_MI355X_MIXRAD")) == 0) return true;
-	const uint64_t M = L / P;
-	if (!dp && P >= 37 && mixrad_cofactor_ok((uint32_t)M) && mixconv_lookup(true, false, P, dp, &v, &len, r5, &f, &t) && mixrad_available(v) &&
-	    mixrad_fits(mixrad_mode((uint32_t)P, (uint32_t)f, (uint32_t)M, true), (uint32_t)P, (uint32_t)f, (uint32_t)M, true)) return false;
-	return true;
+	MixradChoice mr;
+	return !mixrad_choose(L, dp, true, mr);
 }
 
 // ---- real transforms: coverage path -------------------------------------------------------------------------
@@ -1788,7 +1804,10 @@ static bool prefer_full_length_pairs(const TransformDesc& d, uint64_t N, bool un
 	const int mode = getenv("VKFFT_MI355X_EVEN_FULL") ? atoi(getenv("VKFFT_MI355X_EVEN_FULL")) : 1;
 	if (!mode || d.disableFastKernels || !unit || rows < 2 || getenv("VKFFT_MI355X_NO_TMAPS") || getenv("VKFFT_MI355X_NO_ROW_PAIRS") || getenv("VKFFT_MI355X_NO_MIXED_OPS")) return false;
 	int v, r5[5], f, t;
-	if (!mixed_row_lookup(N, d.dp, &v, r5, &f, &t) || t / f < 8) return false; // (eight: the plain sides of R2C / C2R then move directly, kernel_mixed.h DIRECT)
+	// (eight: the plain sides of R2C / C2R then move directly, kernel_mixed.h DIRECT; round 6: or the full length runs on the Rader-stage kernel, whose maps are the
+	// tables of the full-length forms only — the half-length complex form of 328 = 2 * 4 * 41 reals fell back to the interpreter: 0.17x the reference)
+	MixradChoice mr;
+	if (!(mixed_row_lookup(N, d.dp, &v, r5, &f, &t) && t / f >= 8) && !mixrad_choose(N, d.dp, true, mr)) return false;
 	if (mode == 1 && opfft_lookup(halfLen, d.dp, false, false, preHalf, postHalf, &v, r5, &f, &t)) return false;
 	return true;
 }
