@@ -168,11 +168,14 @@ def main():
     copy_GBps = GIB2 / (copy_ms * 1e-3) / 1e9
     # ... and the library's own streaming copy (16 bytes per lane, non-temporal on both sides: extension vkfftMI355XStreamCopy)
     lib = api.load()
-    own = lambda: lib.vkfftMI355XStreamCopy(other.data_ptr(), buf.data_ptr(), 8 << TOTAL_LOG2, stream if stream else None)
+    own_rc = []
+    own = lambda: own_rc.append(lib.vkfftMI355XStreamCopy(other.data_ptr(), buf.data_ptr(), 8 << TOTAL_LOG2, stream if stream else None))
+    other.zero_()
     own()
     own_ms = min(timed(own, 10) for _ in range(2))
     own_GBps = GIB2 / (own_ms * 1e-3) / 1e9
-    copy_ok = bool(torch.equal(other, buf))
+    # (the copy counts as a ceiling only when every launch returned success and the bytes arrived: a refused launch would time as "infinitely fast")
+    copy_ok = all(rc == 0 for rc in own_rc) and bool(torch.equal(other, buf))
     del other
     for k in range(KMIN, KMAX + 1):
         ms = timed(lambda: (apps[k].forward(), apps[k].inverse()), reps)
@@ -204,7 +207,7 @@ def main():
                     launches_per_transform=per_size[kd]["launches"], launch_ms=round(launch_ms, 5),
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
                     copy_GBps_same_box=round(copy_GBps, 1), copy_GBps_own_float4=round(own_GBps, 1) if copy_ok else None,
-                    frac_of_copy=round(achieved / max(copy_GBps, own_GBps), 4), traffic=None)
+                    frac_of_copy=round(achieved / (max(copy_GBps, own_GBps) if copy_ok else copy_GBps), 4), traffic=None)
     # HBM-side bytes per launch from the PMC passes (tools/pmc_probe.py -> tools/summarize_profiles.py); valid only for the build they were
     # collected on, so the newest summary is used only when its source hash is the one of the sources this library was built from
     import glob

@@ -93,3 +93,20 @@ def test_public_header_compiles_as_c99():
         open(os.path.join(d, "caller.c"), "w").write(src)
         subprocess.check_call(["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"), "-I/opt/rocm/include",
                                "-c", os.path.join(d, "caller.c"), "-o", os.path.join(d, "caller.o")])
+
+
+def test_environment_switches_are_documented():
+    """every VKFFT_MI355X_* name the library reads (literal getenv calls in vkfft_amd/csrc) appears in INTEGRATION.md's switch table — by its full name or by the
+    abbreviated `_SUFFIX` form the table uses inside a family — and the table names no switch the sources do not read"""
+    import glob, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = "".join(open(f, errors="replace").read() for f in glob.glob(os.path.join(root, "vkfft_amd", "csrc", "*")) if f.endswith((".cpp", ".hip", ".h")))
+    read = set(re.findall(r'getenv\("(VKFFT_MI355X_[A-Z0-9_]+)"\)', src))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    table = doc[doc.index("## Environment switches"):doc.index("## FFI stubs")]
+    missing = [n for n in sorted(read) if n not in table and ("`" + n[len("VKFFT_MI355X"):]) not in table]
+    assert not missing, missing
+    named = set(re.findall(r"VKFFT_MI355X_[A-Z0-9_]+", table))
+    built = {"VKFFT_MI355X_P2V", "VKFFT_MI355X_FUV", "VKFFT_MI355X_LIB"}  # (names assembled at run time: P2V<k>, FUV<k>; the Python stub's own)
+    stale = [n for n in sorted(named) if n not in read and n not in built and not any(r.startswith(n) for r in read)]
+    assert not stale, stale

@@ -432,7 +432,7 @@ def test_rader_stage_plan_is_taken(emu_lib):
     buf = np.zeros(2670 * 4, np.complex64)
     a = api.App([2670], 4, buffer_ptr=buf.ctypes.data, lib=emu_lib)
     n, kern = a.launch_info(); a.delete()
-    assert n == 1 and "mixconv" in kern, (n, kern)
+    assert n == 1 and "mixrad" in kern, (n, kern)
 
 
 @pytest.mark.parametrize("k,batch", [(14, 5), (15, 3), (16, 3), (17, 2), (18, 2), (19, 2), (20, 1)])
@@ -486,6 +486,7 @@ def _mixconv_cases():
 def test_one_kernel_cyclic_convolution_rows(run, oracle, chunk, monkeypatch):
     """Rader (prime p, transform length p-1) and Bluestein on a smooth padded length, forward and round trip, dense rows and a partial last tile"""
     monkeypatch.setenv("VKFFT_MI355X_MIXCONV", "2")  # always prefer the family: the cost model would give some of these lengths to the power-of-two kernel
+    monkeypatch.setenv("VKFFT_MI355X_MIXRAD_PRIMES", "0")  # (the instances of kernel_mixconv.h themselves: a prime\'s rows otherwise run on kernel_mixrad.h with the tables in LDS)
     for N, dp in _mixconv_cases()[chunk::4]:
         batch = 3 if N > 512 else 37
         x = parity.seeded_complex(N * batch, dp, N)
@@ -499,6 +500,7 @@ def test_one_kernel_cyclic_convolution_rows(run, oracle, chunk, monkeypatch):
 def test_one_kernel_cyclic_convolution_is_chosen(run, monkeypatch):
     """the plan of a Rader prime / of a length just above a power of two is ONE launch of the family (not the interpreter, not the power-of-two kernel)"""
     monkeypatch.setenv("VKFFT_MI355X_MIXCONV", "2")
+    monkeypatch.setenv("VKFFT_MI355X_MIXRAD_PRIMES", "0")  # (the instances of kernel_mixconv.h themselves: a prime\'s rows otherwise run on kernel_mixrad.h with the tables in LDS)
     for N in (257, 8191, 1046, 47):
         x = parity.seeded_complex(N * 2, False, N)
         h, ptr = run._alloc(x)
@@ -515,6 +517,7 @@ def test_one_kernel_cyclic_convolution_is_chosen(run, monkeypatch):
 def test_one_kernel_cyclic_convolution_columns(run, oracle, shape, dp, monkeypatch):
     """strided axes: tiles of neighbouring columns (Rader primes 37, 73, 257, 547, 1009; Bluestein on a smooth length for 47), partial tiles"""
     monkeypatch.setenv("VKFFT_MI355X_MIXCONV", "2")
+    monkeypatch.setenv("VKFFT_MI355X_MIXRAD_PRIMES", "0")  # (the instances of kernel_mixconv.h themselves: a prime\'s rows otherwise run on kernel_mixrad.h with the tables in LDS)
     parity.check_c2c(run, oracle, shape, 2, dp, kind="bluestein")
 
 

@@ -1068,6 +1068,7 @@ def test_every_cyclic_convolution_table_entry(run, oracle, chunk, monkeypatch):
     """kernel_mixconv.h: every ahead-of-time instance — Rader primes and Bluestein ladder lengths, rows and column tiles, fp32 and fp64 — against the
     oracle on a few sequences, then with the chip full against its own small-batch output (same input repeated)."""
     monkeypatch.setenv("VKFFT_MI355X_MIXCONV", "2")
+    monkeypatch.setenv("VKFFT_MI355X_MIXRAD_PRIMES", "0")  # (the instances of kernel_mixconv.h themselves: a prime\'s rows otherwise run on kernel_mixrad.h with the tables in LDS)
     for dp, rader, col, v in parity.mixconv_entries()[chunk::4]:
         N = parity.mixconv_length_for(rader, v)
         if N is None:

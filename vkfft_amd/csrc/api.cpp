@@ -106,6 +106,7 @@ static void describe_passes(const VkFFTPlan* pl, char* names, pfUINT cap, size_t
 		const char* nm = kname[q.kernel >= 0 && q.kernel < 14 ? q.kernel : 4];
 		if (q.kernel == KERNEL_POW2_FUSED) nm = pow2_fused_kernel_name(q.variant);       // (pow2_fused_kernel / _pipe_ / _pk_ / _pkh_)
 		else if (q.kernel == KERNEL_POW2_ROW) nm = pow2_row_kernel_name(q.variant);      // (pow2_row_kernel / pow2_row_lean_kernel / pow2_row_lean_pk_kernel)
+		else if (q.kernel == KERNEL_MIXCONV && q.prm.raderM) nm = "mixrad_kernel";        // (kernel_mixrad.h)
 		int w = snprintf(names + pos, pos < cap ? (size_t)cap - pos : 0, "%s%s<%s>", pos ? "," : "", nm, q.dp ? "double" : "float");
 		if (w > 0) pos = std::min<size_t>(pos + (size_t)w, (size_t)cap - 1);
 	}
@@ -516,9 +517,13 @@ VkFFTResult initialize_convolution(VkFFTApplication* app, const VkFFTConfigurati
 	c = in;
 	c.matrixConvolution = m; c.numberKernels = nk; c.numberBatches = nb;
 	c.coordinateFeatures = m > 1 ? m : (in.coordinateFeatures ? in.coordinateFeatures : 1); // reference: vkFFT_InitializeApp.h:1374
-	c.reorderFourStep = 0;
+	// (as for plain applications, setConfigurationVkFFT: the flag is reported back as not applied — and the notice is printed once, not by the sub-applications too)
+	if (in.disableReorderFourStep && (in.printMemoryLayout || getenv("VKFFT_MI355X_PRINT_PLAN")))
+		fprintf(stderr, "[vkfft_mi355x] disableReorderFourStep requested: not applied, results stay in natural order (app->configuration.disableReorderFourStep reads back 0)\n");
+	c.reorderFourStep = 1; c.disableReorderFourStep = 0;
 	app->actualNumBatches = nb;
 	VkFFTConfiguration f = in, b = in;
+	f.disableReorderFourStep = 0;
 	f.performConvolution = 0; f.matrixConvolution = 0; f.numberKernels = 0; f.symmetricKernel = 0; f.conjugateConvolution = 0; f.crossPowerSpectrumNormalization = 0;
 	f.kernel = nullptr; f.kernelSize = nullptr; f.kernelNum = 0;
 	f.coordinateFeatures = c.coordinateFeatures;

@@ -167,7 +167,7 @@ struct PassParams {
 	uint32_t padInL, padInN, padOutL, padOutN;
 	uint32_t colMerge;   // mixconv_kernel column tiles: the tile index runs over dim[0] x dim[1] (column g of a tile = (g % dim[0].count, g / dim[0].count)): no partly
 	                     // filled tiles when dim[0].count is not a multiple of the tile width (prime planes); tilesPerG0 then counts the tiles of both
-	uint32_t raderM;     // mixrad_kernel (kernel_mixrad.h): cofactor M of a row of M * P points, P the Rader prime of the instance (0 / 1: not that kernel)
+	uint32_t raderM;     // mixrad_kernel (kernel_mixrad.h): cofactor M of a row of M * P points, P the Rader prime of the instance (0: not that kernel; 1: the prime's own rows)
 	uint32_t raderA;     // ... its split M = raderA * B into the two column steps (1: one step; 0: M = P, the column transform is the prime's own convolution)
 	uint32_t pairRows;   // instance kernels between the generic maps (OPS = 1): two real rows per complex transform (kernel_generic.h ops_rows_in / ops_rows_out)
 	// table-driven maps of the real transforms (kernel_tmaps.h): per FFT input position / per spectrum index { byte offsets o1, o2 } and { complex c1, c2 };

@@ -15,7 +15,8 @@
 //      lanes along k2 (consecutive LDS addresses).  The twiddle W_N^(b k2) rides on the first step's loads as a product of two table entries (b k2 < N:
 //      high and low six bits).  Step two stores to memory (B runs of P points per butterfly) or, for the real transforms, back in place, from where the
 //      table-driven post-map takes natural index n at buffer (k1 mod A) * B + k1 / A, offset k2.
-// One instance per prime (the Rader row instances of the mixconv tables): the cofactor and its split are run-time parameters.
+// One instance per prime (the Rader row instances of the mixconv tables): the cofactor and its split are run-time parameters.  M = 1 — a row of P points — runs here
+// too (no column step: VKFFT_MI355X_MIXRAD_PRIMES=1; measured slower than kernel_mixconv.h, which stays the default for a prime's own rows).
 // P * P (1369 = 37 * 37, 3721 = 61 * 61): the column transform is the same prime — the same convolution, its thread groups along the columns (element pitch SP).
 #pragma once
 #include "engine.h"
@@ -193,6 +194,10 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	cx<T>* const sTwHi = sTwLo + 64;
 	cx<T>* const sWM = sTwHi + NH;
 	uint16_t* const sGp = (uint16_t*)(sWM + M);
+	FastDiv divN, divM;
+	divN.d = N; divN.rcp = 1.0f / (float)N; divM.d = M; divM.rcp = 1.0f / (float)M;
+	// (one workgroup per tile.  A persistent form — the tables loaded once per workgroup, tiles blockIdx.x, + gridDim.x, ... — was built and measured: the tile loop
+	// keeps its invariants live, 84-88 -> 128-136 VGPRs, and 3232-point rows fell from 2.44 to 1.74 TB/s; profiles/r06_rader_stage_persistent_form_*.jsonl)
 	uint32_t wg = p.reverseTiles ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
 	const uint32_t tile = wg % p.tilesPerG0;
 	wg /= p.tilesPerG0;
@@ -203,10 +208,31 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	const uint32_t rowsHere = (realRowsHere + rowMult - 1u) / rowMult; // complex rows of the tile
 	const int64_t rowIn0 = (int64_t)g1 * p.dim[1].inStride + (int64_t)g2 * p.dim[2].inStride + (int64_t)f0 * p.dim[0].inStride;
 	const int64_t rowOut0 = (int64_t)g1 * p.dim[1].outStride + (int64_t)g2 * p.dim[2].outStride + (int64_t)f0 * p.dim[0].outStride;
-	FastDiv divN, divM;
-	divN.d = N; divN.rcp = 1.0f / (float)N; divM.d = M; divM.rcp = 1.0f / (float)M;
-	// ---- 1. rows -> buffers (element M a + b of row r = element a of buffer r * M + b), tables -> LDS: one trip to memory for both
+	// ---- 1. tables -> LDS, rows -> buffers (element M a + b of row r = element a of buffer r * M + b).  Every table entry of a thread and its first eight row
+	// elements are REQUESTED before anything is written to LDS: one trip to memory for the tables and most of the tile (a loop that loads, waits and stores per
+	// table and per batch of four cost six trips in a row per workgroup — half the lifetime of a workgroup on 3232-point rows)
+	constexpr int KL = (LUTN + NT - 1) / NT, KT = (L + 64 + 64 + 128 + NT - 1) / NT, KG = (2 * L + NT - 1) / NT; // (NH <= 64, M <= 110)
+	cx<T> tl[KL > 0 ? KL : 1], tt[KT]; uint32_t tg[KG];
+	const uint32_t ntab = (uint32_t)L + 64u + NH + M; // (sBh, sTwLo, sTwHi, sWM are one run)
+	{
+		const GBuf glut = make_gbuf(p.lut), gtab = make_gbuf(ops ? p.aux3 : p.aux2), ggp = make_gbuf(p.rader);
+#pragma unroll
+		for (int k = 0; k < KL; k++) { const uint32_t i = tid + (uint32_t)(k * NT); tl[k] = gb_load<T>(glut, i < (uint32_t)LUTN ? i * ES : kGbInvalid, 0); }
+#pragma unroll
+		for (int k = 0; k < KT; k++) { const uint32_t i = tid + (uint32_t)(k * NT); tt[k] = gb_load<T>(gtab, i < ntab ? i * ES : kGbInvalid, 0); }
+#pragma unroll
+		for (int k = 0; k < KG; k++) { const uint32_t i = tid + (uint32_t)(k * NT); tg[k] = tm_load_u1(ggp, i < 2u * (uint32_t)L ? i * 4u : kGbInvalid, 0u); }
+	}
+	auto tables_to_lds = [&]() {
+#pragma unroll
+		for (int k = 0; k < KL; k++) { const uint32_t i = tid + (uint32_t)(k * NT); if (i < (uint32_t)LUTN) sLut[i] = tl[k]; }
+#pragma unroll
+		for (int k = 0; k < KT; k++) { const uint32_t i = tid + (uint32_t)(k * NT); if (i < ntab) sBh[i] = tt[k]; }
+#pragma unroll
+		for (int k = 0; k < KG; k++) { const uint32_t i = tid + (uint32_t)(k * NT); if (i < 2u * (uint32_t)L) sGp[i] = (uint16_t)tg[k]; }
+	};
 	if (ops) {
+		tables_to_lds();
 		const GBuf gdi = make_gbuf((const char*)p.in + rowIn0 * (int64_t)p.inElemBytes);
 		const uint32_t pitch = (uint32_t)p.dim[0].inStride * p.inElemBytes;
 		auto put = [&](uint32_t r, uint32_t pos, cx<T> z) { uint32_t a, b; divM.divmod(pos, a, b); bufs[(r * M + b) * (uint32_t)SP + a] = z; };
@@ -216,9 +242,9 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 		const GBuf gin = make_gbuf((const cx<T>*)p.in + rowIn0);
 		const bool swI = p.bluesteinSwapIn != 0;
 		const uint32_t inRowBytes = (uint32_t)p.dim[0].inStride * ES;
-		constexpr int U = 4; // elements requested together
+		constexpr int U = 8; // elements requested together
 		const uint32_t total = rowsHere * N;
-		for (uint32_t e0 = tid; e0 < total; e0 += (uint32_t)(U * NT)) {
+		for (uint32_t e0 = tid; e0 < total || e0 == tid; e0 += (uint32_t)(U * NT)) {
 			cx<T> v[U]; uint32_t dst[U];
 #pragma unroll
 			for (int u = 0; u < U; u++) {
@@ -229,18 +255,10 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 				v[u] = gb_load<T>(gin, e < total ? r * inRowBytes + n * ES : kGbInvalid, 0);
 				dst[u] = (r * M + b) * (uint32_t)SP + a;
 			}
+			if (e0 == tid) tables_to_lds(); // (first trip: the tables were requested ahead of these elements and land first)
 #pragma unroll
 			for (int u = 0; u < U; u++) if (e0 + (uint32_t)(u * NT) < total) bufs[dst[u]] = swI ? cswap(v[u]) : v[u];
 		}
-	}
-	{
-		const cx<T>* const glut = (const cx<T>*)p.lut;
-		for (uint32_t i = tid; i < (uint32_t)LUTN; i += (uint32_t)NT) sLut[i] = glut[i];
-		const cx<T>* const gtab = (const cx<T>*)(ops ? p.aux3 : p.aux2);
-		const uint32_t ntab = (uint32_t)L + 64u + NH + M; // (sBh, sTwLo, sTwHi, sWM are one run)
-		for (uint32_t i = tid; i < ntab; i += (uint32_t)NT) sBh[i] = gtab[i];
-		const uint32_t* const gp = (const uint32_t*)p.rader;
-		for (uint32_t i = tid; i < 2u * (uint32_t)L; i += (uint32_t)NT) sGp[i] = (uint16_t)gp[i];
 	}
 	VKFFT_SYNC();
 	// ---- 2. Rader convolution of every buffer, in place (the flow of mixconv_kernel<RADER = 1>)
@@ -301,7 +319,7 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	const GBuf gout = make_gbuf((cx<T>*)p.out + rowOut0);
 	const uint32_t outRowBytes = (uint32_t)p.dim[0].outStride * ES;
 	const uint32_t Ae = A ? A : 1u; // (M = P: one "step" of M, already done)
-	if (SQ && !ops) { // the rows leave in natural order: one contiguous run per row
+	if ((SQ || M == 1u) && !ops) { // (P * P, and M = 1: a row of P points) the rows leave in natural order: one contiguous run per row
 		const uint32_t total = rowsHere * N;
 		for (uint32_t e = tid; e < total; e += (uint32_t)NT) {
 			uint32_t r, n;
@@ -320,7 +338,7 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 #undef VKFFT_MIXRAD_CASE
 		VKFFT_SYNC();
 	}
-	if constexpr (!SQ) {
+	if (!SQ && M > 1u) {
 		auto store = [&](uint32_t r, uint32_t o, uint32_t k2, uint32_t k, cx<T> v) {
 			if (ops) { bufs2[(r * M + o * B + k) * (uint32_t)SP + k2] = v; return; }
 			if (swO) v = cswap(v);
@@ -356,9 +374,11 @@ template <typename T, typename SCH, int TPF, int FPW> void mixrad_launch(const P
 	using G = MixradGeom<T, SCH, TPF>;
 	const bool ops = prm.preOp != OP_NONE || prm.postOp != OP_NONE;
 	const size_t lds = (size_t)mixrad_lds_bytes((uint32_t)G::P, (uint32_t)G::SP, (uint32_t)G::LUTN, prm.raderM, prm.T, (uint32_t)sizeof(cx<T>), ops && mixrad_two_sets(prm.raderM, prm.raderA));
-	if (prm.raderA == 0u) {
-		if constexpr (G::P * G::P <= (int)kMixradLongest) hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, true>), grid, dim3(TPF * FPW), lds, s, prm);
-	} else hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, false>), grid, dim3(TPF * FPW), lds, s, prm);
+	const bool sq = prm.raderA == 0u;
+	const dim3 g = grid;
+	if (sq) {
+		if constexpr (G::P * G::P <= (int)kMixradLongest) hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, true>), g, dim3(TPF * FPW), lds, s, prm);
+	} else hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, false>), g, dim3(TPF * FPW), lds, s, prm);
 }
 // the composite form exists for the Rader ROW instances whose prime leaves room for a cofactor (2 P <= the longest row)
 template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> constexpr auto mixrad_ptr() -> void (*)(const PassParams&, dim3, hipStream_t) {

@@ -164,7 +164,7 @@ int launch_mixconv(const PassPlan& pp, const PassParams& prm, hipStream_t stream
 	const MixConvVariant* tab = mixconv_part((pp.variant >> 16) % kMixConvParts, &cnt);
 	const int idx = pp.variant & 0xffff;
 	if (grid64 > 0x7fffffffull || pp.variant < 0 || idx >= cnt) return 4039;
-	if (prm.raderM > 1) { // the prime as a stage of the composite length raderM * P (kernel_mixrad.h)
+	if (prm.raderM >= 1) { // the prime as a stage of the composite length raderM * P (kernel_mixrad.h; 1: the prime's own rows)
 		if (!tab[idx].launchRad) return 4039;
 		tab[idx].launchRad(prm, dim3((uint32_t)grid64), stream);
 		return hipGetLastError() == hipSuccess ? 0 : 4039;

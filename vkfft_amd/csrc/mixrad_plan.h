@@ -35,7 +35,7 @@ __host__ __device__ constexpr bool mixrad_split(uint32_t M, uint32_t& A, uint32_
 // cofactor (M), and the two generator permutations as 16-bit indices
 __host__ __device__ constexpr uint32_t mixrad_table_elems(uint32_t P, uint32_t M, uint32_t lutN) { return lutN + (P - 1u) + 64u + (M * P + 63u) / 64u + M; }
 // (two sets of buffers: a real transform whose last column step is a direct sum — that step may not write over its inputs, and the post-map reads LDS)
-__host__ __device__ constexpr bool mixrad_two_sets(uint32_t M, uint32_t A) { return A != 0u && !mixrad_radix_reg(M / A); }
+__host__ __device__ constexpr bool mixrad_two_sets(uint32_t M, uint32_t A) { return M > 1u && A != 0u && !mixrad_radix_reg(M / A); }
 __host__ __device__ constexpr uint64_t mixrad_lds_bytes(uint32_t P, uint32_t SP, uint32_t lutN, uint32_t M, uint32_t R, uint32_t elemBytes, bool twoSets) {
 	return ((uint64_t)(R * M) * SP * (twoSets ? 2u : 1u) + mixrad_table_elems(P, M, lutN)) * elemBytes + ((2u * (P - 1u) * 2u + 15u) & ~15u);
 }

@@ -188,15 +188,18 @@ static void make_mixrad_tables(uint64_t P, uint64_t M, bool dp, Arena& ar, size_
 // that splits into the kernel's column radices (mixrad_plan.h).  VKFFT_MI355X_MIXRAD=0: off; VKFFT_MI355X_MIXRAD_LDS_KIB: the LDS budget of a tile (tuning)
 struct MixradChoice { uint64_t P = 0, M = 0, len = 0; uint32_t A = 0, rows = 0; int variant = -1, rad[5] = {1, 1, 1, 1, 1}, fpw = 0, threads = 0; double cost = 2.0; };
 static bool mixrad_choose(uint64_t L, bool dp, bool ops, MixradChoice& c) { // ops: a real transform between the table-driven maps
-	if (dp || L < 74 || L > kMixradLongest) return false;
+	if (dp || L < 37 || L > kMixradLongest) return false;
 	if (getenv("VKFFT_MI355X_MIXRAD") && atoi(getenv("VKFFT_MI355X_MIXRAD")) == 0) return false;
 	uint64_t P = 0, rest = L;
 	for (uint64_t q = 2; q * q <= rest; q++) while (rest % q == 0) { P = q; rest /= q; }
 	if (rest > 1) P = rest; // largest prime factor
-	if (P < 37 || P == L) return false;
+	if (P < 37) return false;
 	const uint64_t M = L / P;
-	uint32_t A = 0, B = 0;
-	if (M == P) A = 0; // P * P: the column transform is the prime's own convolution (kernel_mixrad.h, 2b)
+	uint32_t A = 0, B = 1;
+	if (M == 1) { // a prime's own rows: no column step (VKFFT_MI355X_MIXRAD_PRIMES=1; default: kernel_mixconv.h)
+		if (!(getenv("VKFFT_MI355X_MIXRAD_PRIMES") && atoi(getenv("VKFFT_MI355X_MIXRAD_PRIMES")) == 1)) return false; // (off by default: measured slower than kernel_mixconv.h)
+		A = 1;
+	} else if (M == P) A = 0; // P * P: the column transform is the prime's own convolution (kernel_mixrad.h, 2b)
 	else if (!mixrad_split((uint32_t)M, A, B)) return false;
 	uint64_t len; int sp = 0, lutn = 0;
 	if (!mixconv_lookup(true, false, P, dp, &c.variant, &len, c.rad, &c.fpw, &c.threads) || !mixrad_geom(c.variant, &sp, &lutn)) return false;
@@ -209,7 +212,7 @@ static bool mixrad_choose(uint64_t L, bool dp, bool ops, MixradChoice& c) { // o
 	// forced either way): 1.2-2.2 with register column steps; a direct last step of radix B adds (B / 33)^2.2 (23: 2.4, 29: 2.5, 37: 3.4, 49: 4.3); primes whose
 	// own convolution has a radix-13 stage (131, 157, 313: 2.2-3.2) one more, 521 and up (three stages, 138 registers: 3.9) two
 	c.cost = 1.9;
-	if (A != 0 && !mixrad_radix_reg(B)) c.cost += std::pow((double)B / 33.0, 2.2);
+	if (M > 1 && A != 0 && !mixrad_radix_reg(B)) c.cost += std::pow((double)B / 33.0, 2.2);
 	if ((P - 1) % 13 == 0) c.cost += P >= 500 ? 2.0 : 1.0;
 	return true;
 }
@@ -232,6 +235,7 @@ static bool pairable_family(uint32_t pre, uint32_t post, uint64_t cplxLen, uint3
 // Families: R2C (post) / C2R (pre) in their full-length forms; DCT / DST-I, -II, -III in their full-length forms; DCT / DST-IV of odd length (same-length form)
 // and of even length (half-length complex form).  All but the last carry two rows per transform.
 constexpr uint32_t kTmNoTerm = 0x7FFFFFF8u; // = kGbInvalid (memops.h): a byte offset no buffer access reaches
+static_assert((kTmNoTerm & 1u) == 0u && kTmNoTerm >= 0x7FFFFFF0u, "bit 0 of an offset carries the sign of the second term (set_pre2); the value must lie beyond the range of a buffer resource (memops.h kGbRange)");
 enum TmFamily { TM_NONE = 0, TM_R2C, TM_C2R, TM_R2R2, TM_R2R3, TM_DCT1, TM_DST1, TM_R2R4_ODD, TM_R2R4_EVEN };
 static TmFamily tm_family(uint32_t pre, uint32_t post, uint64_t Lc, uint32_t N) {
 	auto fam = [&](uint32_t a, uint32_t c) { return pre == a && post == c; };
@@ -248,8 +252,8 @@ static TmFamily tm_family(uint32_t pre, uint32_t post, uint64_t Lc, uint32_t N) 
 	}
 	return TM_NONE;
 }
-// threads per row from which the table-driven maps replace the generic ones (measured, profiles/r05_real_rows_table_maps_ab.jsonl: from four threads per row on they
-// win — 91 reals (7 threads) 0.30 -> 0.19 ms, DCT-IV of 65 (5 threads) 0.44 -> 0.22; one thread per row, whose lanes are whole rows apart, loses: 31 reals 0.45 -> 0.77)
+// threads per row from which the table-driven maps replace the generic ones: 1 — since the staging tile of round 5 (rows with fewer than eight threads move as one
+// contiguous run through LDS, kernel_mixed.h) the tables win at every shape measured (31 reals, one thread per row: 0.45 -> 0.19 ms); the switch stays for A/B runs
 static int tmaps_min_tpf() { return getenv("VKFFT_MI355X_TMAPS_MIN_TPF") ? atoi(getenv("VKFFT_MI355X_TMAPS_MIN_TPF")) : 1; }
 static bool tm_family_pairs(TmFamily f) { return f != TM_NONE && f != TM_R2R4_EVEN; }
 struct TmTable {
@@ -1800,6 +1804,17 @@ static int plan_real_by_maps(const TransformDesc& d, const RealMapJob& m, Arena&
 // maps of the paired form are a signed gather and the even / odd split, those of the half-length forms carry a twiddle per point and go through the generic
 // maps.  Where an instance transform of the full length exists with eight or more threads per row, and (mode 1) the half-length form has no fused-map kernel.
 // VKFFT_MI355X_EVEN_FULL = 0 off, 1 (default), 2 also over a fused-map kernel.
+// rows that can travel in pairs: the extent of the tiled dimension after finish_pass has merged the contiguous batch dimensions into it (the pairs are formed inside
+// dims[0] only: a row count of 1 there — non-collapsible outer dimensions — would carry ONE real row per full-length transform, twice the work of the half-length form)
+static uint64_t pairable_rows(const std::vector<HostDim>& others) {
+	if (others.empty()) return 1;
+	uint64_t c = others[0].count;
+	for (size_t i = 1; i < others.size(); i++) {
+		if (others[i].count > 1 && ((int64_t)c * others[0].inStride != others[i].inStride || (int64_t)c * others[0].outStride != others[i].outStride)) break;
+		c *= others[i].count;
+	}
+	return c;
+}
 static bool prefer_full_length_pairs(const TransformDesc& d, uint64_t N, bool unit, uint64_t rows, uint32_t preHalf, uint32_t postHalf, uint64_t halfLen) {
 	const int mode = getenv("VKFFT_MI355X_EVEN_FULL") ? atoi(getenv("VKFFT_MI355X_EVEN_FULL")) : 1;
 	if (!mode || d.disableFastKernels || !unit || rows < 2 || getenv("VKFFT_MI355X_NO_TMAPS") || getenv("VKFFT_MI355X_NO_ROW_PAIRS") || getenv("VKFFT_MI355X_NO_MIXED_OPS")) return false;
@@ -1857,7 +1872,7 @@ static int plan_r2c_axis0_fused(const TransformDesc& d, bool inverse, const std:
 	b.opN = (uint32_t)N; b.scale = scale;
 	bool even = (N % 2 == 0);
 	{
-		uint64_t rows = 1; for (auto& o : othersReal) rows *= o.count;
+		const uint64_t rows = std::min(pairable_rows(othersReal), pairable_rows(othersCplx));
 		if (even && N >= 4 && !padReal && prefer_full_length_pairs(d, N, true, rows, inverse ? OP_C2R_EVEN_PRE : OP_NONE, inverse ? OP_NONE : OP_R2C_EVEN_POST, N / 2)) even = false;
 	}
 	b.L = even ? N / 2 : N;
@@ -2074,7 +2089,7 @@ static int plan_r2r_axis_fused(const TransformDesc& d, int type, bool dst, uint6
 		else { b.L = 2 * N + 2; b.preOp = OP_DST1_PRE; b.postOp = OP_DST1_POST; }
 		break;
 	case 2: case 3: if (N % 2 == 0 && N >= 4 && ![&]() {
-			uint64_t rows = 1; for (auto& o : others) rows *= o.count;
+			const uint64_t rows = pairable_rows(others);
 			const uint32_t ph = type == 2 ? (dst ? OP_DST2H_PRE : OP_DCT2H_PRE) : (dst ? OP_DST3H_PRE : OP_DCT3H_PRE), qh = type == 2 ? (dst ? OP_DST2H_POST : OP_DCT2H_POST) : (dst ? OP_DST3H_POST : OP_DCT3H_POST);
 			return prefer_full_length_pairs(d, N, unit, rows, ph, qh, N / 2);
 		}()) {
