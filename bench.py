@@ -241,7 +241,8 @@ def main():
                    unit="GFLOP/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload="batched 1D C2C fp32 in-place, N=2^8..2^22, batch=2^27/N (1 GiB per GPU), FFT+iFFT pair per size per step (sample-0 protocol)",
-                               sizes_log2=[KMIN, KMAX], buffer_bytes_per_gpu=8 << TOTAL_LOG2, parallelism=f"batch-sharded x{world}, no collectives"),
+                               sizes_log2=[KMIN, KMAX], buffer_bytes_per_gpu=8 << TOTAL_LOG2, parallelism=f"batch-sharded x{world}, no collectives",
+                               source_hash=api.source_hash(), library_newer_than_sources=bool(api.library_is_current())),
                    alg_GBps=round(bytes_step / (ms_per_step * 1e-3) / 1e9, 1),
                    roundtrip_rel_l2=float(f"{roundtrip_rel_l2:.3e}"), max_abs_err=float(f"{max_abs_err:.3e}"), roundtrip_limit_rel_l2=float(f"{rt_limit:.3e}"),
                    roundtrip_pairs=pairs, per_size=per_size, roofline=roofline, cpu_baseline=cpu)

@@ -59,6 +59,14 @@ CASES = [
     dict(name="c2c_15319_f32", kind=0, shape=(15319,), batch=1, dp=0, inverse=0),
     dict(name="c2c_12x10x8_f64", kind=0, shape=(12, 10, 8), batch=1, dp=1, inverse=0),
     dict(name="c2c_2p14_f64", kind=0, shape=(1 << 14,), batch=1, dp=1, inverse=0),
+    # round 6: the Rader-stage composites of the rewritten kernel_mixrad.h — a direct column step of radix 29 (2813 = 29 * 97), P * P (1369 = 37 * 37), two register
+    # steps (3232 = 4 * 8 * 101), a real row on the kernel (R2C of 355 = 5 * 71 reals, DCT-II of 328 = 8 * 41), and the DCT-IV of 1451 reals of BASELINE config 4
+    dict(name="c2c_2813_f32", kind=0, shape=(2813,), batch=2, dp=0, inverse=0),
+    dict(name="c2c_1369_f32_inv", kind=0, shape=(1369,), batch=2, dp=0, inverse=1),
+    dict(name="c2c_3232_f32", kind=0, shape=(3232,), batch=1, dp=0, inverse=0),
+    dict(name="r2c_355_f32", kind=1, shape=(355,), batch=3, dp=0, inverse=0),
+    dict(name="dct2_328_f32", kind=12, shape=(328,), batch=2, dp=0, inverse=0),
+    dict(name="dct4_1451_f32", kind=14, shape=(1451,), batch=2, dp=0, inverse=0),
 ]
 
 

@@ -1,82 +1,87 @@
 #!/usr/bin/env python3
-"""Rewrites the "## Round 3" section of profiles/README.md from the tracked round-3 evidence files (tables of this library next to the reference).
-The sections of earlier rounds stay as they were written."""
-import json, os, statistics, glob
+"""Rewrites the "## Round <n>" section of profiles/README.md from the tracked evidence files of that round (ONE generator; rounds 1-5 had one script each, their
+sections stay in the README as written).  usage: python tools/gen_profiles_readme.py r06 [previous round tag, default: the one before]
+Refuses to run when the bench line, the kernel stats and the PMC summary were not taken on the same sources; the reference column comes ONLY from
+`<tag>_reference_pow2_same_lease.jsonl` (the reference's own sweep run in the same gpurun call as the bench line: the boxes of the pool differ by 3-4 %).  The traffic of
+the roofline's instance is read from the PMC summary (`by_log2N`), not from the bench line (which may have been written before the counters existed)."""
+import collections, glob, json, math, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-s = open(os.path.join(P, "README.md")).read()
-if "## Round 3" in s:
-    s = s[:s.index("## Round 3")]
-s = s.rstrip("\n") + "\n\n"
-d = json.load(open(os.path.join(P, "r03_bench.json")))
-d2 = json.load(open(os.path.join(P, "r02_bench.json")))
-ps, ps2 = d["per_size"], d2["per_size"]
-ref = {8: 5437, 9: 5758, 10: 5512, 11: 5572, 12: 5358, 13: 5248, 14: 4477, 15: 2439, 16: 2500, 17: 2475, 18: 2388, 19: 2209, 20: 1568, 21: 1621, 22: 1494}
-rows = "".join(f"| {k} | {ref[k]} | {round(ps2[str(k)]['alg_GBps'])} | {round(ps[str(k)]['alg_GBps'])} | {round(ps[str(k)]['fwd_only_alg_GBps'])} | {ps[str(k)]['alg_GBps'] / ref[k]:.2f} |\n" for k in range(8, 23))
-kn = {0: "C2C", 1: "R2C", 11: "DCT-I", 12: "DCT-II", 13: "DCT-III", 14: "DCT-IV"}
-def table(items):
-    return "".join(f"| {kn[c['kind']]} | {'×'.join(map(str, c['shape']))} | {'fp64' if c['dp'] else 'fp32'} | {'+'.join(map(str, c['uploads']))} | {round(c['alg_GBps'])} | {round(c['ref_alg_GBps'])} | {c['alg_GBps'] / c['ref_alg_GBps']:.2f} |\n"
-                   for c in items if c.get("ref_alg_GBps"))
-def L(n):
-    f = os.path.join(P, f"r03_{n}_with_reference_same_call.jsonl")
-    return [json.loads(l) for l in open(f) if l.strip().startswith("{")] if os.path.exists(f) else []
-cfg, sm, s7, s1000 = L("config34"), L("samples_3_6_100"), L("sample7_prime_planes"), L("sample1000_sampling")
-g = lambda r: statistics.geometric_mean([x["alg_GBps"] / x["ref_alg_GBps"] for x in r if x.get("ref_alg_GBps")]) if r else float("nan")
-hdr = "| transform | shape | precision | passes | this library | reference | ratio |\n|---|---|---|---|---|---|---|\n"
-what = {
- "r03_bench.json": f"bench.py JSON line ({d['value'] / 1000:.2f} TFLOP/s, {d['ms_per_step']:.2f} ms/step; copy rate of that box {d['roofline']['copy_GBps_same_box'] / 1000:.2f} TB/s) | `python bench.py`",
- "r03_bench_kernel_stats.csv": "per-kernel time of the headline benchmark | `cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline`",
- "r03_config34_kernel_stats.csv": "per-kernel time of the configs-3/4 sweep (the new families included) | the same around `python tools/perf_configs.py`",
- "r03_pmc_traffic.json": "bytes per launch at the L2↔fabric boundary, keyed to the hash of the sources of the build (`source_hash`; bench.py reports `traffic` only when it matches) | `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (one pass each) `-- python tools/pmc_probe.py`, `tools/summarize_profiles.py r03 <dir>`",
- "r03_mall_evidence.jsonl": "HBM-level argument for the fused kernel, 2^16 … 2^22, queue count fixed per size: rings of 128 MiB … 1 GiB | `python tools/mall_evidence.py`",
- "r03_fused_gen1_per_phase_cycle_profile_2p15_to_2p22.txt": "per-phase cycle profile of the product fused kernel (development build) | `VKFFT_MI355X_LIB=build/libvkfft_mi355x_dev.so python tools/prof_fused.py 15 22`",
- "r03_probe_ring_trip_ceilings.jsonl": "what a ring trip costs with NO arithmetic, tickets or flags: 3.5–3.66 TB/s through the Infinity Cache whatever the structure; 4.7–6.1 through an XCD-private L2 ring | `build/probe_dma` (`tools/probe_dma.hip`)",
- "r03_probe_dma_lds_dma_semantics_and_column_streams.jsonl": "LDS-DMA (`buffer_load … lds`) semantics on gfx950 and column-tile stream rates (5.8–6.0 TB/s; 64-byte segments 2.6) | `build/probe_dma`",
- "r03_fused_gen2_dev_profile_2p16.jsonl, r03_fused_gen2_variants_2p16.jsonl, r03_fused_gen2b_*": "second-generation fused kernel (LDS-DMA double buffering; service-wave form; sliced DMA): bit-identical, not faster than generation 1 | `python tools/exp_fused2.py` on the development library",
- "r03_fused_gen1_small_xcd_local_ring_experiment.jsonl": "generation 1 with plain ring stores and rings of 2–6 MiB per XCD: 1.35–2.33 TB/s (dependency stalls) | `tools/exp_fused2.py`",
- "r03_fused_nt_hint_per_side.jsonl": "the non-temporal hint on both sides (product) / neither / loads only / stores only, 2^15 … 2^22: both is best everywhere | `VKFFT_MI355X_LIB=build/libvkfft_mi355x_dev.so python tools/ab_nt.py 15 22`",
- "r03_mixconv_rows_family_on_vs_off.jsonl, r03_mixconv_columns_family_on_vs_off.jsonl": "the Rader / smooth-Bluestein kernel family forced on vs off (the planner's cost factors come from these) | `python tools/tune_mixconv.py rows` / `cols`",
- "r03_all_lengths_2_320_with_reference_same_call.jsonl, r03_all_lengths_2_320_before_single_buffer_rows.jsonl": "1-D C2C of EVERY length 2 … 320 beside the reference (2^25 points): 0.99× after / 0.90× before the short rows shared one LDS buffer | `python tools/perf_all_short.py 2 320`",
- "r03_r2c_rows_4_400_with_reference_same_call.jsonl, r03_dct2_rows_4_400_with_reference_same_call.jsonl, r03_dct4_rows_5_400_with_reference_same_call.jsonl, r03_r2c_rows_4_400_before_*, r03_dct2_rows_4_400_before_*": "real rows of arbitrary length beside the reference: R2C 0.44× (0.25× before the instance transform ran between the interpreter's maps), DCT-II 0.37× (0.22×), DCT-IV 0.40× | `python tools/perf_all_short.py 4 400 1 3` (12, 14: DCT-II, DCT-IV)",
- "r03_short_real_rows_fused_maps_vs_instance_between_maps.jsonl": "fused-map kernels vs the instance transform between the interpreter's maps on short real rows (the planner's threshold) | `python tools/tune_mixed_ops.py`",
- "r03_short_rows_with_reference_same_call.jsonl": "1-D rows of 4 … 128 points and small planes / cubes | `python tools/perf_small_rows.py`",
- "r03_planes_of_smooth_lengths_outside_the_curated_lists_with_reference_same_call.jsonl": "84², 168², 252², 84³ … C2C 0.94–1.09× after the plain column kernels got an instance for every 13-smooth length ≤ 1024; R2C / DCT planes of such lengths 0.4–0.8× (real rows between the generic maps, strided DCT axes on the interpreter) | `python tools/perf_odd_planes.py`",
- "r03_zero_padding_with_reference_same_call.jsonl": "zero-padded 3-D / 2-D systems, padded vs unpadded, reference in the same process | `python tools/perf_zeropad.py`",
- "r03_convolution_with_reference_same_call.jsonl": "convolution plans with the merged last axis, reference's merged kernels in the same process | `python tools/perf_conv.py`",
- "r03_multi_gpu_cxx_drivers_one_gpu_box.jsonl": "C++ drivers: 4 virtual ranks verified against a single-device plan, one rank over RCCL, batch sharding | `build/vkfft_mi355x_multi …`",
- "r03_cli_1024cube_one_gpu_64bit_column_kernel.txt": "1024³ C2C on ONE GPU after the 64-bit column kernel: 31.3 ms per forward+inverse (273 ms in round 2) | `build/vkfft_mi355x_cli -benchmark_vkfft -X 1024 -Y 1024 -Z 1024 -N 3`",
- "r03_gpu_suite.log": "tail of `pytest -m gpu` on the device | `python -m pytest tests -x -q -m gpu`",
- "r03_config34_with_reference_same_call.jsonl": f"configs 3/4, reference in the same process: geometric mean {g(cfg):.2f} | `python tools/perf_configs.py`",
- "r03_samples_3_6_100_with_reference_same_call.jsonl": f"samplings of the reference's multi-dimensional benchmark lists: geometric mean {g(sm):.2f} | `python tools/perf_samples.py`",
- "r03_sample7_prime_planes_with_reference_same_call.jsonl": f"the reference's sample 7 (prime planes and cubes): geometric mean {g(s7):.2f} (round 2: 0.75) | `python tools/perf_sample7.py`",
- "r03_sample1000_sampling_with_reference_same_call.jsonl": f"a sampling of the reference's sample 1000 (every length 2 … 4096): geometric mean {g(s1000):.2f} | `python tools/perf_sample1000.py 60`",
-}
-files = "".join(f"| `{k}` | {v.split(' | ')[0]} | {v.split(' | ')[1]} |\n" for k, v in what.items()
-                if any(os.path.exists(os.path.join(P, n.strip().replace('*', ''))) or glob.glob(os.path.join(P, n.strip())) for n in k.split(",")))
-new = f'''## Round 3
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
+prev = sys.argv[2] if len(sys.argv) > 2 else "r%02d" % (int(tag[1:3]) - 1)
+rnd = int(tag[1:3])
+def geo(v): return math.exp(sum(math.log(x) for x in v) / len(v))
+def jl(name): return [json.loads(l) for l in open(os.path.join(P, name)) if l.startswith("{")]
+out = ""
+# ---- the bench line, the reference in the same lease, kernel stats, PMC traffic
+if os.path.exists(f"{P}/{tag}_bench.json"):
+    d = json.load(open(f"{P}/{tag}_bench.json")); d0 = json.load(open(f"{P}/{prev}_bench.json"))
+    pmc = json.load(open(f"{P}/{tag}_pmc_traffic.json"))
+    ks_lines = open(f"{P}/{tag}_bench_kernel_stats.csv").read().splitlines()
+    ks_hash = re.search(r"sources ([0-9a-f]{16})", ks_lines[0]).group(1)
+    if ks_hash != pmc["source_hash"]:
+        sys.exit(f"kernel stats were taken on sources {ks_hash}, the PMC summary on {pmc['source_hash']}: re-collect both on one build")
+    ref = {r["log2N"]: r for r in jl(f"{tag}_reference_pow2_same_lease.jsonl")}
+    if sorted(ref) != list(range(8, 23)):
+        sys.exit(f"{tag}_reference_pow2_same_lease.jsonl does not hold the 15 sizes of the sweep")
+    ps, ps0 = d["per_size"], d0["per_size"]
+    rows = ""
+    for k in range(8, 23):
+        v = ps[str(k)]; by = pmc.get("by_log2N", {}).get(str(k), {})
+        rows += (f"| {k} | {round(ref[k]['alg_GBps'])} | {round(ps0[str(k)]['alg_GBps'])} | **{round(v['alg_GBps'])}** | {round(v['fwd_only_alg_GBps'])} | {v['alg_GBps'] / ref[k]['alg_GBps']:.2f} | "
+                 f"{v['alg_GBps'] / 8000:.2f} | `{v['kernel'].split('<')[0]}` | {by.get('fetch_bytes_corrected', 0) / 2**30:.3f} / {by.get('write_bytes', 0) / 2**30:.3f} |\n")
+    rl = d["roofline"]
+    inst = pmc.get("by_log2N", {}).get(str(rl["size_log2N"]), {})
+    ref_ms = sum(r["pair_ms"] for r in ref.values()); our_ms = sum(v["pair_ms"] for v in ps.values())
+    ks = [l.split('","')[0].strip('"') + " | " + l.rsplit('"', 1)[1] for l in ks_lines[2:8]]
+    out += f'''
+Files `{tag}_*`.  The bench line, the kernel stats and the PMC traffic are of ONE build (sources `{pmc['source_hash']}`, `vkfft_amd.api.source_hash()`), the reference's sweep
+(`oracle/_ref/vkfft_ref_bench 8 22 0`) was run in the SAME gpurun call as the bench line.  Bench line: **{d['value']/1000:.2f} TFLOP/s, {d['ms_per_step']:.2f} ms per step** (round {rnd - 1}: {d0['value']/1000:.2f} / {d0['ms_per_step']:.2f});
+copy rate of that box {rl['copy_GBps_same_box']/1000:.2f} TB/s (torch) / {(rl.get('copy_GBps_own_float4') or 0)/1000:.2f} TB/s (the library's own 16-byte-per-lane copy); after the timed loop the buffer equals its
+initial contents to {d['roundtrip_rel_l2']:.2e} relative L2 over {d['roundtrip_pairs']} transform pairs (limit {d['roundtrip_limit_rel_l2']:.1e}).  Sum of the 15 pair times: reference {ref_ms:.2f} ms, this library {our_ms:.2f} ms.
+`roofline`: `{rl['kernel']}` at 2^{rl['size_log2N']}, {rl['launch_ms']} ms per launch (HIP events), {rl['achieved']} GB/s algorithmic = {rl['frac']} of 8 TB/s; traffic of THAT instance (PMC summary, `by_log2N[{rl['size_log2N']}]`)
+{(inst.get('bytes_per_launch') or 0)/2**30:.3f} GiB per launch = {(inst.get('bytes_per_launch') or 0) / (2**31 / rl['launches_per_transform']) :.2f} x the algorithmic bytes.
 
-"reference in the same process" = the reference VkFFT-HIP (`oracle/_ref`, built by `oracle/build_ref.sh`) timed right after this library on the same shapes with the same
-protocol; ratios > 1 mean this library is faster.  (Regenerate this section with `tools/gen_profiles_readme.py`.)
-
-| file | what | command |
-|---|---|---|
-{files}
-Headline sweep, algorithmic GB/s of an FFT+iFFT pair (1 GiB); reference from round 1's table (same protocol, its own binary):
-
-| log2 N | reference VkFFT-HIP | round 2 | round 3 | round 3 forward-only | round 3 / reference |
-|---|---|---|---|---|---|
+| log2 N | reference, same lease (alg. GB/s, paired) | round {rnd - 1} | **round {rnd}** | round {rnd}, forward only | ratio to the reference | fraction of 8 TB/s | kernel | PMC fetch / write per launch (GiB; 1 GiB data) |
+|---|---|---|---|---|---|---|---|---|
 {rows}
-Configs 3/4 (`r03_config34_with_reference_same_call.jsonl`):
+Dominant kernels (rocprofv3 `--kernel-trace --stats`, `{tag}_bench_kernel_stats.csv`; name | calls, total ns, average ns, share):
+''' + "".join(f"* `{k[:110]}`\n" for k in ks)
+# ---- sampling of sample 1000
+f = glob.glob(f"{P}/{tag}_sample1000_*.jsonl")
+if f:
+    rows_ = [r for r in jl(os.path.basename(f[0])) if r.get("ref_pair_ms")]
+    q = sorted((r["ref_pair_ms"] / r["pair_ms"], r["shape"][0]) for r in rows_)
+    out += (f"\nSampling of the reference's sample 1000 (`{os.path.basename(f[0])}`, {len(q)} lengths 2 … 4096, reference in the same process): geometric mean **{geo([x[0] for x in q]):.3f}**, "
+            f"below 0.9 ×: {', '.join(f'{n} ({x:.2f})' for x, n in q if x < 0.9) or 'none'}; below 0.7 ×: {sum(1 for x, n in q if x < 0.7)}.\n")
+# ---- real rows
+rr = ""
+for fam, label in (("r2c", "R2C 4 … 400 (step 3)"), ("dct2", "DCT-II 4 … 400 (step 3)"), ("dct4", "DCT-IV 5 … 400 (step 5)")):
+    cur = sorted(glob.glob(f"{P}/{tag}_{fam}_rows_reference_every_length_*.jsonl")); old = glob.glob(f"{P}/{prev}_{fam}_rows_reference_every_length_final.jsonl")
+    if not cur: continue
+    def summ(fn):
+        rs = [(r["ref_ms"] / r["ms"], r["N"], r["kernel"]) for r in jl(os.path.basename(fn)) if r.get("ref_ms")]
+        by = collections.defaultdict(list)
+        for x, n, k in rs: by[k].append(x)
+        return rs, by
+    rs, by = summ(cur[-1]); o = geo([x[0] for x in summ(old[0])[0]]) if old else float("nan")
+    worst = min(rs)
+    rr += (f"| {label} | {len(rs)} | {o:.2f} | **{geo([x[0] for x in rs]):.2f}** | {sum(1 for x in rs if x[0] < 0.5)} | {worst[1]} ({worst[0]:.2f}) | "
+           + ", ".join(f"`{k}` {len(v)}: {geo(v):.2f}" for k, v in sorted(by.items())) + f" | `{os.path.basename(cur[-1])}` |\n")
+if rr:
+    out += f"""
+Real rows, geometric mean of (reference pair time ÷ our pair time), the reference timed in the same process on EVERY length (`tools/perf_real_sweep_r05.py`; 2^25 reals per launch):
 
-{hdr}{table(cfg)}
-Sample 7 (`r03_sample7_…jsonl`):
-
-{hdr}{table(s7)}
-Sample 1000, the sampled lengths (`r03_sample1000_…jsonl`):
-
-{hdr}{table(s1000)}
-Samplings of the reference's multi-dimensional benchmark lists (`r03_samples_3_6_100_…jsonl`):
-
-{hdr}{table(sm)}'''
-open(os.path.join(P, "README.md"), "w").write(s + new)
-print("profiles/README.md: round-3 section rewritten")
+| sweep | lengths | round {rnd - 1} | **round {rnd}** | lengths below 0.5 × | worst length | by kernel (count: geometric mean) | file |
+|---|---|---|---|---|---|---|---|
+{rr}"""
+# ---- every other file of the round: its first comment / note, by name
+notes = json.load(open(f"{P}/{tag}_files.json")) if os.path.exists(f"{P}/{tag}_files.json") else {}
+files = sorted(os.path.basename(x) for x in glob.glob(f"{P}/{tag}_*") if not x.endswith("_files.json"))
+out += "\n| file | what |\n|---|---|\n" + "".join(f"| `{n}` | {notes.get(n, '')} |\n" for n in files)
+s = open(f"{P}/README.md").read()
+head = f"## Round {rnd}"
+if head in s:
+    s = s[:s.index(head)]
+open(f"{P}/README.md", "w").write(s.rstrip("\n") + f"\n\n{head}\n" + out + "\n")
+print(f"profiles/README.md: round {rnd} section written ({len(files)} files)")

@@ -109,6 +109,18 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def library_is_current():
+    """True when the built library is at least as new as every kernel / planner source and generated table: `source_hash()` names the SOURCES a profile was taken
+    on, this says that the binary that ran was built from them (bench.py records both)."""
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    try:
+        so = os.path.getmtime(lib_path())
+    except OSError:
+        return False
+    newest = max(os.path.getmtime(os.path.join(d, n)) for n in os.listdir(d) if n.endswith((".h", ".hip", ".cpp", ".inc")))
+    return so >= newest
+
+
 def _bind(p):
     # torch ships its own copy of the HIP runtime: import it first so that this process ends up with ONE
     # libamdhip64 (the one torch's tensors live in) — device pointers are not shared between two runtimes.

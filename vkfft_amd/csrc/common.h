@@ -169,6 +169,7 @@ struct PassParams {
 	                     // filled tiles when dim[0].count is not a multiple of the tile width (prime planes); tilesPerG0 then counts the tiles of both
 	uint32_t raderM;     // mixrad_kernel (kernel_mixrad.h): cofactor M of a row of M * P points, P the Rader prime of the instance (0: not that kernel; 1: the prime's own rows)
 	uint32_t raderA;     // ... its split M = raderA * B into the two column steps (1: one step; 0: M = P, the column transform is the prime's own convolution)
+	uint32_t raderAligned; // ... 1: the thread groups of its convolution are laid out inside wavefronts (64 / TPF groups each, wave-level ordering); 0: densely (workgroup barriers)
 	uint32_t pairRows;   // instance kernels between the generic maps (OPS = 1): two real rows per complex transform (kernel_generic.h ops_rows_in / ops_rows_out)
 	// table-driven maps of the real transforms (kernel_tmaps.h): per FFT input position / per spectrum index { byte offsets o1, o2 } and { complex c1, c2 };
 	// flags: kTmOn | kTmTwo (second term of the pre-map is used) | kTmSplit | kTmRowB | kTmCplx (post-map forms).  0: the maps of kernel_generic.h

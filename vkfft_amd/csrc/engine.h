@@ -139,7 +139,7 @@ int launch_mixed(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 bool mixconv_lookup(bool rader, bool col, uint64_t pOrMinLen, bool dp, int* variant, uint64_t* len, int rad[5], int* fpw, int* threads);
 int launch_mixconv(const PassPlan& pp, const PassParams& prm, hipStream_t stream);
 bool mixrad_available(int variant); // the Rader row instance also exists as a stage of composite lengths (kernel_mixrad.h)
-bool mixrad_geom(int variant, int* sp, int* lutn); // ... its buffer pitch (elements) and stage-twiddle count
+bool mixrad_geom(int variant, int* sp, int* lutn, int* groups, int* groupsDense); // ... its buffer pitch (elements), stage-twiddle count and thread groups of the wave-aligned layout (0: not offered)
 // op-FFT family (kernel_opfft.h): pre/post are the DCT member of their family (DST variants share the instance)
 bool opfft_lookup(uint64_t n, bool dp, bool col, bool trans, uint32_t pre, uint32_t post, int* variant, int rad[5], int* fpw, int* threads); // trans: column tile in, transposed (per-column contiguous) store out
 int launch_opfft(const PassPlan& pp, const PassParams& prm, hipStream_t stream);

@@ -25,11 +25,19 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 	const uint32_t n = p.blueN; // embedding length (2N-2, 2N+2 or N); p.opN stays the real transform's N for the maps
 	// aux3 = chirp[0..n) followed by FFT(chirp)/M [0..M): aux and aux2 belong to the real transform's own maps
 	const GBuf glut = make_gbuf(p.lut), gch = make_gbuf(p.aux3), gbh = make_gbuf((const cx<T>*)p.aux3 + n);
+	// the chirp and the kernel spectrum of a thread's points are the same for every tile: kept in registers by the persistent workgroups — except in the two
+	// largest shapes (8192 / 16384 points: 512 / 1024 threads at 256 / 128 registers), where they were what spilled (up to 1 248 bytes of scratch per lane, round 5):
+	// there they are read again for every tile (L2 hits)
+	constexpr bool TABREG = TPF * FPW < 512;
 	cx<T> ch[EH], bh[E];
+	if constexpr (TABREG) {
 #pragma unroll
-	for (int m = 0; m < EH; m++) { const uint32_t pos = tau + m * TPF; ch[m] = gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0); }
+		for (int m = 0; m < EH; m++) { const uint32_t pos = tau + m * TPF; ch[m] = gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0); }
 #pragma unroll
-	for (int m = 0; m < E; m++) bh[m] = gb_load<T>(gbh, (tau + m * TPF) * ES, 0);
+		for (int m = 0; m < E; m++) bh[m] = gb_load<T>(gbh, (tau + m * TPF) * ES, 0);
+	}
+	auto chv = [&](int m) -> cx<T> { if constexpr (TABREG) return ch[m]; else { const uint32_t pos = tau + m * TPF; return gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0); } };
+	auto bhv = [&](int m) -> cx<T> { if constexpr (TABREG) return bh[m]; else return gb_load<T>(gbh, (tau + m * TPF) * ES, 0); };
 	const uint32_t tiles = p.tilesPerG0 * p.dim[1].count * p.dim[2].count;
 	for (uint32_t wgi = blockIdx.x; wgi < tiles; wgi += gridDim.x) {
 		uint32_t wg = p.reverseTiles ? tiles - 1u - wgi : wgi;
@@ -68,13 +76,13 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 				if (pair) { const cx<T> xb = pre_gather<T>(p, ioB, pos, nat, op_resolve<PRE>(p.preOp)); x = cx<T>{x.x - xb.y, x.y + xb.x}; }
 			}
 			if (p.swapIn) x = cswap(x);
-			v[m] = cmulc(x, ch[m]);
+			v[m] = cmulc(x, chv(m));
 		}
 #pragma unroll
 		for (int m = EH; m < E; m++) v[m] = cx<T>{(T)0, (T)0};
 		pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
 #pragma unroll
-		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], bh[m]));
+		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], bhv(m)));
 		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); } // the exchange buffer is reused
 		pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
 		const bool split = pair && !realResult;
@@ -82,7 +90,7 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 #pragma unroll
 		for (int m = 0; m < EH; m++) {
 			const uint32_t pos = tau + m * TPF;
-			cx<T> y = cmulc(cswap(v[m]), ch[m]);
+			cx<T> y = cmulc(cswap(v[m]), chv(m));
 			if (p.swapOut) y = cswap(y);
 			v[m] = y;
 			if (pos < n) {

@@ -189,7 +189,7 @@ struct MixConvVariant {
 	void (*launch)(const PassParams&, dim3, hipStream_t);
 	void (*launchOps)(const PassParams&, dim3, hipStream_t); // Rader rows: the form with the interpreter's pre / post maps (nullptr otherwise)
 	void (*launchRad)(const PassParams&, dim3, hipStream_t); // Rader rows: the prime as a stage of a composite length M * P (kernel_mixrad.h; nullptr otherwise)
-	int radSP, radLutN;                                       // ... its buffer pitch and stage-twiddle count (the planner sizes the tile's LDS with them)
+	int radSP, radLutN, radGroups, radGroupsDense;                         // ... its buffer pitch, stage-twiddle count and thread groups of the wave-aligned layout (0: none); the planner sizes the tile with them
 };
 template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL, int OPS> void mixconv_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
 	hipLaunchKernelGGL((mixconv_kernel<T, SCH, TPF, FPW, RADER, COL, OPS>), grid, dim3(TPF * FPW), 0, s, prm);
@@ -201,6 +201,6 @@ template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> conste
 #define VKFFT_MC(T, dp, rader, col, r0, r1, r2, r3, r4, tpf, fpw) \
 	{ (r0) * (r1) * (r2) * (r3) * (r4), dp, rader, col, {r0, r1, r2, r3, r4}, tpf, fpw, &mixconv_launch<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, rader, col, 0>, \
 	  mixconv_ops_ptr<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, rader, col>(), mixrad_ptr<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, rader, col>(), \
-	  mixrad_sp<T, MixSched<r0, r1, r2, r3, r4>, tpf, rader, col>(), mixrad_lutn<T, MixSched<r0, r1, r2, r3, r4>, tpf, rader, col>() },
+	  mixrad_sp<T, MixSched<r0, r1, r2, r3, r4>, tpf, rader, col>(), mixrad_lutn<T, MixSched<r0, r1, r2, r3, r4>, tpf, rader, col>(), mixrad_groups<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, rader, col>(), mixrad_groups_dense<T, MixSched<r0, r1, r2, r3, r4>, tpf, fpw, rader, col>() },
 
 } // namespace vkfft_mi355x

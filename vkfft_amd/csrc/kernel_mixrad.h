@@ -34,8 +34,22 @@ template <typename SCH> __host__ __device__ constexpr int mixrad_lut_elems() { /
 	for (int j = 1; j < SCH::NS; j++) n += (SCH::rad[j] - 1) * SCH::S(j);
 	return n;
 }
-template <typename T, typename SCH, int TPF> struct MixradGeom {
+template <typename T, typename SCH, int TPF, int FPW = 1> struct MixradGeom {
 	static constexpr int L = SCH::N, P = L + 1;
+	// Thread groups of the convolution (TPF threads each), two layouts chosen per plan (PassParams::raderAligned, planner.cpp mixrad_choose):
+	//   dense    — group f = threads [f TPF, (f + 1) TPF): FPW groups, the stages of the convolution behind workgroup barriers unless TPF divides 64;
+	//   aligned  — no group straddles two wavefronts (64 / TPF groups per wavefront, the last lanes idle): the stages order their LDS traffic inside the
+	//              wavefront, wavefronts run ahead of each other through the rounds (first version of round 6, dense only: 42 % of the wave cycles parked at
+	//              barriers and waits for TPF = 10, 11, 13, 14, 15, profiles/r06_rader_stage_sq_counters.txt; aligned 3144 = 24 * 131 1.80 -> 2.75 TB/s).
+	// The aligned layout has WAVES * (64 / TPF) groups — fewer than FPW for some primes (101: 30 instead of 32), which costs a second round where the cofactor was
+	// matched to FPW (3232 = 32 * 101: 2.35 -> 2.21 TB/s): hence the choice per plan.  Offered where whole groups fill four fifths of a wavefront or more.
+	static constexpr int GPW = TPF <= 64 ? 64 / TPF : 0;
+	// Whole wavefronts, rounded to the NEAREST count: 260 threads (13 x 20, 26 x 10) run as 256 — four wavefronts, five workgroups per CU at 86-94 registers — not as 320
+	// (3144 = 24 * 131 2.75 against 2.10 TB/s, 314 3.26 against 2.51); the dense layout then has one group less (19 of 20)
+	static constexpr int WAVES = (TPF * FPW + 32) / 64 > 0 ? (TPF * FPW + 32) / 64 : 1;
+	static constexpr int NT = WAVES * 64;                                   // threads of a workgroup
+	static constexpr int GROUPS_DENSE = NT / TPF < FPW ? NT / TPF : FPW;
+	static constexpr int GROUPS_ALIGNED = (TPF <= 64 && GPW * TPF * 5 >= 64 * 4) ? WAVES * GPW : 0;
 	static constexpr int EXPF = SCH::NS > 1 ? MixPad<SCH, TPF, (int)sizeof(cx<T>)>::elems() : 1;
 	static constexpr int SP = (EXPF > P ? EXPF : P) | 1; // buffer pitch: odd (consecutive buffers start on different banks)
 	static constexpr int LUTN = mixrad_lut_elems<SCH>();
@@ -134,22 +148,40 @@ __device__ inline void mixrad_col_step(const cx<T>* bufs, const uint32_t M, cons
 template <typename T, int P, int SP, int NT, bool FIRST, typename EMIT>
 __device__ inline void mixrad_col_direct(cx<T>* bufs, const uint32_t M, const uint32_t RAD, const uint32_t so, const uint32_t si, const uint32_t rowsHere, const cx<T>* twLo,
                                          const cx<T>* twHi, const cx<T>* wM, const uint32_t tid, const EMIT& emit) {
-	const uint32_t others = M / RAD, total = rowsHere * others * (uint32_t)P, wStep = M / RAD, H = (RAD - 1u) / 2u;
+	const uint32_t others = M / RAD, cols = rowsHere * others * (uint32_t)P, wStep = M / RAD, H = (RAD - 1u) / 2u, stride = si * (uint32_t)SP;
 	FastDiv divO; divO.d = others; divO.rcp = 1.0f / (float)others;
-	for (uint32_t j0 = tid; j0 < total; j0 += (uint32_t)NT) {
-		const uint32_t q = j0 / (uint32_t)P, k2 = j0 - q * (uint32_t)P;
+	if constexpr (FIRST) { // the twiddle W_N^(b k2) once, in place, over every element of the tile's columns (lanes along k2)
+		const uint32_t totalE = cols * RAD;
+		FastDiv divR; divR.d = RAD; divR.rcp = 1.0f / (float)RAD;
+		for (uint32_t e = tid; e < totalE; e += (uint32_t)NT) {
+			const uint32_t qq = e / (uint32_t)P, k2 = e - qq * (uint32_t)P;
+			uint32_t q, i, r, o;
+			divR.divmod(qq, q, i);
+			divO.divmod(q, r, o);
+			const uint32_t b = o * so + i * si;
+			if (b * k2 != 0u) { cx<T>* const x = bufs + (r * M + b) * (uint32_t)SP + k2; *x = cmul(*x, mixrad_tw<T>(twLo, twHi, b * k2)); }
+		}
+		VKFFT_SYNC();
+	}
+	// the pairs of outputs of a column are dealt over KC threads (29 * 97: one column per thread left 97 of 256 threads with a whole 29-point sum each)
+	uint32_t KC = (2u * (uint32_t)NT) / (cols ? cols : 1u);
+	KC = KC < 1u ? 1u : KC > H ? H : KC;
+	const uint32_t items = cols * KC;
+	FastDiv divC; divC.d = cols; divC.rcp = 1.0f / (float)cols;
+	for (uint32_t j0 = tid; j0 < items; j0 += (uint32_t)NT) {
+		uint32_t kc, c;
+		divC.divmod(j0, kc, c);
+		const uint32_t q = c / (uint32_t)P, k2 = c - q * (uint32_t)P;
 		uint32_t r, o;
 		divO.divmod(q, r, o);
-		const uint32_t b0 = o * so, stride = si * (uint32_t)SP;
-		cx<T>* const col = bufs + (r * M + b0) * (uint32_t)SP + k2;
-		if constexpr (FIRST) { // the twiddle W_N^(b k2) once, in place (the column is this thread's)
-			for (uint32_t i = (b0 ? 0u : 1u); i < RAD; i++) col[i * stride] = cmul(col[i * stride], mixrad_tw<T>(twLo, twHi, (b0 + i * si) * k2));
-		}
+		const cx<T>* const col = bufs + (r * M + o * so) * (uint32_t)SP + k2;
 		const cx<T> x0 = col[0];
-		cx<T> sum = x0;
-		for (uint32_t i = 1; i < RAD; i++) sum = cadd(sum, col[i * stride]);
-		emit(r, o, k2, 0u, sum);
-		for (uint32_t k = 1; k <= H; k++) {
+		if (kc == 0u) {
+			cx<T> sum = x0;
+			for (uint32_t i = 1; i < RAD; i++) sum = cadd(sum, col[i * stride]);
+			emit(r, o, k2, 0u, sum);
+		}
+		for (uint32_t k = 1u + kc; k <= H; k += KC) {
 			cx<T> a = x0, b = {(T)0, (T)0};
 			uint32_t m = 0;
 #pragma unroll 2
@@ -173,14 +205,20 @@ __device__ inline void mixrad_col_direct(cx<T>* bufs, const uint32_t M, const ui
 // SQ: the instance for M = P (rows of P * P points; only the primes up to 61 have one) — its column convolution costs registers that the other cofactors of the same
 // prime should not pay for (37-point instance: 84 -> 100 VGPRs)
 template <typename T, typename SCH, int TPF, int FPW, bool SQ>
-__global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
-	using G = MixradGeom<T, SCH, TPF>;
-	constexpr int L = G::L, P = G::P, NT = TPF * FPW, SP = G::SP, LUTN = G::LUTN;
-	constexpr bool waveOnly = (TPF <= 64) && (64 % TPF == 0);
+__global__ void __launch_bounds__((MixradGeom<T, SCH, TPF, FPW>::NT)) mixrad_kernel(const PassParams p) {
+	using G = MixradGeom<T, SCH, TPF, FPW>;
+	constexpr int L = G::L, P = G::P, NT = G::NT, SP = G::SP, LUTN = G::LUTN;
 	constexpr uint32_t ES = (uint32_t)sizeof(cx<T>);
 	VKFFT_DYN_SMEM(smem)
 	const uint32_t tid = threadIdx.x;
-	const uint32_t f = tid / TPF, tau = tid % TPF;
+	// thread group and place inside it (aligned: lanes beyond the last whole group of a wavefront belong to no group — they run along and write nothing; dense: the
+	// threads beyond TPF * FPW likewise)
+	const bool aligned = G::GROUPS_ALIGNED != 0 && p.raderAligned != 0;
+	const uint32_t lane = tid & 63u;
+	const uint32_t f = aligned ? (tid >> 6) * (uint32_t)G::GPW + lane / (uint32_t)TPF : tid / (uint32_t)TPF, tau = aligned ? lane % (uint32_t)TPF : tid % (uint32_t)TPF;
+	const bool inGroup = aligned ? lane < (uint32_t)(G::GPW * TPF) : tid < (uint32_t)(TPF * G::GROUPS_DENSE);
+	const uint32_t GROUPS = aligned ? (uint32_t)G::GROUPS_ALIGNED : (uint32_t)G::GROUPS_DENSE;
+	const bool waveOnly = aligned || 64 % TPF == 0;
 	const uint32_t M = p.raderM, A = p.raderA, B = A ? M / A : 1u, N = M * (uint32_t)P, R = p.T;
 	const uint32_t nbuf = R * M, NH = (N + 63u) / 64u;
 	cx<T>* const bufs = (cx<T>*)smem;
@@ -264,10 +302,10 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	// ---- 2. Rader convolution of every buffer, in place (the flow of mixconv_kernel<RADER = 1>)
 	auto fsync = [&]() { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); };
 	{
-		const uint32_t rounds = (nbuf + (uint32_t)FPW - 1u) / (uint32_t)FPW;
+		const uint32_t rounds = (nbuf + GROUPS - 1u) / GROUPS;
 		for (uint32_t rd = 0; rd < rounds; rd++) {
-			const uint32_t job = rd * (uint32_t)FPW + f;
-			const bool live = job < nbuf;
+			const uint32_t job = rd * GROUPS + f;
+			const bool live = inGroup && job < nbuf;
 			cx<T>* const row = bufs + (live ? job : 0u) * (uint32_t)SP;
 			const cx<T> x0 = row[0];
 			cx<T> dc = {(T)0, (T)0};
@@ -290,10 +328,10 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 	// ---- 2b. M = P (rows of P * P points): the transform along b is the same prime — the same convolution on the COLUMNS of the tile (element b of column k2 of row r
 	// at buffer r * M + b, offset k2: element pitch SP), the twiddle W_N^(b k2) on the gather.  Result k1 lands in buffer k1: natural index n at buffer n / P, offset n mod P
 	if constexpr (SQ) {
-		const uint32_t ncol = R * (uint32_t)P, rounds = (ncol + (uint32_t)FPW - 1u) / (uint32_t)FPW;
+		const uint32_t ncol = R * (uint32_t)P, rounds = (ncol + GROUPS - 1u) / GROUPS;
 		for (uint32_t rd = 0; rd < rounds; rd++) {
-			const uint32_t job = rd * (uint32_t)FPW + f;
-			const bool live = job < ncol;
+			const uint32_t job = rd * GROUPS + f;
+			const bool live = inGroup && job < ncol;
 			const uint32_t jc = live ? job : 0u, r = jc / (uint32_t)P, k2 = jc - r * (uint32_t)P;
 			cx<T>* const col = bufs + r * M * (uint32_t)SP + k2;
 			const cx<T> x0 = col[0];
@@ -371,14 +409,14 @@ __global__ void __launch_bounds__(TPF * FPW) mixrad_kernel(const PassParams p) {
 }
 
 template <typename T, typename SCH, int TPF, int FPW> void mixrad_launch(const PassParams& prm, dim3 grid, hipStream_t s) {
-	using G = MixradGeom<T, SCH, TPF>;
+	using G = MixradGeom<T, SCH, TPF, FPW>;
 	const bool ops = prm.preOp != OP_NONE || prm.postOp != OP_NONE;
 	const size_t lds = (size_t)mixrad_lds_bytes((uint32_t)G::P, (uint32_t)G::SP, (uint32_t)G::LUTN, prm.raderM, prm.T, (uint32_t)sizeof(cx<T>), ops && mixrad_two_sets(prm.raderM, prm.raderA));
 	const bool sq = prm.raderA == 0u;
 	const dim3 g = grid;
 	if (sq) {
-		if constexpr (G::P * G::P <= (int)kMixradLongest) hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, true>), g, dim3(TPF * FPW), lds, s, prm);
-	} else hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, false>), g, dim3(TPF * FPW), lds, s, prm);
+		if constexpr (G::P * G::P <= (int)kMixradLongest) hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, true>), g, dim3(G::NT), lds, s, prm);
+	} else hipLaunchKernelGGL((mixrad_kernel<T, SCH, TPF, FPW, false>), g, dim3(G::NT), lds, s, prm);
 }
 // the composite form exists for the Rader ROW instances whose prime leaves room for a cofactor (2 P <= the longest row)
 template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> constexpr auto mixrad_ptr() -> void (*)(const PassParams&, dim3, hipStream_t) {
@@ -388,5 +426,7 @@ template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> conste
 }
 template <typename T, typename SCH, int TPF, int RADER, int COL> constexpr int mixrad_sp() { if constexpr (RADER != 0 && COL == 0) return MixradGeom<T, SCH, TPF>::SP; else return 0; }
 template <typename T, typename SCH, int TPF, int RADER, int COL> constexpr int mixrad_lutn() { if constexpr (RADER != 0 && COL == 0) return MixradGeom<T, SCH, TPF>::LUTN; else return 0; }
+template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> constexpr int mixrad_groups() { if constexpr (RADER != 0 && COL == 0) return MixradGeom<T, SCH, TPF, FPW>::GROUPS_ALIGNED; else return 0; }
+template <typename T, typename SCH, int TPF, int FPW, int RADER, int COL> constexpr int mixrad_groups_dense() { if constexpr (RADER != 0 && COL == 0) return MixradGeom<T, SCH, TPF, FPW>::GROUPS_DENSE; else return 0; }
 
 } // namespace vkfft_mi355x

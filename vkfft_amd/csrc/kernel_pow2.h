@@ -108,11 +108,18 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 	const uint32_t f = tid / TPF, tau = tid % TPF;
 	const uint32_t n = p.opN;
 	const GBuf glut = make_gbuf(p.lut), gch = make_gbuf(p.aux), gbh = make_gbuf(p.aux2);
+	// (the tables of a thread's points stay in registers across the tiles — except in the 16384-point shape, 1024 threads at 128 registers, where they spilled:
+	// 508 bytes of scratch per lane in round 5; there they are read again for every tile)
+	constexpr bool TABREG = TPF * FPW < 1024;
 	cx<T> ch[EH], bh[E];
+	if constexpr (TABREG) {
 #pragma unroll
-	for (int m = 0; m < EH; m++) { const uint32_t pos = tau + m * TPF; ch[m] = gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0); }
+		for (int m = 0; m < EH; m++) { const uint32_t pos = tau + m * TPF; ch[m] = gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0); }
 #pragma unroll
-	for (int m = 0; m < E; m++) bh[m] = gb_load<T>(gbh, (tau + m * TPF) * ES, 0);
+		for (int m = 0; m < E; m++) bh[m] = gb_load<T>(gbh, (tau + m * TPF) * ES, 0);
+	}
+	auto chv = [&](int m) -> cx<T> { if constexpr (TABREG) return ch[m]; else { const uint32_t pos = tau + m * TPF; return gb_load<T>(gch, pos < n ? pos * ES : kGbInvalid, 0); } };
+	auto bhv = [&](int m) -> cx<T> { if constexpr (TABREG) return bh[m]; else return gb_load<T>(gbh, (tau + m * TPF) * ES, 0); };
 	// which of this thread's points are read / written: inside the sequence and outside the caller's zero-padded range (vkFFT_Zeropad.h:28).  The points do not
 	// depend on the tile, so the tests are made once, one bit per point — as compares inside the loop the four range operands cost the 8192-point
 	// instance 60 scalar-register spills (2049 ... 4096-point rows 11 % slower, profiles/r04b_sample1000_*)
@@ -141,18 +148,18 @@ __global__ void __launch_bounds__(((1 << SCH::LOGN) >> SCH::LOGE) * FPW) pow2_bl
 		for (int m = 0; m < EH; m++) { // points >= n are the zero padding (n <= M/2: they include every m >= E/2)
 			cx<T> x = gb_load<T>(gin, ((rdMask >> m) & 1u) ? laneIn : kGbInvalid, (uint32_t)(m * TPF) * ES);
 			if (p.bluesteinSwapIn) x = cswap(x);
-			v[m] = cmulc(x, ch[m]);
+			v[m] = cmulc(x, chv(m));
 		}
 #pragma unroll
 		for (int m = EH; m < E; m++) v[m] = cx<T>{(T)0, (T)0};
 		pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
 #pragma unroll
-		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], bh[m]));
+		for (int m = 0; m < E; m++) v[m] = cswap(cmul(v[m], bhv(m)));
 		if constexpr (SCH::NS > 1) { if (waveOnly) VKFFT_WAVE_SYNC(); else VKFFT_SYNC(); } // the exchange buffer is reused
 		pow2_stages<T, SCH, 0, TPF, 0, TwGlobal<T>>(v, lds + f * LDSPF, TwGlobal<T>{glut}, tau, waveOnly);
 #pragma unroll
 		for (int m = 0; m < EH; m++) {
-			cx<T> x = cmulc(cswap(v[m]), ch[m]);
+			cx<T> x = cmulc(cswap(v[m]), chv(m));
 			if (p.bluesteinSwapOut) x = cswap(x);
 			if (sc != (T)1) x = cscale(x, sc);
 			gb_store<T>(gout, ((wrMask >> m) & 1u) ? laneOut : kGbInvalid, (uint32_t)(m * TPF) * ES, x);

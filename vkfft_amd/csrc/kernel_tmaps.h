@@ -38,11 +38,14 @@ template <typename T> struct TmGlobal {
 	__device__ inline void put(uint32_t off, T v) const { gb_store_real<T>(g, off, 0, v); }
 	__device__ inline void put2(uint32_t off, cx<T> v) const { gb_store<T>(g, off, 0, v); }
 };
+// slot of scalar i of the staging tile: one scalar of padding per 32.  The tile holds the rows as they lie in memory, and a row pitch that is a multiple of 32
+// scalars (R2C of 31 reals in place: 32) put every lane of a one-thread-per-row instance on ONE bank (round 5: 0.34x the reference, 64-way conflicts)
+__host__ __device__ constexpr uint32_t tm_slot(uint32_t i) { return i + (i >> 5); }
 template <typename T> struct TmLds {
 	T* base;
-	__device__ inline T real(uint32_t off) const { const T v = base[(off < kGbRange ? off : 0u) / (uint32_t)sizeof(T)]; return off < kGbRange ? v : (T)0; }
-	__device__ inline void put(uint32_t off, T v) const { if (off < kGbRange) base[off / (uint32_t)sizeof(T)] = v; }
-	__device__ inline void put2(uint32_t off, cx<T> v) const { if (off < kGbRange) { base[off / (uint32_t)sizeof(T)] = v.x; base[off / (uint32_t)sizeof(T) + 1u] = v.y; } }
+	__device__ inline T real(uint32_t off) const { const T v = base[tm_slot((off < kGbRange ? off : 0u) / (uint32_t)sizeof(T))]; return off < kGbRange ? v : (T)0; }
+	__device__ inline void put(uint32_t off, T v) const { if (off < kGbRange) base[tm_slot(off / (uint32_t)sizeof(T))] = v; }
+	__device__ inline void put2(uint32_t off, cx<T> v) const { if (off < kGbRange) { base[tm_slot(off / (uint32_t)sizeof(T))] = v.x; base[tm_slot(off / (uint32_t)sizeof(T) + 1u)] = v.y; } }
 };
 // the tables of one side: offs = uint32 pairs, coef = pairs of cx<T>, one entry per position; data = the tile's rows
 template <typename T> struct TmSide {

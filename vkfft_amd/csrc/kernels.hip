@@ -150,11 +150,11 @@ bool mixrad_available(int variant) {
 	const int idx = variant & 0xffff;
 	return variant >= 0 && idx < cnt && tab[idx].launchRad != nullptr;
 }
-bool mixrad_geom(int variant, int* sp, int* lutn) {
+bool mixrad_geom(int variant, int* sp, int* lutn, int* groups, int* groupsDense) {
 	if (!mixrad_available(variant)) return false;
 	int cnt = 0;
 	const MixConvVariant* tab = mixconv_part((variant >> 16) % kMixConvParts, &cnt);
-	*sp = tab[variant & 0xffff].radSP; *lutn = tab[variant & 0xffff].radLutN;
+	*sp = tab[variant & 0xffff].radSP; *lutn = tab[variant & 0xffff].radLutN; *groups = tab[variant & 0xffff].radGroups; *groupsDense = tab[variant & 0xffff].radGroupsDense;
 	return true;
 }
 int launch_mixconv(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {

@@ -120,7 +120,7 @@ struct PassBuild {
 	uint32_t raderDirectMax = 0;
 	std::string label;
 	uint32_t forceT = 0;
-	uint32_t raderM = 0, raderA = 0; // mixrad_kernel: cofactor of the composite length and its split (kernel_mixrad.h)
+	uint32_t raderM = 0, raderA = 0, raderAligned = 0; // mixrad_kernel: cofactor of the composite length, its split, layout of the thread groups (kernel_mixrad.h)
 	std::vector<uint32_t> radices; // explicit stage radices (fast kernels fix their own schedule)
 	int fastKernel = KERNEL_GENERIC, fastVariant = -1, fastThreads = 0;
 	bool allowFast = true;
@@ -186,7 +186,7 @@ static void make_mixrad_tables(uint64_t P, uint64_t M, bool dp, Arena& ar, size_
 }
 // A row of L = M * P complex points on the Rader-stage kernel (kernel_mixrad.h): P the largest prime factor (37 or more, with a Rader row instance), M a cofactor
 // that splits into the kernel's column radices (mixrad_plan.h).  VKFFT_MI355X_MIXRAD=0: off; VKFFT_MI355X_MIXRAD_LDS_KIB: the LDS budget of a tile (tuning)
-struct MixradChoice { uint64_t P = 0, M = 0, len = 0; uint32_t A = 0, rows = 0; int variant = -1, rad[5] = {1, 1, 1, 1, 1}, fpw = 0, threads = 0; double cost = 2.0; };
+struct MixradChoice { uint64_t P = 0, M = 0, len = 0; uint32_t A = 0, rows = 0, aligned = 0; int variant = -1, rad[5] = {1, 1, 1, 1, 1}, fpw = 0, threads = 0; double cost = 2.0; };
 static bool mixrad_choose(uint64_t L, bool dp, bool ops, MixradChoice& c) { // ops: a real transform between the table-driven maps
 	if (dp || L < 37 || L > kMixradLongest) return false;
 	if (getenv("VKFFT_MI355X_MIXRAD") && atoi(getenv("VKFFT_MI355X_MIXRAD")) == 0) return false;
@@ -201,12 +201,20 @@ static bool mixrad_choose(uint64_t L, bool dp, bool ops, MixradChoice& c) { // o
 		A = 1;
 	} else if (M == P) A = 0; // P * P: the column transform is the prime's own convolution (kernel_mixrad.h, 2b)
 	else if (!mixrad_split((uint32_t)M, A, B)) return false;
-	uint64_t len; int sp = 0, lutn = 0;
-	if (!mixconv_lookup(true, false, P, dp, &c.variant, &len, c.rad, &c.fpw, &c.threads) || !mixrad_geom(c.variant, &sp, &lutn)) return false;
+	uint64_t len; int sp = 0, lutn = 0, groups = 0, gd = 0;
+	if (!mixconv_lookup(true, false, P, dp, &c.variant, &len, c.rad, &c.fpw, &c.threads) || !mixrad_geom(c.variant, &sp, &lutn, &groups, &gd)) return false;
 	const uint64_t budget = (getenv("VKFFT_MI355X_MIXRAD_LDS_KIB") ? (uint64_t)atoll(getenv("VKFFT_MI355X_MIXRAD_LDS_KIB")) : 40ull) << 10;
 	const bool twoSets = ops && mixrad_two_sets((uint32_t)M, A);
 	c.P = P; c.M = M; c.A = A; c.len = len;
-	c.rows = mixrad_rows((uint32_t)P, (uint32_t)sp, (uint32_t)lutn, (uint32_t)c.fpw, (uint32_t)M, dp ? 16u : 8u, budget, twoSets);
+	// layout of the convolution's thread groups (kernel_mixrad.h MixradGeom): the wave-aligned one runs its rounds without workgroup barriers (a round costs about 0.8
+	// of a dense one: 3144, 3130, 3611, 314 1.2-1.5x faster) but may have fewer groups than the dense FPW — a round more where the cofactor was matched to FPW
+	// (3232 = 32 * 101, 2032 = 16 * 127: 0.9x).  Cost of a row = rounds per tile / rows per tile, per layout with its own tile
+	c.rows = mixrad_rows((uint32_t)P, (uint32_t)sp, (uint32_t)lutn, (uint32_t)gd, (uint32_t)M, dp ? 16u : 8u, budget, twoSets);
+	if (groups > 0 && !getenv("VKFFT_MI355X_MIXRAD_DENSE")) {
+		const uint32_t ra = mixrad_rows((uint32_t)P, (uint32_t)sp, (uint32_t)lutn, (uint32_t)groups, (uint32_t)M, dp ? 16u : 8u, budget, twoSets);
+		auto cost = [&](uint32_t rows, uint32_t g, double w) { const uint64_t jobs = (uint64_t)rows * M; return w * (double)((jobs + g - 1) / g) / (double)rows; };
+		if (cost(ra, (uint32_t)groups, 0.8) <= cost(c.rows, (uint32_t)gd, 1.0)) { c.rows = ra; c.aligned = 1; }
+	}
 	if (mixrad_lds_bytes((uint32_t)P, (uint32_t)sp, (uint32_t)lutn, (uint32_t)M, c.rows, dp ? 16u : 8u, twoSets) > 160ull * 1024) return false;
 	// points of the fused power-of-two Bluestein transform that one point of the row costs (profiles/r06_rader_stage_forced_vs_bluestein.jsonl: every served class
 	// forced either way): 1.2-2.2 with register column steps; a direct last step of radix B adds (B / 33)^2.2 (23: 2.4, 29: 2.5, 37: 3.4, 49: 4.3); primes whose
@@ -219,7 +227,10 @@ static bool mixrad_choose(uint64_t L, bool dp, bool ops, MixradChoice& c) { // o
 
 // Real-transform families that can carry TWO rows per complex transform (kernel_generic.h ops_rows_in / ops_rows_out): the pre-map of a row is a real
 // sequence (R2C of odd length, DCT / DST-I, -II and odd -IV in their full-length forms) or the result is real (C2R of odd length, DCT / DST-III).
-constexpr int kPairPreferDefault = 0;
+// 0: never over a fused-map instance; 1: every pairable family; 2 (default since round 6): DCT-II / -III and the odd DCT-IV — measured with the planner forced either way on every
+// length 4 ... 400 (profiles/r06_real_rows_pairs_preferred_over_fused_map_instances.jsonl): DCT-IV of 5, 25, 35 ... 245 reals 1.10-1.83x faster between the tables than on
+// their fused-map instance (none slower), DCT-II / -III of 7, 25, 49, 175, 343 1.03-1.45x; R2C / C2R mixed (7: 1.29x, 25 and 49: 0.75x) and left where they were
+constexpr int kPairPreferDefault = 2;
 static bool pairable_family(uint32_t pre, uint32_t post, uint64_t cplxLen, uint32_t opN) {
 	auto fam = [&](uint32_t a, uint32_t c) { return pre == a && post == c; };
 	const bool odd4 = (fam(OP_DCT4_PRE, OP_DCT4_POST) || fam(OP_DST4_PRE, OP_DST4_POST)) && cplxLen == opN;
@@ -455,7 +466,8 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 		// two real rows per transform exist only between the generic maps (PassParams::pairRows): VKFFT_MI355X_PAIR_PREFER=1 sends the pairable families there
 		// even where a fused-map instance exists (measurement switch)
 		const int pairPrefer = getenv("VKFFT_MI355X_PAIR_PREFER") ? atoi(getenv("VKFFT_MI355X_PAIR_PREFER")) : kPairPreferDefault;
-		if (!preferMixedOps && pairPrefer && rowOp && pairable_family(b.preOp, b.postOp, b.L, b.opN) && mixed_row_lookup(b.L, b.dp, &v, r5, &f, &t)) preferMixedOps = true;
+		const bool r2cFam = b.preOp == OP_R2C_FULL || b.preOp == OP_C2R_FULL || b.postOp == OP_R2C_FULL || b.postOp == OP_C2R_FULL;
+		if (!preferMixedOps && (pairPrefer == 1 || (pairPrefer == 2 && !r2cFam)) && rowOp && pairable_family(b.preOp, b.postOp, b.L, b.opN) && mixed_row_lookup(b.L, b.dp, &v, r5, &f, &t)) preferMixedOps = true;
 	}
 	if (b.allowOp && opMaskOK && !preferMixedOps && b.fastKernel == KERNEL_GENERIC && !b.forceT && b.midOp == OP_NONE && (b.colIn == b.colOut || transOut) && b.radices.empty()
 	    && !(b.preOp == OP_NONE && b.postOp == OP_NONE && !b.colIn)) {
@@ -504,7 +516,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 				size_t bhatOff;
 				make_mixrad_tables(mr.P, mr.M, b.dp, ar, mixconvTabOff, bhatOff);
 				b.auxOff2ForPre = bhatOff;
-				b.L = mr.len; b.raderM = (uint32_t)mr.M; b.raderA = mr.A;
+				b.L = mr.len; b.raderM = (uint32_t)mr.M; b.raderA = mr.A; b.raderAligned = mr.aligned;
 				b.fastKernel = KERNEL_MIXCONV; b.fastVariant = mr.variant; b.fastThreads = mr.threads;
 				b.forceT = mr.rows;
 				for (int k = 0; k < 5; k++) if (mr.rad[k] > 1) b.radices.push_back((uint32_t)mr.rad[k]);
@@ -674,7 +686,7 @@ static int finish_pass(const PassBuild& bIn, Arena& ar, PassPlan& pp) {
 	p.bigSpan = b.bigSpan ? 1u : 0u;
 	p.divL = make_fastdiv((uint32_t)b.L);
 	p.divOutLen = make_fastdiv(p.outLen);
-	p.raderM = b.raderM; p.raderA = b.raderA; // mixrad_kernel: rows of raderM * (L + 1) points
+	p.raderM = b.raderM; p.raderA = b.raderA; p.raderAligned = b.raderAligned; // mixrad_kernel: rows of raderM * (L + 1) points
 	const uint64_t padded = p.padShift >= 31 ? b.L : b.L + (b.L >> p.padShift);
 	p.ldsElems = (uint32_t)((padded + 1) * p.Tp);
 	p.tilesPerG0 = (uint32_t)((dims[0].count + T - 1) / T);
@@ -1311,7 +1323,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 			for (int k = 0; k < 5; k++) if (mr.rad[k] > 1) b.radices.push_back((uint32_t)mr.rad[k]);
 			b.fastKernel = KERNEL_MIXCONV; b.fastVariant = mr.variant; b.fastThreads = mr.threads;
 			b.forceT = mr.rows; // rows per workgroup
-			b.raderM = (uint32_t)mr.M; b.raderA = mr.A;
+			b.raderM = (uint32_t)mr.M; b.raderA = mr.A; b.raderAligned = mr.aligned;
 			b.bsSwapIn = b.bsSwapOut = j.inverse; b.scale = j.scale;
 			b.inStrideJ = j.inStrideJ; b.outStrideJ = j.outStrideJ; b.dims = j.others;
 			b.colIn = b.colOut = false;
