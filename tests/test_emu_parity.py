@@ -79,11 +79,52 @@ def test_bluestein(run, oracle, N, dp):
     parity.check_c2c(run, oracle, (N,), 2, dp, kind="bluestein")
 
 
-@pytest.mark.parametrize("N,dp,uploads", [(4099, False, 1), (8191, False, 1), (4093, True, 1), (8209, False, 3), (15319, False, 3), (21269, True, 3), (524309, False, 5)])
-def test_bluestein_multi_pass_fused(run, oracle, N, dp, uploads):
-    """Rows whose padded power-of-two length needs two / three column factors: 3 / 5 passes (pow2_col_blue_kernel)."""
+@pytest.mark.parametrize("N,dp,uploads,two_launches", [(4099, False, 1, 1), (8191, False, 1, 1), (4093, True, 1, 1), (8209, False, 3, 1), (15319, False, 3, 1), (21269, True, 3, 0), (524309, False, 5, 1),
+                                                       (8209, False, 3, 0), (15319, False, 3, 0), (524309, False, 5, 0)])
+def test_bluestein_multi_pass_fused(run, oracle, monkeypatch, N, dp, uploads, two_launches):
+    """Rows whose padded length does not fit one pass.  fp32 (round 6): TWO launches of the fused Four-Step kernel with the chirp-z hooks on a registered padded length
+    (kernel_mix_fused.h: 8209 -> 2^15, 15319 -> 30720 = 160 x 192, 524309 -> 1049760 = 972 x 1080); fp64 and VKFFT_MI355X_MIXFUSED=0: the 3 / 5 passes of
+    pow2_col_blue_kernel on a power of two."""
+    if not two_launches:
+        monkeypatch.setenv("VKFFT_MI355X_MIXFUSED", "0")
     up = parity.check_c2c(run, oracle, (N,), 2 if N < 100000 else 1, dp, kind="bluestein", use_c_oracle=False)
-    assert up == [uploads]
+    h, ptr = run._alloc(np.zeros(2 * N, np.complex128 if dp else np.complex64))
+    app = api.App([N], 2, dp=dp, buffer_ptr=ptr, lib=run.lib)
+    n, names = app.launch_info(False)
+    app.delete()
+    if two_launches and uploads > 1:
+        assert up == [2] and n == 2 and names.startswith("mix_fused_kernel"), (up, n, names)
+    else:
+        assert up == [uploads] and n == uploads, (up, n, names)
+
+
+def _largest_prime_with_padded_length(M):
+    def smooth13(v):
+        for q in (2, 3, 5, 7, 11, 13):
+            while v % q == 0:
+                v //= q
+        return v == 1
+    n = (M + 1) // 2
+    while any(n % d == 0 for d in range(2, int(n ** 0.5) + 1)) or smooth13(n - 1):  # (a prime without a Rader form: p - 1 not 13-smooth)
+        n -= 1
+    return n
+
+
+@pytest.mark.parametrize("M", [30720, 1 << 15, 43008, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1049760, 1 << 21, 4014080, 1 << 22])
+def test_chirp_z_in_two_fused_launches_every_padded_length(run, oracle, M):
+    """every registered padded length of the two-launch chirp-z plan (kernels_mixfused.hip, the instances with the hooks): the largest prime N with 2N - 1 <= M, forward
+    against the double truth and the round trip (chirp and zero padding on the first launch's loads, FFT(chirp) on its stores, second chirp and the write mask on the
+    second launch's stores)"""
+    N = _largest_prime_with_padded_length(M)
+    batch = 3 if M <= (1 << 17) else 1
+    up = parity.check_c2c(run, oracle, (N,), batch, False, kind="bluestein", use_c_oracle=False)
+    assert up == [2]
+    h, ptr = run._alloc(np.zeros(batch * N, np.complex64))
+    app = api.App([N], batch, buffer_ptr=ptr, lib=run.lib)
+    n, names = app.launch_info(False)
+    split = [int(app.app.localFFTPlan.contents.axisSplit[0][i]) for i in range(2)]
+    app.delete()
+    assert n == 2 and names.startswith("mix_fused_kernel") and split[0] * split[1] == M, (n, names, split)
 
 
 @pytest.mark.parametrize("N,passes", [(1 << 15, 1), (1 << 16, 2), (1 << 18, 2), (3 ** 10, 2), (1 << 21, 2), (5 ** 9, 3)])
@@ -351,6 +392,43 @@ def test_fused_fourstep_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag
     assert up == [2]
     assert rel_l2(y, oracle.truth_c2c(x, (N,), batch)) < 1e-6
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
+
+
+@pytest.mark.parametrize("N,batch", [(59049, 3), (177147, 2), (531441, 1), (15625, 5), (78125, 3), (390625, 1), (117649, 2), (823543, 1), (14641, 5), (161051, 2), (28561, 3), (371293, 1)])
+def test_fused_fourstep_of_non_power_of_two_lengths(run, oracle, N, batch):
+    """fused Four-Step of two mixed-radix factors (kernel_mix_fused.h): every registered length of BASELINE config 3's powers of 3, 5, 7, 11 and 13 — partial last
+    tiles of either phase (243 = 15 x 16 + 3 columns), phases with different tile counts, one launch per direction"""
+    x = parity.seeded_complex(N * batch, False, N + batch)
+    y, z, up = run.transform(x, (N,), batch, both=True)
+    assert up == [2]
+    h, ptr = run._alloc(x)
+    app = api.App([N], batch, buffer_ptr=ptr, lib=run.lib)
+    n, names = app.launch_info(False)
+    app.delete()
+    assert n == 1 and names.startswith("mix_fused_kernel"), (n, names)
+    truth = oracle.truth_c2c(x, (N,), batch)
+    assert rel_l2(y, truth) < 1e-6
+    assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
+
+
+@pytest.mark.parametrize("N,batch,chunk_kib,lag,ring,queues,shape", [(59049, 7, 512, 2, 3, 1, 0), (59049, 11, 1024, 1, 2, 4, 0), (15625, 37, 256, 2, 3, 8, 0), (15625, 21, 128, 1, 2, 3, 0),
+                                                                     (14641, 19, 256, 3, 5, 8, 0), (531441, 3, 4096, 1, 2, 1, 1)])
+def test_fused_fourstep_of_non_power_of_two_lengths_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag, ring, queues, shape):
+    """the same kernel under forced chunk sizes, lags, rings and queue counts (ring slots reused, a partial last chunk, queues that are helped, the reversed sweep of
+    the inverse), the second registered shape of 3^12, and against the separate passes it replaces (VKFFT_MI355X_MIXFUSED=0)"""
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_CHUNK_KIB", str(chunk_kib))
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_LAG", str(lag))
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_RING", str(ring))
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_QUEUES", str(queues))
+    monkeypatch.setenv("VKFFT_MI355X_MXFV", str(shape))
+    x = parity.seeded_complex(N * batch, False, N + batch)
+    y, z, up = run.transform(x, (N,), batch, both=True)
+    assert up == [2]
+    assert rel_l2(y, oracle.truth_c2c(x, (N,), batch)) < 1e-6
+    assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
+    monkeypatch.setenv("VKFFT_MI355X_MIXFUSED", "0")
+    y2, _ = run.transform(x, (N,), batch)
+    assert rel_l2(y, y2.astype(np.complex128)) < 5e-7
 
 
 @pytest.mark.parametrize("k,variant", [(k, v) for k in (9, 10, 11, 12) for v in range(2)] + [(k, v) for k in (13, 14, 15) for v in range(3)])

@@ -340,6 +340,50 @@ def test_radix_multi_pass(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 2, False, use_c_oracle=False)
 
 
+@pytest.mark.parametrize("N,batch", [(59049, 9), (177147, 5), (531441, 3), (15625, 70), (78125, 13), (390625, 3), (117649, 9), (823543, 2), (14641, 73), (161051, 7), (28561, 37), (371293, 3)])
+def test_fused_fourstep_of_non_power_of_two_lengths_on_device(run, oracle, product_lib, monkeypatch, N, batch):
+    """kernel_mix_fused.h on the device: every registered length against the double truth, ONE launch per direction, and against the separate Four-Step passes
+    it replaces (VKFFT_MI355X_MIXFUSED=0: the same factors in the same order, so the two agree to rounding)"""
+    x = parity.seeded_complex(N * batch, False, N + batch)
+    y, z, up = run.transform(x, (N,), batch, both=True)
+    assert up == [2]
+    h, ptr = run._alloc(x)
+    app = api.App([N], batch, buffer_ptr=ptr, lib=product_lib)
+    n, names = app.launch_info(False)
+    app.delete()
+    assert n == 1 and names.startswith("mix_fused_kernel"), (n, names)
+    assert rel_l2(y, oracle.truth_c2c(x, (N,), batch)) < 1e-6
+    assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
+    monkeypatch.setenv("VKFFT_MI355X_MIXFUSED", "0")
+    y2, _ = run.transform(x, (N,), batch)
+    assert rel_l2(y, y2.astype(np.complex128)) < 5e-7
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("N,queues,lag,ring", [(59049, 3, 1, 4), (59049, 8, 0, 0), (390625, 5, 1, 4), (161051, 7, 1, 3), (14641, 6, 1, 4)])
+def test_fused_fourstep_of_non_power_of_two_lengths_many_launches(product_lib, monkeypatch, N, queues, lag, ring):
+    """the ticket / ring machinery of kernel_mix_fused.h under load: chip-filling batches, queue counts that do not divide the 8 XCDs (most workgroups finish on a
+    queue that is not theirs), the shortest lag, 60 forward + inverse pairs with the zig-zag sweep — every round trip must return the input"""
+    import torch
+    if lag:
+        monkeypatch.setenv("VKFFT_MI355X_FUSED_LAG", str(lag)); monkeypatch.setenv("VKFFT_MI355X_FUSED_RING", str(ring))
+    monkeypatch.setenv("VKFFT_MI355X_FUSED_QUEUES", str(queues))
+    B = (1 << 26) // N
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    x = torch.empty(2 * N * B, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)
+    buf = x.clone()
+    app = api.App([N], B, buffer_ptr=buf.data_ptr(), normalize=True, lib=product_lib)
+    assert app.launch_info(False)[1].startswith("mix_fused_kernel")
+    nx = torch.linalg.norm(x)
+    worst = 0.0
+    for _ in range(60):
+        buf.copy_(x)
+        app.forward(); app.inverse()
+        worst = max(worst, (torch.linalg.norm(buf - x) / nx).item())
+    app.delete()
+    assert worst < 2e-6, (N, queues, worst)
+
+
 @pytest.mark.parametrize("N", [17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 17 * 64, 23 * 27, 59 * 8])
 def test_rader_primes(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 8, False)
@@ -354,6 +398,41 @@ def test_rader_fft_convolution_primes(run, oracle, N, dp):
 @pytest.mark.parametrize("N", [83, 107, 251, 509, 1021, 2039, 4093, 83 * 8, 15319, 21269, 2000083])
 def test_bluestein_fp32(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 4 if N < 100000 else 1, False, kind="bluestein", use_c_oracle=N < 5000)
+
+
+def _prime_without_rader_form_below(M):
+    def smooth13(v):
+        for q in (2, 3, 5, 7, 11, 13):
+            while v % q == 0:
+                v //= q
+        return v == 1
+    n = (M + 1) // 2
+    while any(n % d == 0 for d in range(2, int(n ** 0.5) + 1)) or smooth13(n - 1):
+        n -= 1
+    return n
+
+
+@pytest.mark.parametrize("M,batch", [(30720, 67), (1 << 15, 33), (43008, 41), (1 << 16, 9), (1 << 17, 9), (1 << 18, 5), (1 << 19, 3), (1 << 20, 3), (1049760, 5), (1 << 21, 2), (4014080, 3), (1 << 22, 1)])
+def test_chirp_z_in_two_fused_launches_on_device(run, oracle, product_lib, monkeypatch, M, batch):
+    """the two-launch chirp-z plan (kernel_mix_fused.h with the MixFusedOps hooks) on the device: every registered padded length with the largest prime below it that has
+    no Rader form, several transforms per launch, against the double truth, the round trip, and against the 3 / 5 separate passes of round 2 (VKFFT_MI355X_MIXFUSED=0)"""
+    N = _prime_without_rader_form_below(M)
+    x = parity.seeded_complex(N * batch, False, N + batch)
+    y, z, up = run.transform(x, (N,), batch, both=True)
+    assert up == [2]
+    h, ptr = run._alloc(x)
+    app = api.App([N], batch, buffer_ptr=ptr, lib=product_lib)
+    n, names = app.launch_info(False)
+    split = [int(app.app.localFFTPlan.contents.axisSplit[0][i]) for i in range(2)]
+    app.delete()
+    assert n == 2 and names.startswith("mix_fused_kernel") and split[0] * split[1] == M, (n, names, split)
+    from helpers import TOL
+    tol = TOL[("bluestein", False)]
+    assert rel_l2(y, oracle.truth_c2c(x, (N,), batch)) < tol
+    assert rel_l2(z, x.astype(np.complex128) * N) < 2 * tol
+    monkeypatch.setenv("VKFFT_MI355X_MIXFUSED", "0")
+    y2, _ = run.transform(x, (N,), batch)
+    assert rel_l2(y, y2.astype(np.complex128)) < 2 * tol
 
 
 @pytest.mark.parametrize("N", [127, 1021, 2039, 4093, 15319])

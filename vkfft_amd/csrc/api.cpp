@@ -95,7 +95,7 @@ VKFFT_API void vkfftMI355XStructSizes(pfUINT out[4]) {
 
 static void describe_passes(const VkFFTPlan* pl, char* names, pfUINT cap, size_t& pos, int& launches) {
 	static const char* kname[] = {"generic_pass_kernel", "pow2_row_kernel", "pow2_col_kernel", "r2c_even_pair_kernel", "?", "mixed_row_kernel", "opfft_kernel", "pow2_blue_kernel",
-	                              "pow2_col_blue_kernel", "pow2_blue_r2r_kernel", "pow2_fused_kernel", "transpose_kernel", "real_map_kernel", "mixconv_kernel"};
+	                              "pow2_col_blue_kernel", "pow2_blue_r2r_kernel", "pow2_fused_kernel", "transpose_kernel", "real_map_kernel", "mixconv_kernel", "mix_fused_kernel"};
 	if (!pl || !pl->impl) return;
 	const DirectionPlan* dp = (const DirectionPlan*)pl->impl;
 	for (const PassPlan& q : dp->passes) {
@@ -103,7 +103,7 @@ static void describe_passes(const VkFFTPlan* pl, char* names, pfUINT cap, size_t
 		for (const HostDim& h : q.hostLoop) rep *= h.count;
 		launches += (int)rep;
 		if (!names || !cap) continue;
-		const char* nm = kname[q.kernel >= 0 && q.kernel < 14 ? q.kernel : 4];
+		const char* nm = kname[q.kernel >= 0 && q.kernel < 15 ? q.kernel : 4];
 		if (q.kernel == KERNEL_POW2_FUSED) nm = pow2_fused_kernel_name(q.variant);       // (pow2_fused_kernel / _pipe_ / _pk_ / _pkh_)
 		else if (q.kernel == KERNEL_POW2_ROW) nm = pow2_row_kernel_name(q.variant);      // (pow2_row_kernel / pow2_row_lean_kernel / pow2_row_lean_pk_kernel)
 		else if (q.kernel == KERNEL_MIXCONV && q.prm.raderM) nm = "mixrad_kernel";        // (kernel_mixrad.h)
@@ -327,20 +327,20 @@ VKFFT_API VkFFTResult initializeVkFFT(VkFFTApplication* app, VkFFTConfiguration 
 		}
 	}
 	if (c.printMemoryLayout || getenv("VKFFT_MI355X_PRINT_PLAN")) { // one line per launch: which kernel family serves it
-		static const char* kname[] = {"generic", "pow2_row", "pow2_col", "r2c_pair", "?", "mixed_row", "opfft", "pow2_blue", "pow2_col_blue", "pow2_blue_r2r", "pow2_fused", "transpose", "real_map", "mixconv"};
+		static const char* kname[] = {"generic", "pow2_row", "pow2_col", "r2c_pair", "?", "mixed_row", "opfft", "pow2_blue", "pow2_col_blue", "pow2_blue_r2r", "pow2_fused", "transpose", "real_map", "mixconv", "mix_fused"};
 		for (int dir = 0; dir < 2; dir++) {
 			VkFFTPlan* pl = dir ? app->localFFTPlan_inverse : app->localFFTPlan;
 			if (!pl) continue;
 			const DirectionPlan* dpn = (const DirectionPlan*)pl->impl;
 			for (size_t i = 0; i < dpn->passes.size(); i++) {
 				const PassPlan& q = dpn->passes[i];
-				if (q.kernel == KERNEL_POW2_FUSED) {
-					fprintf(stderr, "[vkfft_mi355x] %s pass %zu: %-10s kernel=pow2_fused variant=%d N=%ux%u threads=%u chunk=%u transforms x %u chunks, %u queues, lag %u, ring %u (%.1f MiB)\n", dir ? "inverse" : "forward", i,
-					        q.label.c_str(), q.variant, q.fused.n0, q.fused.n1, q.threads, 1u << q.fused.logG, q.fused.C, q.fused.Q, q.fused.D, q.fused.NS, (double)dpn->tempBytes / 1048576.0);
+				if (q.kernel == KERNEL_POW2_FUSED || q.kernel == KERNEL_MIX_FUSED) {
+					fprintf(stderr, "[vkfft_mi355x] %s pass %zu: %-10s kernel=%s variant=%d N=%ux%u threads=%u chunk=%u transforms x %u chunks, %u queues, lag %u, ring %u (%.1f MiB)\n", dir ? "inverse" : "forward", i,
+					        q.label.c_str(), q.kernel == KERNEL_MIX_FUSED ? "mix_fused" : "pow2_fused", q.variant, q.fused.n0, q.fused.n1, q.threads, 1u << q.fused.logG, q.fused.C, q.fused.Q, q.fused.D, q.fused.NS, (double)dpn->tempBytes / 1048576.0);
 					continue;
 				}
 				fprintf(stderr, "[vkfft_mi355x] %s pass %zu: %-10s kernel=%s variant=%d L=%u threads=%u tile=%u%s grid=%llu\n", dir ? "inverse" : "forward", i, q.label.c_str(),
-				        kname[q.kernel < 14 ? q.kernel : 4], q.variant, q.prm.L, q.threads, q.prm.T, q.prm.colMerge ? " (tiles over two dimensions)" : "",
+				        kname[q.kernel < 15 ? q.kernel : 4], q.variant, q.prm.L, q.threads, q.prm.T, q.prm.colMerge ? " (tiles over two dimensions)" : "",
 				        (unsigned long long)q.prm.tilesPerG0 * (q.prm.colMerge ? 1u : q.prm.dim[1].count) * q.prm.dim[2].count);
 			}
 		}

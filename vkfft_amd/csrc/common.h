@@ -212,6 +212,7 @@ struct FusedParams {
 	uint32_t Q;           // work queues (1, or one per XCD): chunk c belongs to queue c % Q
 	uint32_t swapIn, swapOut, reverse;
 	double scale;
+	uint32_t tiles, tpc;  // mix_fused_kernel (kernel_mix_fused.h): tickets per transform = max(tiles of A, tiles of B), tickets per chunk = tiles << logG (neither a power of two)
 	unsigned long long* prof; // development only (VKFFT_MI355X_FUSED_PROFILE): per-workgroup cycle sums of the tile phases, else nullptr
 };
 

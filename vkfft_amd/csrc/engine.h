@@ -12,7 +12,7 @@ namespace vkfft_mi355x {
 
 // ROLE_TEMP2: a second scratch region behind ROLE_TEMP in the same allocation, for plans that wrap an inner plan which uses ROLE_TEMP itself
 enum BufRole : int { ROLE_BUFFER = 0, ROLE_TEMP = 1, ROLE_INPUT = 2, ROLE_OUTPUT = 3, ROLE_TEMP2 = 4 };
-enum KernelKind : int { KERNEL_GENERIC = 0, KERNEL_POW2_ROW = 1, KERNEL_POW2_COL = 2, KERNEL_R2C_PAIR = 3, KERNEL_MIXED_ROW = 5, KERNEL_OPFFT = 6, KERNEL_POW2_BLUE = 7, KERNEL_POW2_COL_BLUE = 8, KERNEL_POW2_BLUE_R2R = 9, KERNEL_POW2_FUSED = 10, KERNEL_TRANSPOSE = 11, KERNEL_REAL_MAP = 12, KERNEL_MIXCONV = 13 };
+enum KernelKind : int { KERNEL_GENERIC = 0, KERNEL_POW2_ROW = 1, KERNEL_POW2_COL = 2, KERNEL_R2C_PAIR = 3, KERNEL_MIXED_ROW = 5, KERNEL_OPFFT = 6, KERNEL_POW2_BLUE = 7, KERNEL_POW2_COL_BLUE = 8, KERNEL_POW2_BLUE_R2R = 9, KERNEL_POW2_FUSED = 10, KERNEL_TRANSPOSE = 11, KERNEL_REAL_MAP = 12, KERNEL_MIXCONV = 13, KERNEL_MIX_FUSED = 14 };
 
 struct HostDim {
 	uint64_t count;
@@ -130,6 +130,9 @@ bool pow2_fused_lookup(uint32_t log2n, bool dp, int mode, int* variant, int* la,
 int launch_pow2_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t stream);
 // the __global__ function behind a registry entry (vkfftMI355XDescribePlan: bench labels, rocprofv3 kernel names)
 const char* pow2_fused_kernel_name(int variant);
+// fused Four-Step of a non-power-of-two N = n0 * n1 (kernels_mixfused.hip, kernel_mix_fused.h)
+bool mix_fused_lookup(uint64_t n, bool dp, int* variant, int* n0, int* n1, int radA[5], int radB[5], int* tca, int* tcb, int* threads, int* wgPerCu);
+int launch_mix_fused(const PassPlan& pp, const FusedParams& prm, hipStream_t stream);
 const char* pow2_row_kernel_name(int variant);
 bool mixed_row_lookup(uint64_t n, bool dp, int* variant, int rad[5], int* fpw, int* threads);
 int mixed_row_ops_fpw(int variant); // rows per workgroup of that variant's form between the maps of a real transform

@@ -258,7 +258,7 @@ int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, cons
 	const int np = (int)plan.passes.size();
 	for (int i = 0; i < np; i++) {
 		const PassPlan& pp = plan.passes[i];
-		if (pp.kernel == KERNEL_POW2_FUSED) {
+		if (pp.kernel == KERNEL_POW2_FUSED || pp.kernel == KERNEL_MIX_FUSED) {
 			FusedParams f = pp.fused;
 			const char* ar = (const char*)plan.dArena;
 			f.in = (const char*)bufs.base[pp.inRole] + pp.inOffset * pp.inElemBytes;
@@ -268,7 +268,7 @@ int execute_direction(const DirectionPlan& plan, const LaunchBuffers& bufs, cons
 			f.rowTab = pp.fusedRowTabOff != (size_t)-1 ? ar + pp.fusedRowTabOff : nullptr;
 			f.ctr = (uint32_t*)((char*)plan.dArena + pp.fusedCtrOff);
 			if (sweep) { f.reverse = *sweep & 1u; *sweep ^= 1u; }
-			int r = launch_pow2_fused(pp, f, stream);
+			int r = pp.kernel == KERNEL_MIX_FUSED ? launch_mix_fused(pp, f, stream) : launch_pow2_fused(pp, f, stream);
 			if (r) return r;
 			continue;
 		}

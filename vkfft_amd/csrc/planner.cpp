@@ -1156,6 +1156,155 @@ static bool emit_fused(const TransformDesc& d, const AxisJob& j, Arena& ar, Dire
 	return true;
 }
 
+// stage twiddles of a compile-time mixed-radix schedule, laid out [(i-1)*S + s] per stage from the second on (mix_sched.h, MixSched::lutOff)
+static size_t build_mix_stage_lut(Arena& ar, const int rad[5], bool dp) {
+	uint64_t elems = 0, S = 1;
+	for (int k = 0; k < 5; k++) if (rad[k] > 1) { if (S > 1) elems += (uint64_t)(rad[k] - 1) * S; S *= (uint64_t)rad[k]; }
+	const size_t off = ar.alloc((elems + 1) * (dp ? 16 : 8));
+	uint64_t cur = 0; S = 1;
+	for (int k = 0; k < 5; k++) if (rad[k] > 1) {
+		const uint64_t R = (uint64_t)rad[k];
+		if (S > 1) {
+			for (uint64_t i = 1; i < R; i++) for (uint64_t sidx = 0; sidx < S; sidx++) ar.putc(off, cur + (i - 1) * S + sidx, unit_root(i * sidx, R * S), dp);
+			cur += (R - 1) * S;
+		}
+		S *= R;
+	}
+	return off;
+}
+
+// Fused Four-Step of a NON-power-of-two two-factor length (kernel_mix_fused.h): the same launch shape as emit_fused (chunks, queues, lag, ring), tiles of either
+// phase that need not divide their factor.  One launch of `batch` transforms of M = n0 * n1 points, inS / outS elements apart on either side.
+struct MixFusedShape { int variant, n0, n1, radA[5], radB[5], tca, tcb, thr, wgPerCu; };
+static bool build_mix_fused_pass(const TransformDesc& d, bool dp, uint64_t M, const MixFusedShape& v, uint64_t batch, int64_t inS, int64_t outS, bool inverse, double scale,
+                                 Arena& ar, PassPlan& pp, uint64_t& scratch) {
+	const uint64_t es = dp ? 16 : 8;
+	const uint64_t n0 = (uint64_t)v.n0, n1 = (uint64_t)v.n1;
+	const uint64_t tilesA = (n1 + (uint64_t)v.tca - 1) / (uint64_t)v.tca, tilesB = (n0 + (uint64_t)v.tcb - 1) / (uint64_t)v.tcb, tiles = std::max(tilesA, tilesB);
+	const uint64_t fftBytes = ((M + 1) & ~1ull) * es; // a transform's share of a ring slot (an even number of elements: 16-byte aligned starts)
+	const uint64_t chunkTarget = d.fusedChunkBytes ? d.fusedChunkBytes : (1ull << 20);
+	uint32_t logG = 0;
+	while ((fftBytes << (logG + 1)) <= chunkTarget && (1ull << (logG + 1)) <= batch) logG++;
+	const uint64_t G = 1ull << logG;
+	const uint64_t C = (batch + G - 1) / G;
+	const uint64_t tpc = tiles << logG;
+	const uint64_t ringBudget = fftBytes >= (32ull << 20) ? (256ull << 20) : (224ull << 20);
+	const uint64_t wgs = 256ull * (uint64_t)(d.fusedWgPerCu ? d.fusedWgPerCu : v.wgPerCu);
+	uint64_t marginPct = d.fusedMarginPct ? d.fusedMarginPct : (v.wgPerCu >= 2 ? 300 : 200);
+	uint64_t Q = 1, X = 1, D = 1, NS = 1, Cq = C;
+	auto shape = [&](uint64_t q, uint64_t pct) {
+		Q = q; Cq = (C + Q - 1) / Q;
+		X = ((wgs / Q) * pct / 100 + tpc - 1) / tpc;
+		if (X < 1) X = 1;
+		D = d.fusedLag ? d.fusedLag : 1 + X;
+		NS = d.fusedRing ? d.fusedRing : D + 1 + X;
+		if (NS <= D) NS = D + 1;
+		if (NS > Cq) NS = Cq;
+		if (D > Cq) D = Cq;
+		if (NS < 1) NS = 1;
+		return Q * NS * G * fftBytes;
+	};
+	if (d.fusedQueues) (void)shape(std::min<uint64_t>(std::min<uint64_t>(d.fusedQueues, kFusedMaxQueues), C), marginPct);
+	else {
+		const uint64_t q8 = C >= 4 * kFusedMaxQueues ? kFusedMaxQueues : 1;
+		if (shape(q8, marginPct) > ringBudget && q8 > 1) (void)shape(1, marginPct);
+		while (!d.fusedMarginPct && shape(Q, marginPct) > ringBudget && marginPct > 50) marginPct -= 25;
+	}
+	scratch = Q * NS * G * fftBytes;
+	if ((Cq + D) * tpc >= (1ull << 31)) return false; // 32-bit tickets
+	memset(&pp.prm, 0, sizeof(pp.prm));
+	pp.prm.L = (uint32_t)std::min<uint64_t>(M, 0xffffffffu);
+	pp.kernel = KERNEL_MIX_FUSED; pp.variant = v.variant; pp.threads = (uint32_t)v.thr; pp.dp = dp;
+	pp.inElemBytes = pp.outElemBytes = (int)es;
+	pp.label = "4step-fused";
+	pp.lutOff = build_mix_stage_lut(ar, v.radA, dp);
+	pp.fusedLutBOff = build_mix_stage_lut(ar, v.radB, dp);
+	{ // two-level Four-Step table w_M^e = lo[e & mask] * hi[e >> bits], e < M
+		const uint32_t lo = (ceil_log2(M) + 1) / 2;
+		const uint64_t nlo = 1ull << lo, nhi = (M + nlo - 1) / nlo;
+		const size_t off = ar.alloc((nlo + nhi) * es);
+		for (uint64_t i = 0; i < nlo; i++) ar.putc(off, i, unit_root(i, M), dp);
+		for (uint64_t i = 0; i < nhi; i++) ar.putc(off, nlo + i, unit_root(i * nlo, M), dp);
+		pp.auxOff = off; pp.fused.fsLoBits = lo;
+	}
+	pp.fusedCtrOff = ar.alloc((kFusedCtrDone + 2 * C) * sizeof(uint32_t)); // zero in the host image; the kernel leaves it zeroed
+	memset(ar.b.data() + pp.fusedCtrOff, 0, (kFusedCtrDone + 2 * C) * sizeof(uint32_t));
+	FusedParams& f = pp.fused;
+	f.inBatchStride = inS; f.outBatchStride = outS;
+	f.n0 = (uint32_t)n0; f.n1 = (uint32_t)n1; f.batch = (uint32_t)batch;
+	f.logG = logG; f.logTiles = 0; f.tiles = (uint32_t)tiles; f.tpc = (uint32_t)tpc;
+	f.C = (uint32_t)C; f.NS = (uint32_t)NS; f.D = (uint32_t)D; f.Q = (uint32_t)Q;
+	f.swapIn = f.swapOut = inverse ? 1 : 0; f.reverse = 0; f.scale = scale;
+	pp.fusedWgPerCu = (int)d.fusedWgPerCu;
+	return true;
+}
+// the other dimensions of an axis job as ONE batch progression (what a fused launch can follow)
+static bool one_batch_progression(const AxisJob& j, uint64_t& batch, int64_t& inS, int64_t& outS) {
+	batch = 1; inS = (int64_t)j.N; outS = (int64_t)j.N; bool first = true;
+	for (const HostDim& o : j.others) {
+		if (o.count <= 1) continue;
+		if (first) { inS = o.inStride; outS = o.outStride; batch = o.count; first = false; }
+		else { if (o.inStride != inS * (int64_t)batch || o.outStride != outS * (int64_t)batch) return false; batch *= o.count; }
+	}
+	return inS >= (int64_t)j.N && outS >= (int64_t)j.N && batch < (1ull << 31);
+}
+// Returns false when no instance serves the length or the plan does not qualify (the caller emits separate passes).
+static bool emit_mix_fused(const TransformDesc& d, const AxisJob& j, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
+	if (!d.fused || d.disableFastKernels || (j.N & (j.N - 1)) == 0 || j.inStrideJ != 1 || j.outStrideJ != 1) return false;
+	if (const char* e = getenv("VKFFT_MI355X_MIXFUSED")) { if (atoi(e) == 0) return false; }
+	MixFusedShape v;
+	if (!mix_fused_lookup(j.N, j.dp, &v.variant, &v.n0, &v.n1, v.radA, v.radB, &v.tca, &v.tcb, &v.thr, &v.wgPerCu)) return false;
+	uint64_t batch; int64_t inS, outS;
+	if (!one_batch_progression(j, batch, inS, outS)) return false;
+	PassPlan pp; uint64_t scratch = 0;
+	if (!build_mix_fused_pass(d, j.dp, j.N, v, batch, inS, outS, j.inverse, j.scale, ar, pp, scratch)) return false;
+	if (d.userTempBytes && scratch > d.userTempBytes) return false;
+	pp.inRole = j.inRole; pp.outRole = j.outRole;
+	passes.push_back(pp);
+	out.uploadsPerAxis[j.axisIndex] = 2;
+	out.axisSplit[j.axisIndex][0] = (uint64_t)v.n1; out.axisSplit[j.axisIndex][1] = (uint64_t)v.n0;
+	out.tempBytes = std::max<uint64_t>(out.tempBytes, scratch);
+	return true;
+}
+
+static void make_bluestein_tables(uint64_t N, uint64_t M, bool dp, Arena& ar, size_t& chirpOff, size_t& bhatOff, bool oneBlock = false);
+// Chirp-z transform of a length without a Rader or single-pass Bluestein form (unit stride, fp32) as TWO launches of the fused Four-Step kernel on a registered padded
+// length M >= 2N - 1 (kernel_mix_fused.h, MixFusedOps): chirp and zero padding on the first launch's loads, FFT(chirp) / M on its stores into ROLE_TEMP2, the inverse
+// transform with the second chirp on its stores and nothing stored beyond N.  Reference: vkFFT_Scheduler.h:2406-2578 (multi-upload Bluestein), vkFFT_Bluestein.h:32,201.
+constexpr uint64_t kMixFusedBlueQuery = 1ull << 63; // (kernels_mixfused.hip: mix_fused_lookup(n | this) = the smallest chirp-z instance of n points or more)
+static bool emit_mix_fused_blue(const TransformDesc& d, const AxisJob& j, Arena& ar, DirectionPlan& out, std::vector<PassPlan>& passes) {
+	if (!d.fused || d.disableFastKernels || j.dp || j.inStrideJ != 1 || j.outStrideJ != 1 || d.forceBluesteinSize || d.fixMaxRadixBluestein) return false;
+	if (j.inRole == ROLE_TEMP2 || j.outRole == ROLE_TEMP2) return false; // (an inner plan of a wrapped transform: its rows live where this plan keeps its spectrum)
+	if (const char* e = getenv("VKFFT_MI355X_MIXFUSED")) { if (atoi(e) == 0) return false; }
+	const uint64_t N = j.N;
+	MixFusedShape v;
+	if (!mix_fused_lookup((2 * N - 1) | kMixFusedBlueQuery, false, &v.variant, &v.n0, &v.n1, v.radA, v.radB, &v.tca, &v.tcb, &v.thr, &v.wgPerCu)) return false;
+	const uint64_t M = (uint64_t)v.n0 * (uint64_t)v.n1;
+	uint64_t batch; int64_t inS, outS;
+	if (!one_batch_progression(j, batch, inS, outS)) return false;
+	if (batch * M >= (1ull << 40) || N >= (1ull << 31)) return false;
+	size_t chirpOff, bhatOff;
+	make_bluestein_tables(N, M, false, ar, chirpOff, bhatOff, false);
+	PassPlan p1, p2; uint64_t s1 = 0, s2 = 0;
+	if (!build_mix_fused_pass(d, false, M, v, batch, inS, (int64_t)M, false, 1.0, ar, p1, s1)) return false;
+	if (!build_mix_fused_pass(d, false, M, v, batch, (int64_t)M, outS, true, j.scale, ar, p2, s2)) return false;
+	const uint64_t scratch = std::max(s1, s2), mid = batch * M * 8;
+	if (d.userTempBytes && ((scratch + 255ull) & ~255ull) + mid > d.userTempBytes) return false;
+	// (the hooks travel in the pass descriptor's otherwise unused fields: launch_mix_fused)
+	p1.inRole = j.inRole; p1.outRole = ROLE_TEMP2; p1.label = "bluestein2-1";
+	p1.prm.preOp = OP_BLUESTEIN_PRE; p1.prm.postOp = OP_MUL_LUT; p1.prm.opN = (uint32_t)N; p1.prm.bluesteinSwapIn = j.inverse ? 1 : 0;
+	p1.aux3Off = chirpOff; p1.aux2Off = bhatOff;
+	p2.inRole = ROLE_TEMP2; p2.outRole = j.outRole; p2.label = "bluestein2-2";
+	p2.prm.postOp = OP_BLUESTEIN_POST; p2.prm.opN = (uint32_t)N; p2.prm.bluesteinSwapOut = j.inverse ? 1 : 0;
+	p2.aux3Off = chirpOff; p2.aux2Off = bhatOff;
+	passes.push_back(p1); passes.push_back(p2);
+	out.uploadsPerAxis[j.axisIndex] = 2;
+	out.axisSplit[j.axisIndex][0] = (uint64_t)v.n1; out.axisSplit[j.axisIndex][1] = (uint64_t)v.n0;
+	out.tempBytes = std::max<uint64_t>(out.tempBytes, scratch);
+	out.temp2Bytes = std::max<uint64_t>(out.temp2Bytes, mid);
+	return true;
+}
+
 // Four-Step along a NON-unit-stride axis (element stride W, a unit-stride dimension x of extent nx beside it):
 // coalescing comes from x, so no transposition is needed; the decomposition index becomes an extra batch dim.
 //   2 passes: A  FFT over i0 for every (m, x), twiddle w_N^(k0*m)   [in -> T1, same shape]
@@ -1217,7 +1366,7 @@ static int emit_multipass_strided(const PassBuild& proto, uint64_t N, const std:
 
 // Bluestein tables of a length-N transform through padded length M: chirp[n] = exp(+i pi n^2 / N) (the kernels multiply by its
 // conjugate; vkFFT_RecursiveFFTGenerators.h:139-148) and FFT_M of the wrapped chirp, scaled by 1/M.
-static void make_bluestein_tables(uint64_t N, uint64_t M, bool dp, Arena& ar, size_t& chirpOff, size_t& bhatOff, bool oneBlock = false) {
+static void make_bluestein_tables(uint64_t N, uint64_t M, bool dp, Arena& ar, size_t& chirpOff, size_t& bhatOff, bool oneBlock) {
 	const size_t es = dp ? 16 : 8;
 	if (oneBlock) { chirpOff = ar.alloc((N + M) * es); bhatOff = chirpOff + N * es; } // FFT(chirp) right behind the chirp: one pointer serves both
 	else { chirpOff = ar.alloc(N * es); bhatOff = ar.alloc(M * es); }
@@ -1452,6 +1601,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		const uint64_t N = j.N;
 		uint64_t M = fusedM ? fusedM : d.forceBluesteinSize ? d.forceBluesteinSize : next_smooth(2 * N - 1, d.fixMaxRadixBluestein ? d.fixMaxRadixBluestein : 7);
 		uint64_t cap = unit ? rowCap : max_col_len(dp, d.maxLds, 1);
+		if (unit && !fusedM && !padded && 2 * N - 1 > cap && emit_mix_fused_blue(d, j, ar, out, passes)) return 0; // longer than one pass holds: two fused launches
 		if (unit && !fusedM && !d.disableFastKernels && !d.forceBluesteinSize && !d.fixMaxRadixBluestein) {
 			// multi-pass rows: a power-of-two padded length runs as three passes on the column kernels (below)
 			uint64_t Mp = 1; while (Mp < 2 * N - 1) Mp *= 2;
@@ -1691,6 +1841,7 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 
 	// ---- Four-Step on a unit-stride axis: N = n0 * M, recursively M = n1 * n2 -------------------------
 	if (!padded && emit_fused(d, j, ar, out, passes)) return 0;
+	if (!padded && emit_mix_fused(d, j, ar, out, passes)) return 0;
 	std::vector<uint64_t> sp;
 	if (!choose_split(j.N, dp, d.maxLds, dmax, !d.disableFastKernels, sp)) return 3002;
 	if (padded) {
