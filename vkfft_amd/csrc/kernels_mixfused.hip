@@ -10,49 +10,54 @@ namespace vkfft_mi355x {
 
 constexpr int mixf_min(int a, int b) { return a < b ? a : b; }
 // (a0..a3: radices of the first factor n0 — the strided columns of the input —, threads per transform, columns per tile; the same for the second factor; cap on the workgroups per CU)
-#define VKFFT_MXFB(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue) \
+#define VKFFT_MXFB(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue) VKFFT_MXFM(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue, 2)
+#define VKFFT_MXFM(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue, mode) \
 	{ (uint64_t)((a0) * (a1) * (a2) * (a3)) * (uint64_t)((b0) * (b1) * (b2) * (b3)), (a0) * (a1) * (a2) * (a3), (b0) * (b1) * (b2) * (b3), dp, {a0, a1, a2, a3, 1}, {b0, b1, b2, b3, 1}, tpfa, tca, tpfb, tcb, (tpfa) * (tca), \
 	  mixf_min(cap, mixf_wg_per_cu<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tcb>()), blue, \
-	  &mix_fused_launch<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tpfb, tcb, 2, blue>, \
-	  (const void*)&mix_fused_kernel<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tpfb, tcb, 2, blue> }
+	  &mix_fused_launch<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tpfb, tcb, mode, blue>, \
+	  (const void*)&mix_fused_kernel<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tpfb, tcb, mode, blue> }
 #define VKFFT_MXF(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap) VKFFT_MXFB(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, 0)
 // padded lengths of the two-launch chirp-z plan (kernel_mix_fused.h MixFusedOps): the instance with the hooks
 #define VKFFT_MXB(a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap) VKFFT_MXFB(float, false, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, 1)
 
 // first entry of a length is the default; VKFFT_MI355X_MXFV=k selects the k-th shape of a length (tuning)
 static const MixFusedVariant kMixFusedVariants[] = {
-	// powers of three (BASELINE config 3: 3^10 ... 3^15)
-	VKFFT_MXF(float, false, 9, 9, 3, 1, 27, 16, 9, 9, 3, 1, 27, 16, 4),   // 3^10 = 243 x 243
-	VKFFT_MXF(float, false, 9, 9, 3, 1, 27, 24, 9, 9, 9, 1, 81, 8, 4),    // 3^11 = 243 x 729
-	VKFFT_MXF(float, false, 9, 9, 9, 1, 81, 8, 9, 9, 9, 1, 81, 8, 4),     // 3^12 = 729 x 729
-	VKFFT_MXF(float, false, 9, 9, 9, 1, 27, 16, 9, 9, 9, 1, 27, 16, 4),   // ... 16-column tiles (128-byte segments), one workgroup of 432 threads per CU
-	// powers of five (5^6 ... 5^9)
-	VKFFT_MXF(float, false, 5, 5, 5, 1, 25, 16, 5, 5, 5, 1, 25, 16, 4),   // 5^6 = 125 x 125
-	// (625 points as four radix-5 stages: with two radix-25 stages the instance takes 206-256 registers and spills — the table look-ups of 24 twiddles in flight beside a 25-point butterfly)
-	VKFFT_MXF(float, false, 5, 5, 5, 1, 25, 16, 5, 5, 5, 5, 25, 16, 4),   // 5^7 = 125 x 625
-	VKFFT_MXF(float, false, 5, 5, 5, 5, 25, 16, 5, 5, 5, 5, 25, 16, 4),   // 5^8 = 625 x 625
-	// powers of seven (7^6, 7^7)
-	VKFFT_MXF(float, false, 7, 7, 7, 1, 49, 16, 7, 7, 7, 1, 49, 16, 4),   // 7^6 = 343 x 343
-	VKFFT_MXF(float, false, 7, 7, 7, 1, 49, 16, 7, 7, 7, 7, 98, 8, 4),    // 7^7 = 343 x 2401
-	// powers of eleven and thirteen (11^4 ... 11^5, 13^4 ... 13^5)
-	VKFFT_MXF(float, false, 11, 11, 1, 1, 11, 32, 11, 11, 1, 1, 11, 32, 4), // 11^4 = 121 x 121
-	VKFFT_MXF(float, false, 11, 11, 1, 1, 11, 88, 11, 11, 11, 1, 121, 8, 4), // 11^5 = 121 x 1331
-	VKFFT_MXF(float, false, 13, 13, 1, 1, 13, 32, 13, 13, 1, 1, 13, 32, 4), // 13^4 = 169 x 169
-	VKFFT_MXF(float, false, 13, 13, 1, 1, 10, 68, 13, 13, 13, 1, 85, 8, 4), // 13^5 = 169 x 2197
-	// ---- padded lengths M >= 2N - 1 of the chirp-z plan, ascending: the planner takes the smallest that fits.  Powers of two from 2^15 to 2^22 (any prime up to 2^21 has
-	// one), and the 7-smooth lengths right above 2N - 1 of the primes BASELINE config 3 names (15319 -> 30720, 21269 -> 43008, 524309 -> 1049760, 2000083 -> 4014080)
-	VKFFT_MXB(10, 16, 1, 1, 16, 16, 12, 16, 1, 1, 16, 16, 4),   // 30720 = 160 x 192
-	VKFFT_MXB(8, 16, 1, 1, 16, 16, 16, 16, 1, 1, 16, 16, 4),    // 2^15 = 128 x 256
-	VKFFT_MXB(12, 16, 1, 1, 16, 16, 14, 16, 1, 1, 16, 16, 4),   // 43008 = 192 x 224
-	VKFFT_MXB(16, 16, 1, 1, 16, 16, 16, 16, 1, 1, 16, 16, 4),   // 2^16 = 256 x 256
-	VKFFT_MXB(16, 16, 1, 1, 16, 32, 8, 8, 8, 1, 32, 16, 4),     // 2^17 = 256 x 512
-	VKFFT_MXB(8, 8, 8, 1, 32, 16, 8, 8, 8, 1, 32, 16, 4),       // 2^18 = 512 x 512
-	VKFFT_MXB(8, 8, 8, 1, 32, 16, 16, 8, 8, 1, 64, 8, 4),       // 2^19 = 512 x 1024
-	VKFFT_MXB(16, 8, 8, 1, 64, 8, 16, 8, 8, 1, 64, 8, 4),       // 2^20 = 1024 x 1024
-	VKFFT_MXB(12, 9, 9, 1, 54, 8, 12, 10, 9, 1, 54, 8, 4),      // 1049760 = 972 x 1080
-	VKFFT_MXB(16, 8, 8, 1, 128, 8, 16, 16, 8, 1, 128, 8, 4),    // 2^21 = 1024 x 2048
-	VKFFT_MXB(8, 5, 7, 7, 98, 8, 16, 16, 8, 1, 98, 8, 4),       // 4014080 = 1960 x 2048
-	VKFFT_MXB(16, 16, 8, 1, 128, 8, 16, 16, 8, 1, 128, 8, 4),   // 2^22 = 2048 x 2048
+	// Shapes: ONE butterfly per thread and stage wherever the tile width allows it (threads per column = points / smallest radix) — a thread that owns P butterflies
+	// keeps P x radix points live across the exchange barrier, and the instances of the first version with P = 4 ... 7 took 190-256 registers (one or two wavefronts per
+	// SIMD, up to 1 KiB of scratch) where the same factor with P = 1 takes 61-112.
+	// Shapes from the device sweeps (profiles/r06_mix_fused_*): the smaller factor second (its B tile — the segments of the stores to HBM and of the ring loads — is
+	// then 24 ... 88 columns wide where the larger factor's would be 8); 32-column tiles where both factors are short; never two butterflies per thread and stage
+	// (the shapes that doubled the B tile that way lost 20-40 %).
+	// MODE 10: non-temporal loads, PLAIN stores on the HBM side (against non-temporal stores: 5^6 + 4 %, 5^8 + 5 %, 7^6 + 3.5 %, 11^6 + 12 %, the rest within 1 %)
+#define VKFFT_MXF2(a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb) VKFFT_MXFM(float, false, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, 4, 0, 10)
+	// powers of three (BASELINE config 3: 3^10 ... 3^12)
+	VKFFT_MXF2(9, 9, 3, 1, 27, 32, 9, 9, 3, 1, 27, 32),     // 3^10 = 243 x 243
+	VKFFT_MXF2(9, 9, 9, 1, 81, 8, 9, 9, 3, 1, 27, 24),      // 3^11 = 729 x 243
+	VKFFT_MXF2(9, 9, 9, 1, 81, 8, 9, 9, 9, 1, 81, 8),       // 3^12 = 729 x 729
+	// powers of five (5^6 ... 5^8)
+	VKFFT_MXF2(5, 5, 5, 1, 25, 16, 5, 5, 5, 1, 25, 16),     // 5^6 = 125 x 125
+	VKFFT_MXF2(5, 5, 5, 5, 125, 8, 5, 5, 5, 1, 25, 40),     // 5^7 = 625 x 125
+	VKFFT_MXF2(5, 5, 5, 5, 125, 8, 5, 5, 5, 5, 125, 8),     // 5^8 = 625 x 625
+	// powers of seven (7^6)
+	VKFFT_MXF2(7, 7, 7, 1, 49, 16, 7, 7, 7, 1, 49, 16),     // 7^6 = 343 x 343
+	// powers of eleven and thirteen (11^4 ... 11^6, 13^4)
+	VKFFT_MXF2(11, 11, 1, 1, 11, 32, 11, 11, 1, 1, 11, 32), // 11^4 = 121 x 121
+	VKFFT_MXF2(11, 11, 11, 1, 121, 8, 11, 11, 1, 1, 11, 88), // 11^5 = 1331 x 121
+	VKFFT_MXF2(11, 11, 11, 1, 121, 8, 11, 11, 11, 1, 121, 8), // 11^6 = 1331 x 1331
+	VKFFT_MXF2(13, 13, 1, 1, 13, 32, 13, 13, 1, 1, 13, 32), // 13^4 = 169 x 169
+	// (7^7 = 343 x 2401, 13^5 = 169 x 2197: a 2401- or 2197-point column needs four or two butterflies per thread at 8 columns per tile — 250-330 bytes of scratch,
+	// 0.81 TB/s against 1.22 / 1.42 of the separate passes on the device: not instantiated)
+	// ---- padded lengths M >= 2N - 1 of the chirp-z plan, ascending: the planner takes the smallest that fits.  Powers of two from 2^15 to 2^20 and the 7-smooth
+	// lengths right above 2N - 1 of the primes BASELINE config 3 names (15319 -> 30720, 21269 -> 43008, 524309 -> 1049760); radices up to 8 (12 in the last)
+	VKFFT_MXB(8, 5, 4, 1, 32, 16, 8, 8, 3, 1, 32, 16, 4),     // 30720 = 160 x 192
+	VKFFT_MXB(8, 4, 4, 1, 32, 16, 8, 8, 4, 1, 32, 16, 4),     // 2^15 = 128 x 256
+	VKFFT_MXB(8, 8, 3, 1, 32, 16, 8, 7, 4, 1, 32, 16, 4),     // 43008 = 192 x 224
+	VKFFT_MXB(8, 8, 4, 1, 32, 16, 8, 8, 4, 1, 32, 16, 4),     // 2^16 = 256 x 256
+	VKFFT_MXB(8, 8, 4, 1, 32, 32, 8, 8, 8, 1, 64, 16, 4),     // 2^17 = 256 x 512
+	VKFFT_MXB(8, 8, 8, 1, 64, 16, 8, 8, 8, 1, 64, 16, 4),     // 2^18 = 512 x 512
+	VKFFT_MXB(8, 8, 8, 1, 64, 16, 8, 8, 4, 4, 128, 8, 4),     // 2^19 = 512 x 1024
+	VKFFT_MXB(8, 8, 4, 4, 128, 8, 8, 8, 4, 4, 128, 8, 4),     // 2^20 = 1024 x 1024
+	VKFFT_MXB(12, 9, 9, 1, 108, 8, 12, 10, 9, 1, 108, 8, 4),  // 1049760 = 972 x 1080
 };
 // mix_fused_lookup(n | kMixFusedBlueQuery, ...) asks for the smallest chirp-z instance of n points or more (its length = *n0 * *n1)
 constexpr uint64_t kMixFusedBlueQuery = 1ull << 63;

@@ -1181,7 +1181,7 @@ static bool build_mix_fused_pass(const TransformDesc& d, bool dp, uint64_t M, co
 	const uint64_t es = dp ? 16 : 8;
 	const uint64_t n0 = (uint64_t)v.n0, n1 = (uint64_t)v.n1;
 	const uint64_t tilesA = (n1 + (uint64_t)v.tca - 1) / (uint64_t)v.tca, tilesB = (n0 + (uint64_t)v.tcb - 1) / (uint64_t)v.tcb, tiles = std::max(tilesA, tilesB);
-	const uint64_t fftBytes = ((M + 1) & ~1ull) * es; // a transform's share of a ring slot (an even number of elements: 16-byte aligned starts)
+	const uint64_t fftBytes = ((n0 + 15) & ~15ull) * n1 * es; // a transform's share of a ring slot: n1 columns at a pitch of n0 rounded up to 16 elements (kernel_mix_fused.h NAP)
 	const uint64_t chunkTarget = d.fusedChunkBytes ? d.fusedChunkBytes : (1ull << 20);
 	uint32_t logG = 0;
 	while ((fftBytes << (logG + 1)) <= chunkTarget && (1ull << (logG + 1)) <= batch) logG++;
@@ -1276,6 +1276,10 @@ static bool emit_mix_fused_blue(const TransformDesc& d, const AxisJob& j, Arena&
 	if (!d.fused || d.disableFastKernels || j.dp || j.inStrideJ != 1 || j.outStrideJ != 1 || d.forceBluesteinSize || d.fixMaxRadixBluestein) return false;
 	if (j.inRole == ROLE_TEMP2 || j.outRole == ROLE_TEMP2) return false; // (an inner plan of a wrapped transform: its rows live where this plan keeps its spectrum)
 	if (const char* e = getenv("VKFFT_MI355X_MIXFUSED")) { if (atoi(e) == 0) return false; }
+	// Measured on the device (profiles/r06_chirp_z_two_fused_launches_vs_separate_passes.jsonl): correct, and SLOWER than the three / five separate passes on a power of
+	// two it was built to replace (524309: 157 against 256 GB/s, 15319: 530 against 764) — two launches still move the padded sequence through memory four times,
+	// and the instances with the hooks sit at the 128-register cap.  Off unless asked for; what would win is ONE launch with both intermediates in the ring.
+	{ const char* e = getenv("VKFFT_MI355X_MIXFUSED_BLUE"); if (!e || atoi(e) == 0) return false; }
 	const uint64_t N = j.N;
 	MixFusedShape v;
 	if (!mix_fused_lookup((2 * N - 1) | kMixFusedBlueQuery, false, &v.variant, &v.n0, &v.n1, v.radA, v.radB, &v.tca, &v.tcb, &v.thr, &v.wgPerCu)) return false;
