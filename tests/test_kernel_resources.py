@@ -97,6 +97,7 @@ SCRATCH_ALLOWED = [
     ("pow2_col_blue_kernel", 316),
     ("pow2_fused_kernel", 140),                                      # round-2 shapes kept as FUV<k> alternatives, not launched by default
     ("conv_pointwise_kernel<double>", 144),
+    ("mix_fused_kernel", 640),                                       # the nine instances with the chirp-z hooks only (off by default: VKFFT_MI355X_MIXFUSED_BLUE); the eleven that ship: 0 bytes
 ]
 
 
@@ -122,3 +123,5 @@ def test_instances_with_scratch_are_on_the_shrinking_allow_list():
     assert not stale, f"allow-list entries without a spilling instance (delete them): {stale}"
     for fam in ("mixrad_kernel",):
         assert not any(fam in p for p in dem), fam
+    # the fused Four-Step instances of non-power-of-two lengths that ship (template argument BLUE = 0: "..., 10, 0, 4>") carry none
+    assert not any("mix_fused_kernel" in p and ", 0, 4>(" in p for p in dem)

@@ -1,5 +1,6 @@
 """Workload for the rocprofv3 PMC passes (one counter set per pass): a calibration copy of known size, then two forward + inverse pairs of EVERY plan
-bench.py launches (2^8 ... 2^22 on the 1 GiB buffer, default plans), so that tools/summarize_profiles.py can key the traffic by instance."""
+bench.py launches (2^8 ... 2^22 on the 1 GiB buffer, default plans), so that tools/summarize_profiles.py can key the traffic by instance; then the same for the
+fused Four-Step of the non-power-of-two lengths of BASELINE config 3 (kernel_mix_fused.h; 2^25 points each: summary key by_length)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,3 +24,11 @@ for k in ks:
         app.forward(); app.inverse()
     torch.cuda.synchronize()
     app.delete()
+MIX = [59049, 177147, 531441, 15625, 78125, 390625, 117649, 14641, 161051, 1771561, 28561]
+if not sys.argv[1:]:
+    for N in MIX:
+        app = api.App([N], (1 << 25) // N, buffer_ptr=buf.data_ptr(), normalize=True)
+        for _ in range(2):
+            app.forward(); app.inverse()
+        torch.cuda.synchronize()
+        app.delete()

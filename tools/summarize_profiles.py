@@ -48,7 +48,7 @@ for kname, c in cnt.items():
     if "FETCH_SIZE" in c: e["fetch_bytes_corrected"] = c["FETCH_SIZE"] * 1024 * 2
     if "WRITE_SIZE" in c: e["write_bytes"] = c["WRITE_SIZE"] * 1024
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c: e["bytes_per_launch"] = e["fetch_bytes_corrected"] + e["write_bytes"]
-    summ["kernels"][kname[:150]] = e
+    summ["kernels"][kname[:220]] = e
 # the instance of every size: log2 N from the template arguments of the kernel's name (row kernels: the bits of their schedule; fused kernels: the bits of
 # both factors; tiles of two halves: twice the half's bits + the two split flags) — bench.py reads by_log2N[size the roofline names]
 import re
@@ -64,6 +64,19 @@ for kname, e in summ["kernels"].items():
         if "pow2_row_pairs_kernel" in kname: k += 1  # (rows as pairs of samples: the schedule is the half length's)
     summ["by_log2N"][str(k)] = dict(kernel=kname, bytes_per_launch=e["bytes_per_launch"], fetch_bytes_corrected=e["fetch_bytes_corrected"], write_bytes=e["write_bytes"],
                                     algorithmic_bytes_per_transform=2.0 * (1 << 30))
+# the fused Four-Step instances of non-power-of-two lengths (kernel_mix_fused.h): keyed by the length = product of the radices of both factors; tools/pmc_probe.py
+# launches (2^25 // N) transforms of N points each
+summ["by_length"] = {}
+for kname, e in summ["kernels"].items():
+    if "bytes_per_launch" not in e or "mix_fused_kernel" not in kname: continue
+    sch = re.findall(r"MixSched<(\d+), (\d+), (\d+), (\d+), (\d+)>", kname)
+    if len(sch) != 2: continue
+    n = 1
+    for t in sch:
+        for b in t: n *= int(b)
+    alg = 2.0 * 8.0 * n * ((1 << 25) // n)
+    summ["by_length"][str(n)] = dict(kernel=kname, bytes_per_launch=e["bytes_per_launch"], fetch_bytes_corrected=e["fetch_bytes_corrected"], write_bytes=e["write_bytes"],
+                                     algorithmic_bytes_per_launch=alg, ratio=round(e["bytes_per_launch"] / alg, 3))
 for fam in ("pow2_fused_kernel", "pow2_row_kernel", "pow2_col_kernel"):
     ks_ = [k for k in summ["kernels"] if fam in k and "bytes_per_launch" in summ["kernels"][k]]
     if ks_:

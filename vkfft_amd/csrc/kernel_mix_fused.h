@@ -119,8 +119,15 @@ struct MixFusedOps {
 };
 
 // MODE bit 1: non-temporal hint on the HBM side
-template <typename T, typename SA, int TPFA, int TCA, typename SB, int TPFB, int TCB, int MODE, int BLUE>
-__global__ void __launch_bounds__(TPFA * TCA, (mixf_wg_per_cu<T, SA, TPFA, TCA, SB, TCB>() * TPFA * TCA + 255) / 256 > 4 ? 4 : (mixf_wg_per_cu<T, SA, TPFA, TCA, SB, TCB>() * TPFA * TCA + 255) / 256)
+// WGC: workgroups per CU the instance's REGISTER budget is set for through __launch_bounds__ (at most four wavefronts per SIMD: 128 registers).  Measured both ways
+// (profiles/r06_mix_fused_register_budgets.jsonl): budgets of 64-85 registers, which would let two workgroups of 650-1000 threads share a CU, cost 20-144 bytes of
+// scratch and 10-40 % (a reload from scratch drains the wave's one wait counter); the large factors run ONE workgroup per CU, and with the budget of
+// one (WGC = 1: 168 registers) 3^12 gained 11 % over the 128-register build: the compiler keeps more of a tile's requests in flight
+template <typename T, typename SA, int TPFA, int TCA, typename SB, int TCB, int WGC> __host__ __device__ constexpr int mixf_wgc() {
+	return WGC < mixf_wg_per_cu<T, SA, TPFA, TCA, SB, TCB>() ? WGC : mixf_wg_per_cu<T, SA, TPFA, TCA, SB, TCB>();
+}
+template <typename T, typename SA, int TPFA, int TCA, typename SB, int TPFB, int TCB, int MODE, int BLUE, int WGC>
+__global__ void __launch_bounds__(TPFA * TCA, (mixf_wgc<T, SA, TPFA, TCA, SB, TCB, WGC>() * TPFA * TCA + 255) / 256 > 4 ? 4 : (mixf_wgc<T, SA, TPFA, TCA, SB, TCB, WGC>() * TPFA * TCA + 255) / 256)
 mix_fused_kernel(const FusedParams p, const MixFusedOps o) {
 	constexpr int NA = SA::N, NBN = SB::N; // n0 (first factor: strided columns of the input), n1 (second factor)
 	constexpr int NT = TPFA * TCA;
@@ -382,8 +389,8 @@ struct MixFusedVariant {
 	void (*launch)(const FusedParams&, const MixFusedOps&, dim3, hipStream_t);
 	const void* fn;
 };
-template <typename T, typename SA, int TPFA, int TCA, typename SB, int TPFB, int TCB, int MODE, int BLUE> void mix_fused_launch(const FusedParams& prm, const MixFusedOps& ops, dim3 grid, hipStream_t s) {
-	hipLaunchKernelGGL((mix_fused_kernel<T, SA, TPFA, TCA, SB, TPFB, TCB, MODE, BLUE>), grid, dim3(TPFA * TCA), 0, s, prm, ops);
+template <typename T, typename SA, int TPFA, int TCA, typename SB, int TPFB, int TCB, int MODE, int BLUE, int WGC> void mix_fused_launch(const FusedParams& prm, const MixFusedOps& ops, dim3 grid, hipStream_t s) {
+	hipLaunchKernelGGL((mix_fused_kernel<T, SA, TPFA, TCA, SB, TPFB, TCB, MODE, BLUE, WGC>), grid, dim3(TPFA * TCA), 0, s, prm, ops);
 }
 
 } // namespace vkfft_mi355x

@@ -10,12 +10,12 @@ namespace vkfft_mi355x {
 
 constexpr int mixf_min(int a, int b) { return a < b ? a : b; }
 // (a0..a3: radices of the first factor n0 — the strided columns of the input —, threads per transform, columns per tile; the same for the second factor; cap on the workgroups per CU)
-#define VKFFT_MXFB(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue) VKFFT_MXFM(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue, 2)
-#define VKFFT_MXFM(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue, mode) \
+#define VKFFT_MXFB(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue) VKFFT_MXFM(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue, 2, 4)
+#define VKFFT_MXFM(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue, mode, wgc) \
 	{ (uint64_t)((a0) * (a1) * (a2) * (a3)) * (uint64_t)((b0) * (b1) * (b2) * (b3)), (a0) * (a1) * (a2) * (a3), (b0) * (b1) * (b2) * (b3), dp, {a0, a1, a2, a3, 1}, {b0, b1, b2, b3, 1}, tpfa, tca, tpfb, tcb, (tpfa) * (tca), \
 	  mixf_min(cap, mixf_wg_per_cu<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tcb>()), blue, \
-	  &mix_fused_launch<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tpfb, tcb, mode, blue>, \
-	  (const void*)&mix_fused_kernel<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tpfb, tcb, mode, blue> }
+	  &mix_fused_launch<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tpfb, tcb, mode, blue, wgc>, \
+	  (const void*)&mix_fused_kernel<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tpfb, tcb, mode, blue, wgc> }
 #define VKFFT_MXF(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap) VKFFT_MXFB(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, 0)
 // padded lengths of the two-launch chirp-z plan (kernel_mix_fused.h MixFusedOps): the instance with the hooks
 #define VKFFT_MXB(a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap) VKFFT_MXFB(float, false, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, 1)
@@ -29,22 +29,24 @@ static const MixFusedVariant kMixFusedVariants[] = {
 	// then 24 ... 88 columns wide where the larger factor's would be 8); 32-column tiles where both factors are short; never two butterflies per thread and stage
 	// (the shapes that doubled the B tile that way lost 20-40 %).
 	// MODE 10: non-temporal loads, PLAIN stores on the HBM side (against non-temporal stores: 5^6 + 4 %, 5^8 + 5 %, 7^6 + 3.5 %, 11^6 + 12 %, the rest within 1 %)
-#define VKFFT_MXF2(a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb) VKFFT_MXFM(float, false, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, 4, 0, 10)
+	// last argument: workgroups per CU the launch and the planner's lag reckon with — 1 where the registers hold one workgroup per CU anyway (650 threads x 110-128
+	// registers): with 3 the ring's lag was sized for workgroups that never become resident, and 3^12 lost 10 % to the longer fill and drain of its queues
+#define VKFFT_MXF2(a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap) VKFFT_MXFM(float, false, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, 0, 10, 4)
 	// powers of three (BASELINE config 3: 3^10 ... 3^12)
-	VKFFT_MXF2(9, 9, 3, 1, 27, 32, 9, 9, 3, 1, 27, 32),     // 3^10 = 243 x 243
-	VKFFT_MXF2(9, 9, 9, 1, 81, 8, 9, 9, 3, 1, 27, 24),      // 3^11 = 729 x 243
-	VKFFT_MXF2(9, 9, 9, 1, 81, 8, 9, 9, 9, 1, 81, 8),       // 3^12 = 729 x 729
+	VKFFT_MXF2(9, 9, 3, 1, 27, 32, 9, 9, 3, 1, 27, 32, 4),     // 3^10 = 243 x 243
+	VKFFT_MXF2(9, 9, 9, 1, 81, 8, 9, 9, 3, 1, 27, 24, 1),      // 3^11 = 729 x 243
+	VKFFT_MXF2(9, 9, 9, 1, 81, 8, 9, 9, 9, 1, 81, 8, 1),       // 3^12 = 729 x 729
 	// powers of five (5^6 ... 5^8)
-	VKFFT_MXF2(5, 5, 5, 1, 25, 16, 5, 5, 5, 1, 25, 16),     // 5^6 = 125 x 125
-	VKFFT_MXF2(5, 5, 5, 5, 125, 8, 5, 5, 5, 1, 25, 40),     // 5^7 = 625 x 125
-	VKFFT_MXF2(5, 5, 5, 5, 125, 8, 5, 5, 5, 5, 125, 8),     // 5^8 = 625 x 625
+	VKFFT_MXF2(5, 5, 5, 1, 25, 16, 5, 5, 5, 1, 25, 16, 4),     // 5^6 = 125 x 125
+	VKFFT_MXF2(5, 5, 5, 5, 125, 8, 5, 5, 5, 1, 25, 40, 4),     // 5^7 = 625 x 125
+	VKFFT_MXF2(5, 5, 5, 5, 125, 8, 5, 5, 5, 5, 125, 8, 4),     // 5^8 = 625 x 625
 	// powers of seven (7^6)
-	VKFFT_MXF2(7, 7, 7, 1, 49, 16, 7, 7, 7, 1, 49, 16),     // 7^6 = 343 x 343
+	VKFFT_MXF2(7, 7, 7, 1, 49, 16, 7, 7, 7, 1, 49, 16, 4),     // 7^6 = 343 x 343
 	// powers of eleven and thirteen (11^4 ... 11^6, 13^4)
-	VKFFT_MXF2(11, 11, 1, 1, 11, 32, 11, 11, 1, 1, 11, 32), // 11^4 = 121 x 121
-	VKFFT_MXF2(11, 11, 11, 1, 121, 8, 11, 11, 1, 1, 11, 88), // 11^5 = 1331 x 121
-	VKFFT_MXF2(11, 11, 11, 1, 121, 8, 11, 11, 11, 1, 121, 8), // 11^6 = 1331 x 1331
-	VKFFT_MXF2(13, 13, 1, 1, 13, 32, 13, 13, 1, 1, 13, 32), // 13^4 = 169 x 169
+	VKFFT_MXF2(11, 11, 1, 1, 11, 32, 11, 11, 1, 1, 11, 32, 4), // 11^4 = 121 x 121
+	VKFFT_MXF2(11, 11, 11, 1, 121, 8, 11, 11, 1, 1, 11, 88, 4), // 11^5 = 1331 x 121
+	VKFFT_MXF2(11, 11, 11, 1, 121, 8, 11, 11, 11, 1, 121, 8, 4), // 11^6 = 1331 x 1331
+	VKFFT_MXF2(13, 13, 1, 1, 13, 32, 13, 13, 1, 1, 13, 32, 4), // 13^4 = 169 x 169
 	// (7^7 = 343 x 2401, 13^5 = 169 x 2197: a 2401- or 2197-point column needs four or two butterflies per thread at 8 columns per tile — 250-330 bytes of scratch,
 	// 0.81 TB/s against 1.22 / 1.42 of the separate passes on the device: not instantiated)
 	// ---- padded lengths M >= 2N - 1 of the chirp-z plan, ascending: the planner takes the smallest that fits.  Powers of two from 2^15 to 2^20 and the 7-smooth
