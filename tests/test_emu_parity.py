@@ -395,10 +395,11 @@ def test_fused_fourstep_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
 
 
-@pytest.mark.parametrize("N,batch", [(59049, 3), (177147, 2), (531441, 1), (15625, 5), (78125, 3), (390625, 1), (117649, 2), (14641, 5), (161051, 2), (1771561, 1), (28561, 3)])
-def test_fused_fourstep_of_non_power_of_two_lengths(run, oracle, N, batch):
+@pytest.mark.parametrize("N,batch", [(59049, 3), (177147, 2), (531441, 1), (15625, 5), (78125, 3), (390625, 1), (16807, 5), (117649, 2), (14641, 5), (161051, 2), (1771561, 1), (28561, 3)])
+def test_fused_fourstep_of_non_power_of_two_lengths(run, oracle, monkeypatch, N, batch):
     """fused Four-Step of two mixed-radix factors (kernel_mix_fused.h): every registered length of BASELINE config 3's powers of 3, 5, 7, 11 and 13 — partial last
     tiles of either phase (243 = 15 x 16 + 3 columns), phases with different tile counts, one launch per direction"""
+    monkeypatch.setenv("VKFFT_MI355X_LONGROWS", "0")  # (11^4, 5^6, 7^5 run as ONE pass of the long mixed-radix rows by default: test_long_mixed_radix_rows_in_one_pass)
     x = parity.seeded_complex(N * batch, False, N + batch)
     y, z, up = run.transform(x, (N,), batch, both=True)
     assert up == [2]
@@ -412,6 +413,22 @@ def test_fused_fourstep_of_non_power_of_two_lengths(run, oracle, N, batch):
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
 
 
+@pytest.mark.parametrize("N,batch", [(9000, 3), (10000, 2), (10240, 3), (12000, 2), (12288, 3), (14641, 3), (15000, 2), (15360, 3), (15625, 2), (16000, 2), (16807, 3)])
+def test_long_mixed_radix_rows_in_one_pass(run, oracle, N, batch):
+    """9000 ... 16000, 11^4, 5^6, 7^5: one pass of mixed_row_kernel with the whole row in one LDS buffer (mixed_table_6.inc; two butterflies per thread for 11^4, three for 7^5), where the
+    generated table stops at 8192 points and the Four-Step plan takes two passes"""
+    x = parity.seeded_complex(N * batch, False, N + batch)
+    y, z, up = run.transform(x, (N,), batch, both=True)
+    assert up == [1]
+    h, ptr = run._alloc(x)
+    app = api.App([N], batch, buffer_ptr=ptr, lib=run.lib)
+    n, names = app.launch_info(False)
+    app.delete()
+    assert n == 1 and names.startswith("mixed_row_kernel"), (n, names)
+    assert rel_l2(y, oracle.truth_c2c(x, (N,), batch)) < 1e-6
+    assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
+
+
 @pytest.mark.parametrize("N,batch,chunk_kib,lag,ring,queues,shape", [(59049, 7, 512, 2, 3, 1, 0), (59049, 11, 1024, 1, 2, 4, 0), (15625, 37, 256, 2, 3, 8, 0), (15625, 21, 128, 1, 2, 3, 0),
                                                                      (14641, 19, 256, 3, 5, 8, 0), (531441, 3, 4096, 1, 2, 1, 0), (177147, 5, 2048, 1, 2, 2, 0), (78125, 7, 512, 2, 3, 3, 0)])
 def test_fused_fourstep_of_non_power_of_two_lengths_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag, ring, queues, shape):
@@ -422,6 +439,7 @@ def test_fused_fourstep_of_non_power_of_two_lengths_queue(run, oracle, monkeypat
     monkeypatch.setenv("VKFFT_MI355X_FUSED_RING", str(ring))
     monkeypatch.setenv("VKFFT_MI355X_FUSED_QUEUES", str(queues))
     monkeypatch.setenv("VKFFT_MI355X_MXFV", str(shape))
+    monkeypatch.setenv("VKFFT_MI355X_LONGROWS", "0")
     x = parity.seeded_complex(N * batch, False, N + batch)
     y, z, up = run.transform(x, (N,), batch, both=True)
     assert up == [2]

@@ -340,10 +340,11 @@ def test_radix_multi_pass(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 2, False, use_c_oracle=False)
 
 
-@pytest.mark.parametrize("N,batch", [(59049, 9), (177147, 5), (531441, 3), (15625, 70), (78125, 13), (390625, 3), (117649, 9), (14641, 73), (161051, 7), (1771561, 2), (28561, 37)])
+@pytest.mark.parametrize("N,batch", [(59049, 9), (177147, 5), (531441, 3), (15625, 70), (78125, 13), (390625, 3), (16807, 61), (117649, 9), (14641, 73), (161051, 7), (1771561, 2), (28561, 37)])
 def test_fused_fourstep_of_non_power_of_two_lengths_on_device(run, oracle, product_lib, monkeypatch, N, batch):
     """kernel_mix_fused.h on the device: every registered length against the double truth, ONE launch per direction, and against the separate Four-Step passes
     it replaces (VKFFT_MI355X_MIXFUSED=0: the same factors in the same order, so the two agree to rounding)"""
+    monkeypatch.setenv("VKFFT_MI355X_LONGROWS", "0")  # (11^4, 5^6, 7^5 run as ONE pass by default: test_long_mixed_radix_rows_in_one_pass_on_device)
     x = parity.seeded_complex(N * batch, False, N + batch)
     y, z, up = run.transform(x, (N,), batch, both=True)
     assert up == [2]
@@ -359,6 +360,25 @@ def test_fused_fourstep_of_non_power_of_two_lengths_on_device(run, oracle, produ
     assert rel_l2(y, y2.astype(np.complex128)) < 5e-7
 
 
+@pytest.mark.parametrize("N,batch", [(9000, 400), (10000, 301), (10240, 257), (12000, 300), (12288, 259), (14641, 517), (15000, 263), (15360, 257), (15625, 301), (16000, 263), (16807, 259)])
+def test_long_mixed_radix_rows_in_one_pass_on_device(run, oracle, product_lib, monkeypatch, N, batch):
+    """11^4, 5^6, 7^5 as ONE pass of mixed_row_kernel (mixed_table_6.inc: the whole row in one LDS buffer of 117-151 KB), chip-filling batches, against the double truth,
+    the round trip and the fused Four-Step launch of the same length (VKFFT_MI355X_LONGROWS=0)"""
+    x = parity.seeded_complex(N * batch, False, N + batch)
+    y, z, up = run.transform(x, (N,), batch, both=True)
+    assert up == [1]
+    h, ptr = run._alloc(x)
+    app = api.App([N], batch, buffer_ptr=ptr, lib=product_lib)
+    n, names = app.launch_info(False)
+    app.delete()
+    assert n == 1 and names.startswith("mixed_row_kernel"), (n, names)
+    assert rel_l2(y, oracle.truth_c2c(x, (N,), batch)) < 1e-6
+    assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
+    monkeypatch.setenv("VKFFT_MI355X_LONGROWS", "0")  # (the fused Four-Step launch for the three lengths that have one, the separate passes for the rest)
+    y2, up2 = run.transform(x, (N,), batch)
+    assert up2 == [2] and rel_l2(y, y2.astype(np.complex128)) < 5e-7
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("N,queues,lag,ring", [(59049, 3, 1, 4), (59049, 8, 0, 0), (390625, 5, 1, 4), (161051, 7, 1, 3), (14641, 6, 1, 4)])
 def test_fused_fourstep_of_non_power_of_two_lengths_many_launches(product_lib, monkeypatch, N, queues, lag, ring):
@@ -368,6 +388,7 @@ def test_fused_fourstep_of_non_power_of_two_lengths_many_launches(product_lib, m
     if lag:
         monkeypatch.setenv("VKFFT_MI355X_FUSED_LAG", str(lag)); monkeypatch.setenv("VKFFT_MI355X_FUSED_RING", str(ring))
     monkeypatch.setenv("VKFFT_MI355X_FUSED_QUEUES", str(queues))
+    monkeypatch.setenv("VKFFT_MI355X_LONGROWS", "0")
     B = (1 << 26) // N
     g = torch.Generator(device="cuda"); g.manual_seed(11)
     x = torch.empty(2 * N * B, dtype=torch.float32, device="cuda").uniform_(-1, 1, generator=g)

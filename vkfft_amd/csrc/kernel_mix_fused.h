@@ -126,8 +126,10 @@ struct MixFusedOps {
 template <typename T, typename SA, int TPFA, int TCA, typename SB, int TCB, int WGC> __host__ __device__ constexpr int mixf_wgc() {
 	return WGC < mixf_wg_per_cu<T, SA, TPFA, TCA, SB, TCB>() ? WGC : mixf_wg_per_cu<T, SA, TPFA, TCA, SB, TCB>();
 }
-template <typename T, typename SA, int TPFA, int TCA, typename SB, int TPFB, int TCB, int MODE, int BLUE, int WGC>
-__global__ void __launch_bounds__(TPFA * TCA, (mixf_wgc<T, SA, TPFA, TCA, SB, TCB, WGC>() * TPFA * TCA + 255) / 256 > 4 ? 4 : (mixf_wgc<T, SA, TPFA, TCA, SB, TCB, WGC>() * TPFA * TCA + 255) / 256)
+// PIPE = 1: software-pipelined tickets (the other tile's memory traffic in flight while one computes: two tiles' first-stage inputs live at a time);
+// PIPE = 0: one tile at a time (12-20 registers fewer: for the shapes whose register count decides whether TWO workgroups share a CU — they overlap each other instead)
+template <typename T, typename SA, int TPFA, int TCA, typename SB, int TPFB, int TCB, int MODE, int BLUE, int WGC, int PIPE = 1>
+__global__ void __launch_bounds__(TPFA * TCA, (mixf_wgc<T, SA, TPFA, TCA, SB, TCB, WGC>() * TPFA * TCA + 255) / 256 > (PIPE ? 4 : 8) ? (PIPE ? 4 : 8) : (mixf_wgc<T, SA, TPFA, TCA, SB, TCB, WGC>() * TPFA * TCA + 255) / 256)
 mix_fused_kernel(const FusedParams p, const MixFusedOps o) {
 	constexpr int NA = SA::N, NBN = SB::N; // n0 (first factor: strided columns of the input), n1 (second factor)
 	constexpr int NT = TPFA * TCA;
@@ -226,7 +228,7 @@ mix_fused_kernel(const FusedParams p, const MixFusedOps o) {
 	if (tid == 0) draw(0);
 	uint32_t it = 0;
 	VKFFT_SYNC();
-	requestA(sTicket[0]); // invariant at the head of the loop: the A tile of the ticket about to be read has been requested
+	if constexpr (PIPE != 0) requestA(sTicket[0]); // invariant at the head of the loop: the A tile of the ticket about to be read has been requested
 	for (;;) {
 		VKFFT_SYNC(); // S1: ticket visible; exchange buffer free again
 		const uint32_t t = sTicket[it];
@@ -239,7 +241,7 @@ mix_fused_kernel(const FusedParams p, const MixFusedOps o) {
 			totq = Cq ? (Cq + p.D) * TPC : 0u;
 			if (tid == 0) draw(it);
 			VKFFT_SYNC();
-			requestA(sTicket[it]);
+			if constexpr (PIPE != 0) requestA(sTicket[it]);
 			continue;
 		}
 		const uint32_t okA = sOkA[it], okB = sOkB[it];
@@ -257,7 +259,7 @@ mix_fused_kernel(const FusedParams p, const MixFusedOps o) {
 		const uint32_t laneB = (liveB && k00 + cB < (uint32_t)NA) ? cB * ES : kGbInvalid;
 		if (hasB && !okB) fused_wait(p.ctr + depB(s), TPC); // rare (the flag was sampled one ticket ago: ordered before these loads by S1)
 		cx<T> xb[P0B][R0B];
-		{
+		auto requestB = [&]() {
 			const char* const sbaseB = (const char*)p.scratch + ((uint64_t)(((q * p.NS + (hasB ? sB % p.NS : 0u)) << p.logG) + f) * nPts) * ES;
 			const GBuf gsB = make_gbuf(sbaseB + (uint64_t)(liveB ? k00 : 0u) * ES);
 #pragma unroll
@@ -268,7 +270,8 @@ mix_fused_kernel(const FusedParams p, const MixFusedOps o) {
 					for (int i = 0; i < R0B; i++) xb[bb][i] = gb_load_x<T, AUX_SC>(gsB, laneB + t2 * NAP * ES, (uint32_t)(i * NB0B) * NAP * ES + oz);
 				}
 			}
-		}
+		};
+		if constexpr (PIPE != 0) requestB(); else requestA(t);
 		// ---- A: FFT over n0 of TCA neighbouring columns (stride n1), twiddle, per-column contiguous stores into the ring
 		const uint32_t chA = q + Q * s; // chunk in processing order (counters, ring slot)
 		const uint32_t bA = ((p.reverse ? p.C - 1u - chA : chA) << p.logG) + f;
@@ -328,6 +331,7 @@ mix_fused_kernel(const FusedParams p, const MixFusedOps o) {
 				for (uint32_t e0 = tid; e0 < lim; e0 += (uint32_t)NT) { const uint32_t c2 = e0 / (uint32_t)NA, k = e0 - c2 * (uint32_t)NA; gb_store_x<T, AUX_ST>(gs, (c2 * NAP + k) * ES, 0, elem(c2, k)); }
 			}
 		}
+		if constexpr (PIPE == 0) requestB();
 		VKFFT_VMEM_DRAIN();     // this wave: B tile in registers, ring stores acknowledged by the memory side
 		if (tid == 0) draw(it); // next ticket + the state of its dependencies (read after S1 of the next iteration)
 		VKFFT_SYNC();           // S3: ... in every wave; the exchange buffer is free
@@ -335,7 +339,7 @@ mix_fused_kernel(const FusedParams p, const MixFusedOps o) {
 			if (hasA) (void)VKFFT_ATOMIC_ADD_U32(p.ctr + doneA + chA, 1u); // the chunk's tile is in the ring
 			if (hasB) (void)VKFFT_ATOMIC_ADD_U32(p.ctr + doneB + chB, 1u); // the ring slot's tile has been read
 		}
-		requestA(sTicket[it]); // the A tile of the next ticket travels while the B tile computes
+		if constexpr (PIPE != 0) requestA(sTicket[it]); // the A tile of the next ticket travels while the B tile computes
 		if (liveB) {
 			// ---- B: FFT over n1 of TCB neighbouring k0, natural-order store X[k0 + n0 * k1] straight from the last stage
 			const GBuf gout = make_gbuf((cx<T>*)p.out + ((int64_t)bB * p.outBatchStride + k00));
@@ -389,8 +393,8 @@ struct MixFusedVariant {
 	void (*launch)(const FusedParams&, const MixFusedOps&, dim3, hipStream_t);
 	const void* fn;
 };
-template <typename T, typename SA, int TPFA, int TCA, typename SB, int TPFB, int TCB, int MODE, int BLUE, int WGC> void mix_fused_launch(const FusedParams& prm, const MixFusedOps& ops, dim3 grid, hipStream_t s) {
-	hipLaunchKernelGGL((mix_fused_kernel<T, SA, TPFA, TCA, SB, TPFB, TCB, MODE, BLUE, WGC>), grid, dim3(TPFA * TCA), 0, s, prm, ops);
+template <typename T, typename SA, int TPFA, int TCA, typename SB, int TPFB, int TCB, int MODE, int BLUE, int WGC, int PIPE = 1> void mix_fused_launch(const FusedParams& prm, const MixFusedOps& ops, dim3 grid, hipStream_t s) {
+	hipLaunchKernelGGL((mix_fused_kernel<T, SA, TPFA, TCA, SB, TPFB, TCB, MODE, BLUE, WGC, PIPE>), grid, dim3(TPFA * TCA), 0, s, prm, ops);
 }
 
 } // namespace vkfft_mi355x

@@ -66,16 +66,17 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 }
 
 // ---- mixed-radix registry: six table parts, one translation unit each (kernels_mixed_*.hip) --------------------
-constexpr int kMixedParts = 6;
+constexpr int kMixedParts = 7; // (part 6: the hand-written long rows, mixed_table_6.inc)
 const MixedVariant* mixed_table_0(int*);
 const MixedVariant* mixed_table_1(int*);
 const MixedVariant* mixed_table_2(int*);
 const MixedVariant* mixed_table_3(int*);
 const MixedVariant* mixed_table_4(int*);
 const MixedVariant* mixed_table_5(int*);
+const MixedVariant* mixed_table_6(int*);
 static const MixedVariant* mixed_part(int part, int* count) {
 	typedef const MixedVariant* (*Fn)(int*);
-	static const Fn fns[kMixedParts] = {&mixed_table_0, &mixed_table_1, &mixed_table_2, &mixed_table_3, &mixed_table_4, &mixed_table_5};
+	static const Fn fns[kMixedParts] = {&mixed_table_0, &mixed_table_1, &mixed_table_2, &mixed_table_3, &mixed_table_4, &mixed_table_5, &mixed_table_6};
 	return fns[part % kMixedParts](count);
 }
 bool mixed_row_lookup(uint64_t n, bool dp, int* variant, int rad[5], int* fpw, int* threads) {

@@ -11,11 +11,12 @@ namespace vkfft_mi355x {
 constexpr int mixf_min(int a, int b) { return a < b ? a : b; }
 // (a0..a3: radices of the first factor n0 — the strided columns of the input —, threads per transform, columns per tile; the same for the second factor; cap on the workgroups per CU)
 #define VKFFT_MXFB(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue) VKFFT_MXFM(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue, 2, 4)
-#define VKFFT_MXFM(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue, mode, wgc) \
+#define VKFFT_MXFM(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue, mode, wgc) VKFFT_MXFP(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue, mode, wgc, 1)
+#define VKFFT_MXFP(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, blue, mode, wgc, pipe) \
 	{ (uint64_t)((a0) * (a1) * (a2) * (a3)) * (uint64_t)((b0) * (b1) * (b2) * (b3)), (a0) * (a1) * (a2) * (a3), (b0) * (b1) * (b2) * (b3), dp, {a0, a1, a2, a3, 1}, {b0, b1, b2, b3, 1}, tpfa, tca, tpfb, tcb, (tpfa) * (tca), \
 	  mixf_min(cap, mixf_wg_per_cu<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tcb>()), blue, \
-	  &mix_fused_launch<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tpfb, tcb, mode, blue, wgc>, \
-	  (const void*)&mix_fused_kernel<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tpfb, tcb, mode, blue, wgc> }
+	  &mix_fused_launch<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tpfb, tcb, mode, blue, wgc, pipe>, \
+	  (const void*)&mix_fused_kernel<T, MixSched<a0, a1, a2, a3, 1>, tpfa, tca, MixSched<b0, b1, b2, b3, 1>, tpfb, tcb, mode, blue, wgc, pipe> }
 #define VKFFT_MXF(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap) VKFFT_MXFB(T, dp, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, 0)
 // padded lengths of the two-launch chirp-z plan (kernel_mix_fused.h MixFusedOps): the instance with the hooks
 #define VKFFT_MXB(a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap) VKFFT_MXFB(float, false, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, 1)
@@ -34,13 +35,14 @@ static const MixFusedVariant kMixFusedVariants[] = {
 #define VKFFT_MXF2(a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap) VKFFT_MXFM(float, false, a0, a1, a2, a3, tpfa, tca, b0, b1, b2, b3, tpfb, tcb, cap, 0, 10, 4)
 	// powers of three (BASELINE config 3: 3^10 ... 3^12)
 	VKFFT_MXF2(9, 9, 3, 1, 27, 32, 9, 9, 3, 1, 27, 32, 4),     // 3^10 = 243 x 243
-	VKFFT_MXF2(9, 9, 9, 1, 81, 8, 9, 9, 3, 1, 27, 24, 1),      // 3^11 = 729 x 243
+	VKFFT_MXFP(float, false, 9, 9, 9, 1, 81, 8, 9, 9, 3, 1, 27, 24, 2, 0, 10, 2, 0), // 3^11 = 729 x 243 — one tile at a time, two workgroups per CU (+ 6 / + 13 % over the pipelined form)
 	VKFFT_MXF2(9, 9, 9, 1, 81, 8, 9, 9, 9, 1, 81, 8, 1),       // 3^12 = 729 x 729
 	// powers of five (5^6 ... 5^8)
 	VKFFT_MXF2(5, 5, 5, 1, 25, 16, 5, 5, 5, 1, 25, 16, 4),     // 5^6 = 125 x 125
-	VKFFT_MXF2(5, 5, 5, 5, 125, 8, 5, 5, 5, 1, 25, 40, 4),     // 5^7 = 625 x 125
+	VKFFT_MXFP(float, false, 5, 5, 5, 5, 125, 8, 5, 5, 5, 1, 25, 40, 2, 0, 10, 2, 0), // 5^7 = 625 x 125 — one tile at a time, two workgroups per CU (+ 6 / + 13 % over the pipelined form)
 	VKFFT_MXF2(5, 5, 5, 5, 125, 8, 5, 5, 5, 5, 125, 8, 4),     // 5^8 = 625 x 625
-	// powers of seven (7^6)
+	// powers of seven (7^5, 7^6)
+	VKFFT_MXF2(7, 7, 7, 1, 49, 13, 7, 7, 1, 1, 7, 91, 4),      // 7^5 = 343 x 49 (four tiles of 13 columns / of 91)
 	VKFFT_MXF2(7, 7, 7, 1, 49, 16, 7, 7, 7, 1, 49, 16, 4),     // 7^6 = 343 x 343
 	// powers of eleven and thirteen (11^4 ... 11^6, 13^4)
 	VKFFT_MXF2(11, 11, 1, 1, 11, 32, 11, 11, 1, 1, 11, 32, 4), // 11^4 = 121 x 121

@@ -1798,7 +1798,15 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
 		p2rowOK = (rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && pow2_row_lookup(ilog2(j.N), dp, &variant, bits, &fpw, &thr, padded);
 	}
-	if (j.N <= singleCap || p2rowOK) {
+	// ... and the hand-written long rows of the mixed-radix family (mixed_table_6.inc: 11^4, 5^6, 7^5 in ONE LDS buffer of 117-151 KB, one workgroup per CU): one pass where
+	// the Four-Step plan would take two (VKFFT_MI355X_LONGROWS=0: the fused Four-Step launch of kernel_mix_fused.h instead)
+	bool mixLongOK = false;
+	if (unit && !padded && !dp && !d.disableFastKernels && (j.N & (j.N - 1)) != 0 && j.N > singleCap && j.N <= 16807 && !(getenv("VKFFT_MI355X_LONGROWS") && atoi(getenv("VKFFT_MI355X_LONGROWS")) == 0)) {
+		int variant, rad5[5], fpw, thr;
+		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
+		mixLongOK = (rowPitch * 64 + j.N) * 8 < 0x7FFFFF00ull && mixed_row_lookup(j.N, dp, &variant, rad5, &fpw, &thr);
+	}
+	if (j.N <= singleCap || p2rowOK || mixLongOK) {
 		b.L = j.N;
 		if (unit && !padded && !d.disableFastKernels && ((j.N & (j.N - 1)) != 0 || j.N == 2)) { // curated non-power-of-two lengths (and N = 2): hand-specialised mixed-radix kernel
 			int variant, rad5[5], fpw, thr;
