@@ -110,7 +110,7 @@ def _largest_prime_with_padded_length(M):
     return n
 
 
-@pytest.mark.parametrize("M", [30720, 1 << 15, 43008, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1049760])
+@pytest.mark.parametrize("M", [30720, 43008, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1049760])
 def test_chirp_z_in_two_fused_launches_every_padded_length(run, oracle, monkeypatch, M):
     """every registered padded length of the two-launch chirp-z plan (kernels_mixfused.hip, the instances with the hooks): the largest prime N with 2N - 1 <= M, forward
     against the double truth and the round trip (chirp and zero padding on the first launch's loads, FFT(chirp) on its stores, second chirp and the write mask on the
@@ -395,7 +395,7 @@ def test_fused_fourstep_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
 
 
-@pytest.mark.parametrize("N,batch", [(59049, 3), (177147, 2), (531441, 1), (15625, 5), (78125, 3), (390625, 1), (16807, 5), (117649, 2), (14641, 5), (161051, 2), (1771561, 1), (28561, 3)])
+@pytest.mark.parametrize("N,batch", [(59049, 3), (177147, 2), (531441, 1), (78125, 3), (390625, 1), (117649, 2), (161051, 2), (1771561, 1), (28561, 3)])
 def test_fused_fourstep_of_non_power_of_two_lengths(run, oracle, monkeypatch, N, batch):
     """fused Four-Step of two mixed-radix factors (kernel_mix_fused.h): every registered length of BASELINE config 3's powers of 3, 5, 7, 11 and 13 — partial last
     tiles of either phase (243 = 15 x 16 + 3 columns), phases with different tile counts, one launch per direction"""
@@ -429,8 +429,7 @@ def test_long_mixed_radix_rows_in_one_pass(run, oracle, N, batch):
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
 
 
-@pytest.mark.parametrize("N,batch,chunk_kib,lag,ring,queues,shape", [(59049, 7, 512, 2, 3, 1, 0), (59049, 11, 1024, 1, 2, 4, 0), (15625, 37, 256, 2, 3, 8, 0), (15625, 21, 128, 1, 2, 3, 0),
-                                                                     (14641, 19, 256, 3, 5, 8, 0), (531441, 3, 4096, 1, 2, 1, 0), (177147, 5, 2048, 1, 2, 2, 0), (78125, 7, 512, 2, 3, 3, 0)])
+@pytest.mark.parametrize("N,batch,chunk_kib,lag,ring,queues,shape", [(59049, 7, 512, 2, 3, 1, 0), (59049, 11, 1024, 1, 2, 4, 0), (28561, 37, 256, 2, 3, 8, 0), (28561, 21, 128, 1, 2, 3, 0), (531441, 3, 4096, 1, 2, 1, 0), (177147, 5, 2048, 1, 2, 2, 0), (78125, 7, 512, 2, 3, 3, 0)])
 def test_fused_fourstep_of_non_power_of_two_lengths_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag, ring, queues, shape):
     """the same kernel under forced chunk sizes, lags, rings and queue counts (ring slots reused, a partial last chunk, queues that are helped, the reversed sweep of
     the inverse), and against the separate passes it replaces (VKFFT_MI355X_MIXFUSED=0)"""

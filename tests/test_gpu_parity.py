@@ -340,7 +340,7 @@ def test_radix_multi_pass(run, oracle, N):
     parity.check_c2c(run, oracle, (N,), 2, False, use_c_oracle=False)
 
 
-@pytest.mark.parametrize("N,batch", [(59049, 9), (177147, 5), (531441, 3), (15625, 70), (78125, 13), (390625, 3), (16807, 61), (117649, 9), (14641, 73), (161051, 7), (1771561, 2), (28561, 37)])
+@pytest.mark.parametrize("N,batch", [(59049, 9), (177147, 5), (531441, 3), (78125, 13), (390625, 3), (117649, 9), (161051, 7), (1771561, 2), (28561, 37)])
 def test_fused_fourstep_of_non_power_of_two_lengths_on_device(run, oracle, product_lib, monkeypatch, N, batch):
     """kernel_mix_fused.h on the device: every registered length against the double truth, ONE launch per direction, and against the separate Four-Step passes
     it replaces (VKFFT_MI355X_MIXFUSED=0: the same factors in the same order, so the two agree to rounding)"""
@@ -380,7 +380,7 @@ def test_long_mixed_radix_rows_in_one_pass_on_device(run, oracle, product_lib, m
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("N,queues,lag,ring", [(59049, 3, 1, 4), (59049, 8, 0, 0), (390625, 5, 1, 4), (161051, 7, 1, 3), (14641, 6, 1, 4)])
+@pytest.mark.parametrize("N,queues,lag,ring", [(59049, 3, 1, 4), (59049, 8, 0, 0), (390625, 5, 1, 4), (161051, 7, 1, 3), (28561, 6, 1, 4)])
 def test_fused_fourstep_of_non_power_of_two_lengths_many_launches(product_lib, monkeypatch, N, queues, lag, ring):
     """the ticket / ring machinery of kernel_mix_fused.h under load: chip-filling batches, queue counts that do not divide the 8 XCDs (most workgroups finish on a
     queue that is not theirs), the shortest lag, 60 forward + inverse pairs with the zig-zag sweep — every round trip must return the input"""
@@ -433,7 +433,7 @@ def _prime_without_rader_form_below(M):
     return n
 
 
-@pytest.mark.parametrize("M,batch", [(30720, 67), (1 << 15, 33), (43008, 41), (1 << 16, 9), (1 << 17, 9), (1 << 18, 5), (1 << 19, 3), (1 << 20, 3), (1049760, 5)])
+@pytest.mark.parametrize("M,batch", [(30720, 67), (43008, 41), (1 << 16, 9), (1 << 17, 9), (1 << 18, 5), (1 << 19, 3), (1 << 20, 3), (1049760, 5)])
 def test_chirp_z_in_two_fused_launches_on_device(run, oracle, product_lib, monkeypatch, M, batch):
     """the two-launch chirp-z plan (kernel_mix_fused.h with the MixFusedOps hooks) on the device: every registered padded length with the largest prime below it that has
     no Rader form, several transforms per launch, against the double truth, the round trip, and against the 3 / 5 separate passes of round 2 (VKFFT_MI355X_MIXFUSED=0)"""

@@ -18,6 +18,8 @@ cp("config34.jsonl", "r06_config34_with_reference_same_call.jsonl")
 cp("gpu_suite.log", "r06_gpu_suite.log")
 cp("mix_fused_with_reference.jsonl", "r06_mix_fused_final_with_reference.jsonl")
 cp("mix_fused_separate_passes.jsonl", "r06_mix_fused_final_separate_passes_same_call.jsonl")
+cp("long_rows_with_reference.jsonl", "r06_long_rows_one_pass_with_reference.jsonl")
+cp("long_rows_two_passes.jsonl", "r06_long_rows_two_passes_same_call.jsonl")
 # kernel stats of the bench line + PMC traffic (power-of-two plans by_log2N, fused non-power-of-two plans by_length)
 for d in ("pmc_fetch", "pmc_write"):
     pass
@@ -30,7 +32,7 @@ tmp2 = os.path.join(ROOT, "gpurun_out", sub + "_mf"); shutil.rmtree(tmp2, ignore
 if os.path.isdir(os.path.join(G, "prof_mixfused")):
     shutil.copytree(os.path.join(G, "prof_mixfused"), os.path.join(tmp2, "prof_mixfused"))
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_profiles.py"), "r06tmp", sub + "_mf", "mix_fused_kernel_stats",
-                           "python tools/pmc_mixrad.py 59049 177147 531441 15625 78125 390625 117649 14641 161051 1771561 28561"], stdout=subprocess.DEVNULL)
+                           "python tools/pmc_mixrad.py 59049 177147 531441 78125 390625 117649 161051 1771561 28561"], stdout=subprocess.DEVNULL)
     if os.path.exists(os.path.join(P, "r06tmp_mix_fused_kernel_stats.csv")): os.replace(os.path.join(P, "r06tmp_mix_fused_kernel_stats.csv"), os.path.join(P, "r06_mix_fused_kernel_stats.csv"))
 pj = json.load(open(os.path.join(P, "r06_pmc_traffic.json")))
 print("pmc sources", pj.get("source_hash"), "by_log2N", sorted(pj.get("by_log2N", {}), key=int), "by_length", {k: v["ratio"] for k, v in pj.get("by_length", {}).items()})

@@ -24,7 +24,7 @@ for k in ks:
         app.forward(); app.inverse()
     torch.cuda.synchronize()
     app.delete()
-MIX = [59049, 177147, 531441, 15625, 78125, 390625, 117649, 14641, 161051, 1771561, 28561]
+MIX = [59049, 177147, 531441, 78125, 390625, 117649, 161051, 1771561, 28561]
 if not sys.argv[1:]:
     for N in MIX:
         app = api.App([N], (1 << 25) // N, buffer_ptr=buf.data_ptr(), normalize=True)

@@ -37,15 +37,12 @@ static const MixFusedVariant kMixFusedVariants[] = {
 	VKFFT_MXF2(9, 9, 3, 1, 27, 32, 9, 9, 3, 1, 27, 32, 4),     // 3^10 = 243 x 243
 	VKFFT_MXFP(float, false, 9, 9, 9, 1, 81, 8, 9, 9, 3, 1, 27, 24, 2, 0, 10, 2, 0), // 3^11 = 729 x 243 — one tile at a time, two workgroups per CU (+ 6 / + 13 % over the pipelined form)
 	VKFFT_MXF2(9, 9, 9, 1, 81, 8, 9, 9, 9, 1, 81, 8, 1),       // 3^12 = 729 x 729
-	// powers of five (5^6 ... 5^8)
-	VKFFT_MXF2(5, 5, 5, 1, 25, 16, 5, 5, 5, 1, 25, 16, 4),     // 5^6 = 125 x 125
+	// powers of five (5^7, 5^8; 5^6 = 15625, 7^5 and 11^4 run as ONE pass of the long mixed-radix rows, mixed_table_6.inc: 2.9-3.3 against 1.9-2.4 TB/s fused)
 	VKFFT_MXFP(float, false, 5, 5, 5, 5, 125, 8, 5, 5, 5, 1, 25, 40, 2, 0, 10, 2, 0), // 5^7 = 625 x 125 — one tile at a time, two workgroups per CU (+ 6 / + 13 % over the pipelined form)
 	VKFFT_MXF2(5, 5, 5, 5, 125, 8, 5, 5, 5, 5, 125, 8, 4),     // 5^8 = 625 x 625
-	// powers of seven (7^5, 7^6)
-	VKFFT_MXF2(7, 7, 7, 1, 49, 13, 7, 7, 1, 1, 7, 91, 4),      // 7^5 = 343 x 49 (four tiles of 13 columns / of 91)
+	// powers of seven (7^6)
 	VKFFT_MXF2(7, 7, 7, 1, 49, 16, 7, 7, 7, 1, 49, 16, 4),     // 7^6 = 343 x 343
 	// powers of eleven and thirteen (11^4 ... 11^6, 13^4)
-	VKFFT_MXF2(11, 11, 1, 1, 11, 32, 11, 11, 1, 1, 11, 32, 4), // 11^4 = 121 x 121
 	VKFFT_MXF2(11, 11, 11, 1, 121, 8, 11, 11, 1, 1, 11, 88, 4), // 11^5 = 1331 x 121
 	VKFFT_MXF2(11, 11, 11, 1, 121, 8, 11, 11, 11, 1, 121, 8, 4), // 11^6 = 1331 x 1331
 	VKFFT_MXF2(13, 13, 1, 1, 13, 32, 13, 13, 1, 1, 13, 32, 4), // 13^4 = 169 x 169
@@ -54,7 +51,6 @@ static const MixFusedVariant kMixFusedVariants[] = {
 	// ---- padded lengths M >= 2N - 1 of the chirp-z plan, ascending: the planner takes the smallest that fits.  Powers of two from 2^15 to 2^20 and the 7-smooth
 	// lengths right above 2N - 1 of the primes BASELINE config 3 names (15319 -> 30720, 21269 -> 43008, 524309 -> 1049760); radices up to 8 (12 in the last)
 	VKFFT_MXB(8, 5, 4, 1, 32, 16, 8, 8, 3, 1, 32, 16, 4),     // 30720 = 160 x 192
-	VKFFT_MXB(8, 4, 4, 1, 32, 16, 8, 8, 4, 1, 32, 16, 4),     // 2^15 = 128 x 256
 	VKFFT_MXB(8, 8, 3, 1, 32, 16, 8, 7, 4, 1, 32, 16, 4),     // 43008 = 192 x 224
 	VKFFT_MXB(8, 8, 4, 1, 32, 16, 8, 8, 4, 1, 32, 16, 4),     // 2^16 = 256 x 256
 	VKFFT_MXB(8, 8, 4, 1, 32, 32, 8, 8, 8, 1, 64, 16, 4),     // 2^17 = 256 x 512
