@@ -24,13 +24,22 @@ cp("long_rows_two_passes.jsonl", "r06_long_rows_two_passes_same_call.jsonl")
 for d in ("pmc_fetch", "pmc_write"):
     pass
 tmp = os.path.join(ROOT, "gpurun_out", sub + "_pmc"); shutil.rmtree(tmp, ignore_errors=True); os.makedirs(tmp)
+def newest_only(src, dst):
+    # (gpurun MERGES a call's files into gpurun_out/: an earlier call's CSVs — other process ids in their names — are still there; keep the newest of each kind)
+    import glob, re
+    os.makedirs(dst, exist_ok=True)
+    kinds = {}
+    for f in glob.glob(os.path.join(src, "**", "*.csv"), recursive=True):
+        k = re.sub(r"^\d+_", "", os.path.basename(f))
+        if k not in kinds or os.path.getmtime(f) > os.path.getmtime(kinds[k]): kinds[k] = f
+    for k, f in kinds.items(): shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 for d in ("prof_bench", "pmc_fetch", "pmc_write"):
-    if os.path.isdir(os.path.join(G, d)): shutil.copytree(os.path.join(G, d), os.path.join(tmp, d))
+    if os.path.isdir(os.path.join(G, d)): newest_only(os.path.join(G, d), os.path.join(tmp, d))
 if os.path.exists(os.path.join(G, "pmc_source_hash.txt")): shutil.copy(os.path.join(G, "pmc_source_hash.txt"), tmp)
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_profiles.py"), "r06", sub + "_pmc"], stdout=subprocess.DEVNULL)
 tmp2 = os.path.join(ROOT, "gpurun_out", sub + "_mf"); shutil.rmtree(tmp2, ignore_errors=True); os.makedirs(tmp2)
 if os.path.isdir(os.path.join(G, "prof_mixfused")):
-    shutil.copytree(os.path.join(G, "prof_mixfused"), os.path.join(tmp2, "prof_mixfused"))
+    newest_only(os.path.join(G, "prof_mixfused"), os.path.join(tmp2, "prof_mixfused"))
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "summarize_profiles.py"), "r06tmp", sub + "_mf", "mix_fused_kernel_stats",
                            "python tools/pmc_mixrad.py 59049 177147 531441 78125 390625 117649 161051 1771561 28561"], stdout=subprocess.DEVNULL)
     if os.path.exists(os.path.join(P, "r06tmp_mix_fused_kernel_stats.csv")): os.replace(os.path.join(P, "r06tmp_mix_fused_kernel_stats.csv"), os.path.join(P, "r06_mix_fused_kernel_stats.csv"))

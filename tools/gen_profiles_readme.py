@@ -75,6 +75,21 @@ Real rows, geometric mean of (reference pair time ÷ our pair time), the referen
 | sweep | lengths | round {rnd - 1} | **round {rnd}** | lengths below 0.5 × | worst length | by kernel (count: geometric mean) | file |
 |---|---|---|---|---|---|---|---|
 {rr}"""
+# ---- two-pass plans replaced this round: fused Four-Step of non-power-of-two lengths, long rows in one pass
+def two_col(title, cur, base, label_cur, label_base):
+    if not (os.path.exists(f"{P}/{cur}") and os.path.exists(f"{P}/{base}")): return ""
+    a = {r["shape"][0]: r for r in jl(cur) if "alg_GBps" in r}; b = {r["shape"][0]: r for r in jl(base) if "alg_GBps" in r}
+    t = f"\n{title} (alg. GB/s of a forward + inverse pair, 2^25 points; `{cur}`, `{base}`, same gpurun call):\n\n| N | {label_base} | **{label_cur}** | gain | reference, same process | ratio to the reference | fraction of 8 TB/s |\n|---|---|---|---|---|---|---|\n"
+    for n, r in a.items():
+        ref = r.get("ref_alg_GBps")
+        t += f"| {n} | {round(b[n]['alg_GBps']) if n in b else ''} | **{round(r['alg_GBps'])}** | {r['alg_GBps'] / b[n]['alg_GBps']:.2f} | {round(ref) if ref else ''} | {r['alg_GBps'] / ref:.2f} | {r['alg_GBps'] / 8000:.2f} |\n" if n in b and ref else ""
+    return t
+out += two_col("Fused Four-Step of non-power-of-two two-factor lengths (`kernel_mix_fused.h`, DESIGN §4.15) against the separate passes", f"{tag}_mix_fused_final_with_reference.jsonl", f"{tag}_mix_fused_final_separate_passes_same_call.jsonl", "one fused launch", "separate passes")
+out += two_col("Rows of 8192 … 16807 points in ONE pass (`mixed_table_6.inc`, DESIGN §4.4a) against the two-pass plans", f"{tag}_long_rows_one_pass_with_reference.jsonl", f"{tag}_long_rows_two_passes_same_call.jsonl", "one pass", "two passes")
+if os.path.exists(f"{P}/{tag}_pmc_traffic.json"):
+    bl = json.load(open(f"{P}/{tag}_pmc_traffic.json")).get("by_length", {})
+    if bl:
+        out += "\nL2 ↔ fabric traffic of the fused non-power-of-two launches (`" + tag + "_pmc_traffic.json` `by_length`; bytes per launch ÷ algorithmic bytes, Infinity-Cache hits of the ring included): " + ", ".join(f"{n}: {v['ratio']:.2f}" for n, v in sorted(bl.items(), key=lambda kv: int(kv[0]))) + ".\n"
 # ---- every other file of the round: its first comment / note, by name
 notes = json.load(open(f"{P}/{tag}_files.json")) if os.path.exists(f"{P}/{tag}_files.json") else {}
 files = sorted(os.path.basename(x) for x in glob.glob(f"{P}/{tag}_*") if not x.endswith("_files.json"))
