@@ -413,7 +413,7 @@ def test_fused_fourstep_of_non_power_of_two_lengths(run, oracle, monkeypatch, N,
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
 
 
-@pytest.mark.parametrize("N,batch", [(9000, 3), (10000, 2), (10240, 3), (12000, 2), (12288, 3), (14641, 3), (15000, 2), (15360, 3), (15625, 2), (16000, 2), (16807, 3)])
+@pytest.mark.parametrize("N,batch", [(8232, 3), (9000, 3), (10000, 2), (10080, 3), (12000, 2), (12288, 3), (13125, 2), (14641, 3), (15000, 2), (15625, 2), (16128, 2), (16384 - 184, 2), (16807, 3)])
 def test_long_mixed_radix_rows_in_one_pass(run, oracle, N, batch):
     """9000 ... 16000, 11^4, 5^6, 7^5: one pass of mixed_row_kernel with the whole row in one LDS buffer (mixed_table_6.inc; two butterflies per thread for 11^4, three for 7^5), where the
     generated table stops at 8192 points and the Four-Step plan takes two passes"""

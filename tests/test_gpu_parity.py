@@ -360,7 +360,7 @@ def test_fused_fourstep_of_non_power_of_two_lengths_on_device(run, oracle, produ
     assert rel_l2(y, y2.astype(np.complex128)) < 5e-7
 
 
-@pytest.mark.parametrize("N,batch", [(9000, 400), (10000, 301), (10240, 257), (12000, 300), (12288, 259), (14641, 517), (15000, 263), (15360, 257), (15625, 301), (16000, 263), (16807, 259)])
+@pytest.mark.parametrize("N,batch", [(8232, 400), (9000, 400), (10000, 301), (10080, 257), (12000, 300), (12288, 259), (13125, 263), (14641, 517), (15000, 263), (15625, 301), (16128, 257), (16200, 263), (16807, 259)])
 def test_long_mixed_radix_rows_in_one_pass_on_device(run, oracle, product_lib, monkeypatch, N, batch):
     """11^4, 5^6, 7^5 as ONE pass of mixed_row_kernel (mixed_table_6.inc: the whole row in one LDS buffer of 117-151 KB), chip-filling batches, against the double truth,
     the round trip and the fused Four-Step launch of the same length (VKFFT_MI355X_LONGROWS=0)"""
