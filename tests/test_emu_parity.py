@@ -429,6 +429,25 @@ def test_long_mixed_radix_rows_in_one_pass(run, oracle, N, batch):
     assert rel_l2(z, x.astype(np.complex128) * N) < 2e-6
 
 
+@pytest.mark.parametrize("kind,N,type,dst", [("r2c", 8400, 0, False), ("r2c", 16464, 0, False), ("r2c", 20000, 0, False), ("r2c", 30000, 0, False), ("r2c", 10125, 0, False),
+                                             ("r2r", 10080, 2, False), ("r2r", 8400, 2, True), ("r2r", 12000, 3, False), ("r2r", 16200, 4, False), ("r2r", 10125, 4, True), ("r2r", 14406, 2, False)])
+def test_real_transforms_on_the_long_rows(run, oracle, kind, N, type, dst):
+    """real transforms whose complex length is one of the long rows (8193 ... 16807 points, tools/gen_long_rows_table.py): ONE launch of mixed_row_kernel between the
+    table-driven maps where the real planners stopped at 8192 points and fell to the interpreter's multi-pass plans — R2C of even lengths on the half-length form (the long
+    rows keep it: no full-length pairs), odd R2C and DCT / DST II-IV on the full-length forms"""
+    if kind == "r2c":
+        parity.check_r2c(run, oracle, (N,), 2, False)
+        kw = dict(r2c=True)
+    else:
+        parity.check_r2r(run, oracle, (N,), 2, False, type, dst)
+        kw = dict(dst=type) if dst else dict(dct=type)
+    h, ptr = run._alloc(np.zeros(2 * (N + 2) * 2, np.float32))
+    app = api.App([N], 2, buffer_ptr=ptr, lib=run.lib, **kw)
+    n, names = app.launch_info(False)
+    app.delete()
+    assert n == 1 and names.startswith("mixed_row_kernel"), (n, names)
+
+
 @pytest.mark.parametrize("N,batch,chunk_kib,lag,ring,queues,shape", [(59049, 7, 512, 2, 3, 1, 0), (59049, 11, 1024, 1, 2, 4, 0), (28561, 37, 256, 2, 3, 8, 0), (28561, 21, 128, 1, 2, 3, 0), (531441, 3, 4096, 1, 2, 1, 0), (177147, 5, 2048, 1, 2, 2, 0), (78125, 7, 512, 2, 3, 3, 0)])
 def test_fused_fourstep_of_non_power_of_two_lengths_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag, ring, queues, shape):
     """the same kernel under forced chunk sizes, lags, rings and queue counts (ring slots reused, a partial last chunk, queues that are helped, the reversed sweep of

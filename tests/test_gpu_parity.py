@@ -379,6 +379,25 @@ def test_long_mixed_radix_rows_in_one_pass_on_device(run, oracle, product_lib, m
     assert up2 == [2] and rel_l2(y, y2.astype(np.complex128)) < 5e-7
 
 
+@pytest.mark.parametrize("kind,N,type,dst", [("r2c", 8400, 0, False), ("r2c", 16464, 0, False), ("r2c", 20000, 0, False), ("r2c", 30000, 0, False), ("r2c", 10125, 0, False),
+                                             ("r2r", 10080, 2, False), ("r2r", 8400, 2, True), ("r2r", 12000, 3, False), ("r2r", 16200, 4, False), ("r2r", 10125, 4, True), ("r2r", 14406, 2, False)])
+def test_real_transforms_on_the_long_rows_on_device(run, oracle, product_lib, kind, N, type, dst):
+    """real transforms whose complex length is one of the long rows (8193 ... 16807 points, tools/gen_long_rows_table.py): ONE launch of mixed_row_kernel between the
+    table-driven maps where the real planners stopped at 8192 points and fell to the interpreter's multi-pass plans — R2C of even lengths on the half-length form (the long
+    rows keep it: no full-length pairs), odd R2C and DCT / DST II-IV on the full-length forms"""
+    if kind == "r2c":
+        parity.check_r2c(run, oracle, (N,), 300, False)
+        kw = dict(r2c=True)
+    else:
+        parity.check_r2r(run, oracle, (N,), 300, False, type, dst)
+        kw = dict(dst=type) if dst else dict(dct=type)
+    h, ptr = run._alloc(np.zeros(2 * (N + 2) * 2, np.float32))
+    app = api.App([N], 2, buffer_ptr=ptr, lib=product_lib, **kw)
+    n, names = app.launch_info(False)
+    app.delete()
+    assert n == 1 and names.startswith("mixed_row_kernel"), (n, names)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("N,queues,lag,ring", [(59049, 3, 1, 4), (59049, 8, 0, 0), (390625, 5, 1, 4), (161051, 7, 1, 3), (28561, 6, 1, 4)])
 def test_fused_fourstep_of_non_power_of_two_lengths_many_launches(product_lib, monkeypatch, N, queues, lag, ring):

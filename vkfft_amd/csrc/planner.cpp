@@ -1990,8 +1990,15 @@ static uint64_t pairable_rows(const std::vector<HostDim>& others) {
 	}
 	return c;
 }
+// a unit-stride fp32 row longer than the two-buffer single-pass limit that has one of the long instances of tools/gen_long_rows_table.py (one LDS buffer, one workgroup per CU)
+static bool long_row_instance(const TransformDesc& d, uint64_t L, bool dp) {
+	if (dp || d.disableFastKernels || L <= max_row_len(dp, d.maxLds) || L > 16807 || (getenv("VKFFT_MI355X_LONGROWS") && atoi(getenv("VKFFT_MI355X_LONGROWS")) == 0)) return false;
+	int v, r5[5], f, t;
+	return mixed_row_lookup(L, dp, &v, r5, &f, &t);
+}
 static bool prefer_full_length_pairs(const TransformDesc& d, uint64_t N, bool unit, uint64_t rows, uint32_t preHalf, uint32_t postHalf, uint64_t halfLen) {
 	const int mode = getenv("VKFFT_MI355X_EVEN_FULL") ? atoi(getenv("VKFFT_MI355X_EVEN_FULL")) : 1;
+	if (N > max_row_len(d.dp, d.maxLds)) return false; // (the long rows keep their half-length forms: one workgroup per CU is no place for twice the points)
 	if (!mode || d.disableFastKernels || !unit || rows < 2 || getenv("VKFFT_MI355X_NO_TMAPS") || getenv("VKFFT_MI355X_NO_ROW_PAIRS") || getenv("VKFFT_MI355X_NO_MIXED_OPS")) return false;
 	int v, r5[5], f, t;
 	// (eight: the plain sides of R2C / C2R then move directly, kernel_mixed.h DIRECT; round 6: or the full length runs on the Rader-stage kernel, whose maps are the
@@ -2113,7 +2120,7 @@ static int plan_r2c_axis0_fused(const TransformDesc& d, bool inverse, const std:
 		if (!inverse) { h.inStride = rs; h.outStride = cs; } else { h.inStride = cs; h.outStride = rs; }
 		dims.push_back(h);
 	}
-	if (b.L > max_row_len(dp, d.maxLds)) {
+	if (b.L > max_row_len(dp, d.maxLds) && !(!blueM && !padReal && long_row_instance(d, b.L, dp))) {
 		// long even rows: multi-pass half-length complex FFT + the pair pass of the even decomposition
 		// (reference: VkFFTPlanR2CMultiUploadDecomposition, vkFFT_Plan_R2C.h:30; kernel vkFFT_R2C_even_decomposition.h:40)
 		if (!even) {
@@ -2355,7 +2362,7 @@ static int plan_r2r_axis_fused(const TransformDesc& d, int type, bool dst, uint6
 		b.fastKernel = KERNEL_POW2_BLUE_R2R; b.fastVariant = variant; b.fastThreads = thr; b.forceT = (uint32_t)fpw;
 		b.radices.clear();
 		for (int k = 0; k < 4; k++) if (bits[k]) b.radices.push_back(1u << bits[k]);
-	} else if (b.L > (unit ? max_row_len(dp, d.maxLds) : max_col_len(dp, d.maxLds, 1))) {
+	} else if (b.L > (unit ? max_row_len(dp, d.maxLds) : max_col_len(dp, d.maxLds, 1)) && !(unit && long_row_instance(d, b.L, dp))) {
 		// longer than one pass: the full-length form of the real transform through a multi-pass (Four-Step) complex FFT of the
 		// embedding length; the first load / last store apply the pre / post map to the row by natural index (the reference
 		// lifts the same limit: vkFFT_Scheduler.h:2894-2897)
