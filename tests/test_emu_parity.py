@@ -448,6 +448,22 @@ def test_real_transforms_on_the_long_rows(run, oracle, kind, N, type, dst):
     assert n == 1 and names.startswith("mixed_row_kernel"), (n, names)
 
 
+@pytest.mark.parametrize("N", [4116, 4200, 5040, 5625, 6300, 6561, 7203, 7560, 8000, 8064])
+def test_fp64_rows_of_4097_to_8192_points_in_one_pass(run, oracle, N):
+    """double precision: the two-buffer single-pass limit is 4096 points, a row of up to 8192 fits ONE LDS buffer — instances of mixed_row_kernel<double> for every 7-smooth length
+    of that range (mixed_table_15 / 16.inc) where the interpreter ran two passes; complex rows, and R2C / DCT-II rows whose complex length is one of them"""
+    up = parity.check_c2c(run, oracle, (N,), 2, True, use_c_oracle=False)
+    assert up == [1]
+    h, ptr = run._alloc(np.zeros(4 * N, np.complex128))
+    app = api.App([N], 2, dp=True, buffer_ptr=ptr, lib=run.lib)
+    n, names = app.launch_info(False)
+    app.delete()
+    assert n == 1 and names.startswith("mixed_row_kernel<double>"), (n, names)
+    if N in (5040, 6300):
+        parity.check_r2c(run, oracle, (2 * N,), 2, True)
+        parity.check_r2r(run, oracle, (N,), 2, True, 2, False)
+
+
 @pytest.mark.parametrize("N,batch,chunk_kib,lag,ring,queues,shape", [(59049, 7, 512, 2, 3, 1, 0), (59049, 11, 1024, 1, 2, 4, 0), (28561, 37, 256, 2, 3, 8, 0), (28561, 21, 128, 1, 2, 3, 0), (531441, 3, 4096, 1, 2, 1, 0), (177147, 5, 2048, 1, 2, 2, 0), (78125, 7, 512, 2, 3, 3, 0)])
 def test_fused_fourstep_of_non_power_of_two_lengths_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag, ring, queues, shape):
     """the same kernel under forced chunk sizes, lags, rings and queue counts (ring slots reused, a partial last chunk, queues that are helped, the reversed sweep of

@@ -398,6 +398,31 @@ def test_real_transforms_on_the_long_rows_on_device(run, oracle, product_lib, ki
     assert n == 1 and names.startswith("mixed_row_kernel"), (n, names)
 
 
+def _fp64_long_row_lengths():
+    import glob, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(root, "vkfft_amd", "csrc", "mixed_table_1[56].inc"))))
+    return sorted(set(int(m) for m in re.findall(r"// N=(\d+)", txt)))
+
+
+@pytest.mark.parametrize("part", range(4))
+def test_fp64_rows_of_4097_to_8192_points_in_one_pass_on_device(run, oracle, product_lib, part):
+    """every fp64 instance of mixed_table_15 / 16.inc (7-smooth rows of 4097 ... 8192 points in one LDS buffer) on the device: chip-filling batches against the long-double truth
+    and the round trip; R2C / DCT-II of two of them"""
+    for N in _fp64_long_row_lengths()[part::4]:
+        up = parity.check_c2c(run, oracle, (N,), 600, True, use_c_oracle=False)
+        assert up == [1], N
+    if part == 0:
+        for N in (5040, 6300):
+            parity.check_r2c(run, oracle, (2 * N,), 300, True)
+            parity.check_r2r(run, oracle, (N,), 300, True, 2, False)
+    h, ptr = run._alloc(np.zeros(4 * 5040, np.complex128))
+    app = api.App([5040], 2, dp=True, buffer_ptr=ptr, lib=product_lib)
+    n, names = app.launch_info(False)
+    app.delete()
+    assert n == 1 and names.startswith("mixed_row_kernel<double>"), (n, names)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("N,queues,lag,ring", [(59049, 3, 1, 4), (59049, 8, 0, 0), (390625, 5, 1, 4), (161051, 7, 1, 3), (28561, 6, 1, 4)])
 def test_fused_fourstep_of_non_power_of_two_lengths_many_launches(product_lib, monkeypatch, N, queues, lag, ring):

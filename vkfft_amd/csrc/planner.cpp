@@ -1801,10 +1801,10 @@ static int plan_c2c_axis(const TransformDesc& d, const AxisJob& j, Arena& ar, Di
 	// ... and the hand-written long rows of the mixed-radix family (mixed_table_6.inc: 11^4, 5^6, 7^5 in ONE LDS buffer of 117-151 KB, one workgroup per CU): one pass where
 	// the Four-Step plan would take two (VKFFT_MI355X_LONGROWS=0: the fused Four-Step launch of kernel_mix_fused.h instead)
 	bool mixLongOK = false;
-	if (unit && !padded && !dp && !d.disableFastKernels && (j.N & (j.N - 1)) != 0 && j.N > singleCap && j.N <= 16807 && !(getenv("VKFFT_MI355X_LONGROWS") && atoi(getenv("VKFFT_MI355X_LONGROWS")) == 0)) {
+	if (unit && !padded && !d.disableFastKernels && (j.N & (j.N - 1)) != 0 && j.N > singleCap && j.N <= (dp ? 8192u : 16807u) && !(getenv("VKFFT_MI355X_LONGROWS") && atoi(getenv("VKFFT_MI355X_LONGROWS")) == 0)) {
 		int variant, rad5[5], fpw, thr;
 		const uint64_t rowPitch = j.others.empty() ? j.N : (uint64_t)std::max<int64_t>(std::llabs(j.others[0].inStride), std::llabs(j.others[0].outStride));
-		mixLongOK = (rowPitch * 64 + j.N) * 8 < 0x7FFFFF00ull && mixed_row_lookup(j.N, dp, &variant, rad5, &fpw, &thr);
+		mixLongOK = (rowPitch * 64 + j.N) * (dp ? 16 : 8) < 0x7FFFFF00ull && mixed_row_lookup(j.N, dp, &variant, rad5, &fpw, &thr);
 	}
 	if (j.N <= singleCap || p2rowOK || mixLongOK) {
 		b.L = j.N;
@@ -1992,7 +1992,7 @@ static uint64_t pairable_rows(const std::vector<HostDim>& others) {
 }
 // a unit-stride fp32 row longer than the two-buffer single-pass limit that has one of the long instances of tools/gen_long_rows_table.py (one LDS buffer, one workgroup per CU)
 static bool long_row_instance(const TransformDesc& d, uint64_t L, bool dp) {
-	if (dp || d.disableFastKernels || L <= max_row_len(dp, d.maxLds) || L > 16807 || (getenv("VKFFT_MI355X_LONGROWS") && atoi(getenv("VKFFT_MI355X_LONGROWS")) == 0)) return false;
+	if (d.disableFastKernels || L <= max_row_len(dp, d.maxLds) || L > (dp ? 8192u : 16807u) || (getenv("VKFFT_MI355X_LONGROWS") && atoi(getenv("VKFFT_MI355X_LONGROWS")) == 0)) return false;
 	int v, r5[5], f, t;
 	return mixed_row_lookup(L, dp, &v, r5, &f, &t);
 }
