@@ -448,10 +448,10 @@ def test_real_transforms_on_the_long_rows(run, oracle, kind, N, type, dst):
     assert n == 1 and names.startswith("mixed_row_kernel"), (n, names)
 
 
-@pytest.mark.parametrize("N", [4116, 4200, 5040, 5625, 6300, 6561, 7203, 7560, 8000, 8064])
+@pytest.mark.parametrize("N", [4116, 4200, 5040, 5625, 6300, 6561, 7203, 7560, 8000, 8064, 4158, 4225, 5005, 6006, 6591, 7007, 8190])
 def test_fp64_rows_of_4097_to_8192_points_in_one_pass(run, oracle, N):
-    """double precision: the two-buffer single-pass limit is 4096 points, a row of up to 8192 fits ONE LDS buffer — instances of mixed_row_kernel<double> for every 7-smooth length
-    of that range (mixed_table_15 / 16.inc) where the interpreter ran two passes; complex rows, and R2C / DCT-II rows whose complex length is one of them"""
+    """double precision: the two-buffer single-pass limit is 4096 points, a row of up to 8192 fits ONE LDS buffer — instances of mixed_row_kernel<double> for every 13-smooth length
+    of that range (mixed_table_15 ... 19.inc) where the interpreter ran two passes; complex rows, and R2C / DCT-II rows whose complex length is one of them"""
     up = parity.check_c2c(run, oracle, (N,), 2, True, use_c_oracle=False)
     assert up == [1]
     h, ptr = run._alloc(np.zeros(4 * N, np.complex128))

@@ -66,7 +66,7 @@ int launch_pass(const PassPlan& pp, const PassParams& prm, hipStream_t stream) {
 }
 
 // ---- mixed-radix registry: six table parts, one translation unit each (kernels_mixed_*.hip) --------------------
-constexpr int kMixedParts = 17; // (parts 6-8: tools/gen_long_rows_table.py — the long rows; the 7-smooth lengths of 4097 ... 8192 points outside the first six tables)
+constexpr int kMixedParts = 20; // (parts 6-8: tools/gen_long_rows_table.py — the long rows; the 7-smooth lengths of 4097 ... 8192 points outside the first six tables)
 const MixedVariant* mixed_table_0(int*);
 const MixedVariant* mixed_table_1(int*);
 const MixedVariant* mixed_table_2(int*);
@@ -84,9 +84,12 @@ const MixedVariant* mixed_table_13(int*);
 const MixedVariant* mixed_table_14(int*);
 const MixedVariant* mixed_table_15(int*);
 const MixedVariant* mixed_table_16(int*);
+const MixedVariant* mixed_table_17(int*);
+const MixedVariant* mixed_table_18(int*);
+const MixedVariant* mixed_table_19(int*);
 static const MixedVariant* mixed_part(int part, int* count) {
 	typedef const MixedVariant* (*Fn)(int*);
-	static const Fn fns[kMixedParts] = {&mixed_table_0, &mixed_table_1, &mixed_table_2, &mixed_table_3, &mixed_table_4, &mixed_table_5, &mixed_table_6, &mixed_table_7, &mixed_table_8, &mixed_table_9, &mixed_table_10, &mixed_table_11, &mixed_table_12, &mixed_table_13, &mixed_table_14, &mixed_table_15, &mixed_table_16};
+	static const Fn fns[kMixedParts] = {&mixed_table_0, &mixed_table_1, &mixed_table_2, &mixed_table_3, &mixed_table_4, &mixed_table_5, &mixed_table_6, &mixed_table_7, &mixed_table_8, &mixed_table_9, &mixed_table_10, &mixed_table_11, &mixed_table_12, &mixed_table_13, &mixed_table_14, &mixed_table_15, &mixed_table_16, &mixed_table_17, &mixed_table_18, &mixed_table_19};
 	return fns[part % kMixedParts](count);
 }
 bool mixed_row_lookup(uint64_t n, bool dp, int* variant, int rad[5], int* fpw, int* threads) {
