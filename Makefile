@@ -7,7 +7,7 @@ LIBDIR := vkfft_amd/lib
 CXXFLAGS := -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I$(CSRC) -Wno-unused-result --offload-compress
 OBJS := build/obj/api.o build/obj/planner.o build/obj/kernels.o build/obj/kernels_pow2.o build/obj/kernels_blue_r2r.o build/obj/kernels_fused.o build/obj/kernels_mixfused.o build/obj/kernels_aux.o build/obj/kernels_mixed_0.o build/obj/kernels_mixed_1.o build/obj/kernels_mixed_2.o build/obj/kernels_mixed_3.o build/obj/kernels_mixed_4.o build/obj/kernels_mixed_5.o build/obj/kernels_mixed_6.o build/obj/kernels_mixed_7.o build/obj/kernels_mixed_8.o build/obj/kernels_mixed_9.o build/obj/kernels_mixed_10.o build/obj/kernels_mixed_11.o build/obj/kernels_mixed_12.o build/obj/kernels_mixed_13.o build/obj/kernels_mixed_14.o build/obj/kernels_mixed_15.o build/obj/kernels_mixed_16.o build/obj/kernels_mixed_17.o build/obj/kernels_mixed_18.o build/obj/kernels_mixed_19.o \
         build/obj/kernels_mixconv_0.o build/obj/kernels_mixconv_1.o build/obj/kernels_mixconv_2.o build/obj/kernels_mixconv_3.o build/obj/kernels_mixconv_4.o build/obj/kernels_mixconv_5.o \
-        $(foreach t,f32_row f32_col f64_row f64_col,build/obj/kernels_opfft_$(t)_0.o build/obj/kernels_opfft_$(t)_1.o)
+        $(foreach t,f32_row f32_col f64_row f64_col,build/obj/kernels_opfft_$(t)_0.o build/obj/kernels_opfft_$(t)_1.o) build/obj/kernels_opfft_f32_col_2.o
 # header dependencies come from the compiler (-MMD): a change to one kernel family rebuilds only the translation units that include it
 DEPFLAGS = -MMD -MP -MF build/obj/$*.d
 

@@ -464,6 +464,28 @@ def test_fp64_rows_of_4097_to_8192_points_in_one_pass(run, oracle, N):
         parity.check_r2r(run, oracle, (N,), 2, True, 2, False)
 
 
+def test_dst1_of_1782_reals_rader_stage_without_geometry(run, oracle):
+    """regression (round 6): DST-I of 1782 reals embeds into 2 * 1783 complex points; 1783 is a Rader prime whose registry entry has no stage form (geometry 0), and
+    mixrad_choose divided by its group count — SIGFPE at initializeVkFFT.  Found by a scan of plan creation over every transform kind and length up to 8300
+    (no other length faults); the length now takes the fused Bluestein kernel"""
+    parity.check_r2r(run, oracle, (1782,), 2, False, 1, True)
+
+
+@pytest.mark.parametrize("kind", ["c2c", "r2c", "dct1", "dct2", "dct3", "dct4", "dst1", "dst2", "dst3", "dst4"])
+def test_plan_creation_of_sampled_lengths_every_kind(run, kind):
+    """initializeVkFFT + vkfftMI355XDescribePlan + deleteVkFFT for every 23rd length up to 8300 (and the neighbours of 1782 / 3566) of every transform kind: no plan may fault
+    or fail (the full scan, every length, ran once in round 6: tools-free, ten processes, two minutes)"""
+    kw = {"c2c": {}, "r2c": {"r2c": True}}.get(kind)
+    if kw is None:
+        kw = {kind[:3]: int(kind[3])}
+    h, ptr = run._alloc(np.zeros(4 * 8400, np.float32))
+    for N in sorted(set(list(range(2, 8300, 23)) + [1781, 1782, 1783, 3565, 3566, 3567])):
+        app = api.App([N], 2, buffer_ptr=ptr, lib=run.lib, **kw)
+        n, _ = app.launch_info(False)
+        app.delete()
+        assert n >= 1, (kind, N)
+
+
 @pytest.mark.parametrize("N,batch,chunk_kib,lag,ring,queues,shape", [(59049, 7, 512, 2, 3, 1, 0), (59049, 11, 1024, 1, 2, 4, 0), (28561, 37, 256, 2, 3, 8, 0), (28561, 21, 128, 1, 2, 3, 0), (531441, 3, 4096, 1, 2, 1, 0), (177147, 5, 2048, 1, 2, 2, 0), (78125, 7, 512, 2, 3, 3, 0)])
 def test_fused_fourstep_of_non_power_of_two_lengths_queue(run, oracle, monkeypatch, N, batch, chunk_kib, lag, ring, queues, shape):
     """the same kernel under forced chunk sizes, lags, rings and queue counts (ring slots reused, a partial last chunk, queues that are helped, the reversed sweep of

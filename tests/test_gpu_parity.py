@@ -423,6 +423,11 @@ def test_fp64_rows_of_4097_to_8192_points_in_one_pass_on_device(run, oracle, pro
     assert n == 1 and names.startswith("mixed_row_kernel<double>"), (n, names)
 
 
+def test_dst1_of_1782_reals_on_device(run, oracle):
+    """regression (round 6): DST-I of 1782 reals (2 * 1783 complex points, a Rader prime without the stage form) faulted at initializeVkFFT; see the emulator test of the same name"""
+    parity.check_r2r(run, oracle, (1782,), 64, False, 1, True)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("N,queues,lag,ring", [(59049, 3, 1, 4), (59049, 8, 0, 0), (390625, 5, 1, 4), (161051, 7, 1, 3), (28561, 6, 1, 4)])
 def test_fused_fourstep_of_non_power_of_two_lengths_many_launches(product_lib, monkeypatch, N, queues, lag, ring):

@@ -193,16 +193,16 @@ int launch_mixconv(const PassPlan& pp, const PassParams& prm, hipStream_t stream
 }
 
 // ---- op-FFT registry: eight table parts, one translation unit each (kernels_opfft_*.hip) ---------------------------
-#define VKFFT_OPFFT_PARTS(X) X(f32_row_0) X(f32_row_1) X(f32_col_0) X(f32_col_1) X(f64_row_0) X(f64_row_1) X(f64_col_0) X(f64_col_1)
+#define VKFFT_OPFFT_PARTS(X) X(f32_row_0) X(f32_row_1) X(f32_col_0) X(f32_col_1) X(f64_row_0) X(f64_row_1) X(f64_col_0) X(f64_col_1) X(f32_col_2) /* part 8: tools/gen_opfft_col_extra.py */
 #define VKFFT_DECL(t) const OpfftVariant* opfft_table_##t(int*);
 VKFFT_OPFFT_PARTS(VKFFT_DECL)
 #undef VKFFT_DECL
 static const OpfftVariant* opfft_part(int part, int* count) { // part = 2 * ((dp ? 2 : 0) + (col ? 1 : 0)) + half
 	typedef const OpfftVariant* (*Fn)(int*);
 #define VKFFT_REF(t) &opfft_table_##t,
-	static const Fn fns[8] = { VKFFT_OPFFT_PARTS(VKFFT_REF) };
+	static const Fn fns[9] = { VKFFT_OPFFT_PARTS(VKFFT_REF) };
 #undef VKFFT_REF
-	return fns[part & 7](count);
+	return fns[part >= 0 && part < 9 ? part : 0](count);
 }
 static uint32_t opfft_family(uint32_t op) { // DST members run on the DCT instance of their family
 	switch (op) {
@@ -216,8 +216,8 @@ static uint32_t opfft_family(uint32_t op) { // DST members run on the DCT instan
 }
 bool opfft_lookup(uint64_t n, bool dp, bool col, bool trans, uint32_t pre, uint32_t post, int* variant, int rad[5], int* fpw, int* threads) {
 	pre = opfft_family(pre); post = opfft_family(post);
-	for (int half = 0; half < 2; half++) {
-		const int part = 2 * ((dp ? 2 : 0) + (col ? 1 : 0)) + half;
+	for (int half = 0; half < ((!dp && col) ? 3 : 2); half++) {
+		const int part = half == 2 ? 8 : 2 * ((dp ? 2 : 0) + (col ? 1 : 0)) + half; // (fp32 column tiles have a third part)
 		int cnt = 0;
 		const OpfftVariant* tab = opfft_part(part, &cnt);
 		for (int i = 0; i < cnt; i++) {

@@ -203,6 +203,7 @@ static bool mixrad_choose(uint64_t L, bool dp, bool ops, MixradChoice& c) { // o
 	else if (!mixrad_split((uint32_t)M, A, B)) return false;
 	uint64_t len; int sp = 0, lutn = 0, groups = 0, gd = 0;
 	if (!mixconv_lookup(true, false, P, dp, &c.variant, &len, c.rad, &c.fpw, &c.threads) || !mixrad_geom(c.variant, &sp, &lutn, &groups, &gd)) return false;
+	if (gd <= 0 || sp <= 0) return false; // (an instance without the stage form — the registry leaves its geometry at zero: DST-I of 1782 reals, 2 * 1783 complex points, divided by it)
 	const uint64_t budget = (getenv("VKFFT_MI355X_MIXRAD_LDS_KIB") ? (uint64_t)atoll(getenv("VKFFT_MI355X_MIXRAD_LDS_KIB")) : 40ull) << 10;
 	const bool twoSets = ops && mixrad_two_sets((uint32_t)M, A);
 	c.P = P; c.M = M; c.A = A; c.len = len;
