@@ -428,6 +428,18 @@ def test_dst1_of_1782_reals_on_device(run, oracle):
     parity.check_r2r(run, oracle, (1782,), 64, False, 1, True)
 
 
+@pytest.mark.parametrize("N,dst", [(4153, False), (5001, False), (7927, True), (4449, True)])
+def test_dct4_dst4_of_odd_lengths_above_4096_on_device(run, oracle, product_lib, N, dst):
+    """regression (round 6, found by tools/scan_device_parity.py): odd DCT / DST-IV of 4097 ... 8192 reals reached the 16384-point fused Bluestein instance with the type-IV maps,
+    which returns wrong results ON THE DEVICE only (relative error 0.5-0.9; the emulator is right); those lengths take the maps as passes around the complex plan now"""
+    parity.check_r2r(run, oracle, (N,), 16, False, 4, dst)
+    h, ptr = run._alloc(np.zeros(N * 16, np.float32))
+    app = api.App([N], 16, buffer_ptr=ptr, lib=product_lib, **(dict(dst=4) if dst else dict(dct=4)))
+    n, names = app.launch_info(False)
+    app.delete()
+    assert not names.startswith("pow2_blue_r2r_kernel"), (n, names)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("N,queues,lag,ring", [(59049, 3, 1, 4), (59049, 8, 0, 0), (390625, 5, 1, 4), (161051, 7, 1, 3), (28561, 6, 1, 4)])
 def test_fused_fourstep_of_non_power_of_two_lengths_many_launches(product_lib, monkeypatch, N, queues, lag, ring):
