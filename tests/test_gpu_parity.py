@@ -440,6 +440,20 @@ def test_dct4_dst4_of_odd_lengths_above_4096_on_device(run, oracle, product_lib,
     assert not names.startswith("pow2_blue_r2r_kernel"), (n, names)
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kind", ["c2c", "r2c", "dct1", "dct2", "dct3", "dct4", "dst1", "dst2", "dst3", "dst4"])
+def test_sampled_lengths_of_every_kind_on_device(run, oracle, kind):
+    """the scan that found the wrong odd DCT / DST-IV above 4096 reals (tools/scan_device_parity.py), in reduced form: every 211th length up to 8300 (odd and even alternate) of every
+    transform kind, four transforms per plan, forward against the double truth and the round trip — whatever plan the planner picks for a length nobody listed"""
+    for N in range(9, 8300, 211):
+        if kind == "c2c":
+            parity.check_c2c(run, oracle, (N,), 4, False, kind="bluestein", use_c_oracle=False)
+        elif kind == "r2c":
+            parity.check_r2c(run, oracle, (N,), 4, False)
+        else:
+            parity.check_r2r(run, oracle, (N,), 4, False, int(kind[3]), kind.startswith("dst"))
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("N,queues,lag,ring", [(59049, 3, 1, 4), (59049, 8, 0, 0), (390625, 5, 1, 4), (161051, 7, 1, 3), (28561, 6, 1, 4)])
 def test_fused_fourstep_of_non_power_of_two_lengths_many_launches(product_lib, monkeypatch, N, queues, lag, ring):
